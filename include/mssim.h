@@ -1,0 +1,219 @@
+/*
+ * mssim.h -- C ABI of the MI355X-native batched rigid-body simulation core.
+ *
+ * This header is the drop-in boundary of the hot path: it is what a
+ * ManiSkill maintainer would bind behind `ManiSkillScene.px` in place of
+ * `sapien.physx.PhysxGpuSystem`.  Every entry point names the reference call site it replaces
+ * (paths relative to the reference checkout, mani_skill/...).
+ *
+ * Plain C: pointers and sizes only, no torch / C++ types.  All device pointers are raw HIP device
+ * pointers (e.g. `torch.Tensor.data_ptr()`); `stream` is a `hipStream_t` passed as `void*`
+ * (`torch.cuda.current_stream().cuda_stream`), NULL = the HIP null stream.
+ *
+ * Two libraries export this same ABI shape:
+ *   - libmssim.so          symbols `mssim_*`      HIP / gfx950 kernels (the product).
+ *   - oracle/_build/...    symbols `mssim_ref_*`  plain C++ CPU restatement (test oracle only;
+ *                                                 pointers are host pointers, stream ignored).
+ *
+ * Data conventions
+ *   - quaternions are (w, x, y, z); poses are 7 floats p(3), q(4); Z is up.
+ *   - user-visible ("cuda_*") buffers follow the reference contract (structs/base.py:103-114,
+ *     structs/articulation.py:567-659):
+ *        rigid_body_data  [R*N][13]   pos3 quat4 linvel3 angvel3   (row = body_row*N + env)
+ *        articulation_*   [N][n_dof]
+ *     Row order inside `cuda_rigid_body_data` is unspecified by SAPIEN
+ *     (docs/source/user_guide/concepts/gpu_simulation.md); this core uses body-major rows so a
+ *     body's rows for all envs are one contiguous slice.
+ *     Deviation (documented): velocity columns are lin 7:10 / ang 10:13 for ALL
+ *     rows, including articulation links.
+ *   - internal simulation state is struct-of-arrays with the env index fastest (coalesced);
+ *     apply/fetch move data between the two, exactly as px.gpu_apply_* / px.gpu_fetch_* do.
+ */
+#ifndef MSSIM_H
+#define MSSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSSIM_ABI_VERSION 1
+#define MSSIM_MAX_DOF 16        /* max articulation degrees of freedom per env            */
+#define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
+#define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
+#define MSSIM_MAX_HULL_VERTS 64 /* per convex hull (PhysX GPU-compatible hull limit)      */
+
+/* joint types of the moving articulation bodies (fixed joints are folded at compile time) */
+enum { MSSIM_JOINT_REVOLUTE = 0, MSSIM_JOINT_PRISMATIC = 1 };
+/* drive modes, articulation_joint.py:184-201 (`set_drive_properties(..., mode)`) */
+enum { MSSIM_DRIVE_FORCE = 0, MSSIM_DRIVE_ACCELERATION = 1 };
+/* collision shape types, utils/building/actor_builder.py:73-155 */
+enum {
+  MSSIM_SHAPE_PLANE = 0,   /* half space; normal = +x of the shape frame (PhysX convention)   */
+  MSSIM_SHAPE_BOX = 1,     /* param = half extents                                          */
+  MSSIM_SHAPE_SPHERE = 2,  /* param[0] = radius                                             */
+  MSSIM_SHAPE_CAPSULE = 3, /* param[0] = radius, param[1] = half length, axis = +x of frame  */
+  MSSIM_SHAPE_CYLINDER = 4,/* param[0] = radius, param[1] = half length, axis = +x of frame  */
+  MSSIM_SHAPE_CONVEX = 5   /* hull vertices in `hull_verts[hull_offset .. +hull_count)`      */
+};
+/* what a shape / body row is attached to */
+enum {
+  MSSIM_BODY_WORLD = 0, /* static, fixed in the env frame                                   */
+  MSSIM_BODY_ART = 1,   /* articulation: index = moving body (== dof) or -1 for the base    */
+  MSSIM_BODY_FREE = 2,  /* free dynamic rigid body                                          */
+  MSSIM_BODY_KIN = 3    /* kinematic body (pose set by the user, infinite mass)             */
+};
+
+/* Compiled, env-shared model (constant tables; uploaded once at create). All pointers are HOST
+ * pointers, only read during mssim_create.  Built by maniskill_amd/model/compile.py from the
+ * URDF/SRDF + actor builders (reference build path: utils/building/actor_builder.py:57-260,
+ * articulation_builder.py:65-212, urdf_loader.py:28-47). */
+typedef struct mssim_model_desc {
+  int32_t abi_version;
+
+  /* ---- articulation (0 or 1 per env; fixed base) ---- */
+  int32_t n_dof;                 /* moving bodies == active joints                               */
+  const int32_t* dof_parent;     /* [n_dof] parent moving body, -1 = base                        */
+  const int32_t* dof_type;       /* [n_dof] MSSIM_JOINT_*                                        */
+  const float* dof_frame;        /* [n_dof][7] joint frame in the parent body frame (p, q)       */
+  const float* dof_axis;         /* [n_dof][3] unit axis in the joint frame                      */
+  const float* dof_limit;        /* [n_dof][2] lower, upper                                      */
+  const float* dof_drive;        /* [n_dof][4] stiffness, damping, force_limit, mode             */
+  const float* dof_armature;     /* [n_dof] extra joint-space inertia                            */
+  const float* body_inertial;    /* [n_dof][10] mass, com(3), inertia about com xx yy zz xy xz yz
+                                    (fixed-joint children already folded in), body frame        */
+  const int32_t* body_gravity;   /* [n_dof] 1 = gravity acts on this body (base_agent.py:272-282
+                                    disables it on every robot link)                            */
+  int32_t n_tendon;              /* mimic joints, articulation_builder.py:160-199                */
+  const int32_t* tendon_dof;     /* [n_tendon][2] dof a, dof b                                   */
+  const float* tendon_param;     /* [n_tendon][5] coef_a, coef_b, rest_length, stiffness, damping */
+
+  /* ---- rigid body rows of `rigid_body_data` ---- */
+  int32_t n_link;                /* articulation links (all URDF links incl. fixed ones), rows 0..n_link-1 */
+  const int32_t* link_body;      /* [n_link] moving body the link is rigidly attached to, -1 = base */
+  const float* link_frame;       /* [n_link][7] link frame in that body's frame                   */
+  int32_t n_free;                /* free bodies, rows n_link .. n_link+n_free-1                   */
+  const float* free_inertial;    /* [n_free][10] as body_inertial                                 */
+  const float* free_damping;     /* [n_free][2] linear, angular damping                           */
+  const int32_t* free_gravity;   /* [n_free]                                                      */
+  int32_t n_kin;                 /* kinematic bodies, rows n_link+n_free ..                       */
+
+  /* ---- collision shapes ---- */
+  int32_t n_shape;
+  const int32_t* shape_type;     /* [n_shape] MSSIM_SHAPE_*                                       */
+  const int32_t* shape_body_kind;/* [n_shape] MSSIM_BODY_*                                        */
+  const int32_t* shape_body_index;/* [n_shape] index within its kind                              */
+  const int32_t* shape_row;      /* [n_shape] rigid_body_data row of the owning body, -1 = none   */
+  const float* shape_frame;      /* [n_shape][7] shape frame in the body frame                    */
+  const float* shape_param;      /* [n_shape][4] see MSSIM_SHAPE_*                                */
+  const float* shape_material;   /* [n_shape][4] static friction, dynamic friction, restitution, patch_radius */
+  const int32_t* shape_hull;     /* [n_shape][2] hull_offset, hull_count (CONVEX only)            */
+  const float* shape_bound;      /* [n_shape][4] bounding sphere: centre in shape frame, radius   */
+  int32_t n_hull_verts;
+  const float* hull_verts;       /* [n_hull_verts][3] in the shape frame                          */
+
+  /* ---- candidate collision pairs (static broadphase result: group bits, SRDF
+   *      disable_collisions, same-body and static-static pairs already removed) ---- */
+  int32_t n_pair;
+  const int32_t* pair_shape;     /* [n_pair][2] shape a, shape b                                  */
+
+  /* ---- scene configuration, utils/structs/types.py:36-67 ---- */
+  float gravity[3];
+  float timestep;                /* 1 / sim_freq, envs/sapien_env.py:1111                         */
+  float contact_offset;          /* 0.02                                                          */
+  float rest_offset;             /* 0                                                             */
+  float bounce_threshold;        /* 2.0                                                           */
+  int32_t position_iterations;   /* 15                                                            */
+  int32_t velocity_iterations;   /* 1                                                             */
+  float erp;                     /* fraction of penetration removed per substep by the bias       */
+  float max_depenetration_velocity;
+  float sleep_threshold;         /* reserved (0.005)                                              */
+} mssim_model_desc;
+
+/* User-visible buffers (device pointers owned by the caller, e.g. torch tensors); mirrors
+ * `px.cuda_*` (structs/base.py:112-114, structs/articulation.py:567-659, actor.py:305-316). */
+typedef struct mssim_buffers {
+  float* rigid_body_data;   /* [R*N][13], R = n_link + n_free + n_kin                            */
+  float* rigid_body_force;  /* [R*N][4] force xyz (+pad) applied for the next step only, may be NULL */
+  float* art_qpos;          /* [N][n_dof]                                                         */
+  float* art_qvel;
+  float* art_qacc;
+  float* art_qf;
+  float* art_target_qpos;
+  float* art_target_qvel;
+} mssim_buffers;
+
+/* apply / fetch selector bits, one per px.gpu_apply_* / px.gpu_fetch_* call
+ * (envs/scene.py:941-977) */
+enum {
+  MSSIM_RIGID_DATA = 1u << 0,   /* gpu_apply_rigid_dynamic_data / gpu_fetch_rigid_dynamic_data   */
+  MSSIM_ART_QPOS = 1u << 1,
+  MSSIM_ART_QVEL = 1u << 2,
+  MSSIM_ART_QF = 1u << 3,
+  MSSIM_ART_ROOT_POSE = 1u << 4,
+  MSSIM_ART_ROOT_VEL = 1u << 5,
+  MSSIM_ART_TARGET_POS = 1u << 6,
+  MSSIM_ART_TARGET_VEL = 1u << 7,
+  MSSIM_RIGID_FORCE = 1u << 8,  /* gpu_apply_rigid_dynamic_force                                  */
+  MSSIM_LINK_POSE = 1u << 9,    /* gpu_fetch_articulation_link_pose                               */
+  MSSIM_LINK_VEL = 1u << 10,    /* gpu_fetch_articulation_link_velocity                           */
+  MSSIM_ART_QACC = 1u << 11,
+  MSSIM_ALL = 0xFFFu
+};
+
+typedef struct mssim_sim* mssim_handle;
+
+#ifndef MSSIM_PREFIX
+#define MSSIM_PREFIX mssim_
+#endif
+#define MSSIM_CAT2(a, b) a##b
+#define MSSIM_CAT(a, b) MSSIM_CAT2(a, b)
+#define MSSIM_FN(name) MSSIM_CAT(MSSIM_PREFIX, name)
+
+/* replaces sapien.physx.PhysxGpuSystem(device) + px.gpu_init()   (sapien_env.py:1077, scene.py:905).
+ * device >= 0: HIP device ordinal.  Returns 0 on success. */
+int MSSIM_FN(create)(const mssim_model_desc* model, int32_t num_envs, int32_t device, mssim_handle* out);
+void MSSIM_FN(destroy)(mssim_handle h);
+/* binds the px.cuda_* tensors (structs/base.py:112-114) */
+int MSSIM_FN(bind_buffers)(mssim_handle h, const mssim_buffers* buffers);
+/* px.timestep setter/getter (sapien_env.py:1111) */
+int MSSIM_FN(set_timestep)(mssim_handle h, float dt);
+float MSSIM_FN(get_timestep)(mssim_handle h);
+/* px.gpu_apply_*  (scene.py:941-957): user buffers -> simulation state, whole buffers */
+int MSSIM_FN(apply)(mssim_handle h, uint32_t what, void* stream);
+/* px.gpu_fetch_*  (scene.py:959-977): simulation state -> user buffers */
+int MSSIM_FN(fetch)(mssim_handle h, uint32_t what, void* stream);
+/* px.step() x n_substeps (scene.py:374-375; loop at sapien_env.py:1016-1021).  No host sync. */
+int MSSIM_FN(step)(mssim_handle h, int32_t n_substeps, void* stream);
+/* px.gpu_update_articulation_kinematics() (sapien_env.py:861-865) */
+int MSSIM_FN(update_kinematics)(mssim_handle h, void* stream);
+/* px.gpu_create_contact_pair_impulse_query (scene.py:769-772): body_pairs = [n_pairs][2]
+ * rigid_body_data body rows (row / N), -1 = static world. */
+int MSSIM_FN(create_pair_query)(mssim_handle h, const int32_t* body_pairs, int32_t n_pairs, int32_t* query_id);
+/* px.gpu_query_contact_pair_impulses (scene.py:773-776): out = [n_pairs*N][3] device floats,
+ * row = pair*N + env, impulse on body A from body B during the LAST substep. */
+int MSSIM_FN(query_pair_impulses)(mssim_handle h, int32_t query_id, float* out, void* stream);
+/* px.gpu_create_contact_body_impulse_query / gpu_query_contact_body_impulses
+ * (structs/base.py:116-136): net contact impulse on each listed body row. */
+int MSSIM_FN(create_body_query)(mssim_handle h, const int32_t* body_rows, int32_t n_bodies, int32_t* query_id);
+int MSSIM_FN(query_body_impulses)(mssim_handle h, int32_t query_id, float* out, void* stream);
+/* Update drive gains after create (ArticulationJoint.set_drive_properties,
+ * articulation_joint.py:184-201; allowed post-init in the reference): drive = [n_dof][4] host. */
+int MSSIM_FN(set_drive_properties)(mssim_handle h, const float* dof_drive);
+/* Debug/parity access to internal SoA state: copies the named array ([items][N] floats) into
+ * `out` (device pointer for the HIP build, host for the oracle).  Names: "q", "qd", "free"
+ * (13 per body), "kin" (7 per body), "root" (7), "bodypose" (7 per moving body),
+ * "contact_count" (per pair, as float), "overflow" (1).  Returns number of items or <0. */
+int MSSIM_FN(read_internal)(mssim_handle h, const char* name, float* out, int32_t max_items, void* stream);
+/* capacity overflow must be a reported condition (SURVEY 8b error conventions): number of envs
+ * whose solver row capacity was exceeded since the last call (synchronises the stream). */
+int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
+/* last error message of this handle (or of create when h == NULL) */
+const char* MSSIM_FN(last_error)(mssim_handle h);
+int MSSIM_FN(abi_version)(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSSIM_H */

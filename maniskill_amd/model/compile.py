@@ -1,0 +1,512 @@
+"""Scene model compiler: builder records -> flat constant tables (`mssim_model_desc`).
+
+The reference builds one `sapien.Entity` per sub-scene in O(N) Python loops
+(mani_skill/utils/building/actor_builder.py:191-260, articulation_builder.py:113-212) and lets
+PhysX cook shapes and inertias. Here every env shares ONE compiled model: fixed joints are folded
+into their moving ancestor for dynamics (all link frames are kept for pose output), convex
+meshes are cooked to <=64-vertex hulls, and the broadphase filter (collision-group words, SRDF
+`disable_collisions`, adjacent links, static-static) is evaluated once into a candidate
+shape-pair table.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import geom, mesh
+from .urdf import RobotDescription
+
+# enums mirrored from include/mssim.h
+JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
+SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_CONVEX = range(6)
+BODY_WORLD, BODY_ART, BODY_FREE, BODY_KIN = range(4)
+MAX_DOF, MAX_FREE, MAX_HULL_VERTS = 16, 8, 64
+
+_SHAPE_NAMES = {
+    "plane": SHAPE_PLANE,
+    "box": SHAPE_BOX,
+    "sphere": SHAPE_SPHERE,
+    "capsule": SHAPE_CAPSULE,
+    "cylinder": SHAPE_CYLINDER,
+    "convex": SHAPE_CONVEX,
+}
+
+
+@dataclass
+class ShapeRecord:
+    """One collision shape in its owner's (actor / link) frame."""
+
+    type: str  # plane | box | sphere | capsule | cylinder | convex
+    pose: np.ndarray = field(default_factory=geom.pose)
+    half_size: Optional[np.ndarray] = None  # box
+    radius: float = 0.0
+    half_length: float = 0.0
+    vertices: Optional[np.ndarray] = None  # convex, shape frame
+    static_friction: float = 0.3
+    dynamic_friction: float = 0.3
+    restitution: float = 0.0
+    patch_radius: float = 0.0
+    min_patch_radius: float = 0.0
+    density: float = 1000.0
+    collision_groups: Sequence[int] = (1, 1, 0, 0)
+
+    def param(self):
+        if self.type == "box":
+            return np.array([*self.half_size, 0.0])
+        if self.type == "sphere":
+            return np.array([self.radius, 0, 0, 0.0])
+        if self.type in ("capsule", "cylinder"):
+            return np.array([self.radius, self.half_length, 0, 0.0])
+        return np.zeros(4)
+
+    def bound(self):
+        """bounding sphere (centre in the shape frame, radius); planes are unbounded (r<0)."""
+        if self.type == "plane":
+            return np.zeros(3), -1.0
+        if self.type == "box":
+            return np.zeros(3), float(np.linalg.norm(self.half_size))
+        if self.type == "sphere":
+            return np.zeros(3), float(self.radius)
+        if self.type == "capsule":
+            return np.zeros(3), float(self.radius + self.half_length)
+        if self.type == "cylinder":
+            return np.zeros(3), float(np.hypot(self.radius, self.half_length))
+        return mesh.bounding_sphere(self.vertices)
+
+    def mass_properties(self):
+        """(mass, com, inertia about com) in the shape frame from density."""
+        rho = self.density
+        if self.type == "box":
+            hx, hy, hz = self.half_size
+            m = rho * 8 * hx * hy * hz
+            I = np.diag([hy * hy + hz * hz, hx * hx + hz * hz, hx * hx + hy * hy]) * m / 3.0
+            return m, np.zeros(3), I
+        if self.type == "sphere":
+            m = rho * 4.0 / 3.0 * np.pi * self.radius**3
+            return m, np.zeros(3), np.eye(3) * 0.4 * m * self.radius**2
+        if self.type == "cylinder":
+            r, h = self.radius, 2 * self.half_length
+            m = rho * np.pi * r * r * h
+            return m, np.zeros(3), np.diag([0.5 * m * r * r, m * (3 * r * r + h * h) / 12, m * (3 * r * r + h * h) / 12])
+        if self.type == "capsule":
+            r, h = self.radius, 2 * self.half_length
+            mc = rho * np.pi * r * r * h
+            ms = rho * 4.0 / 3.0 * np.pi * r**3
+            ix = 0.5 * mc * r * r + 0.4 * ms * r * r
+            iy = mc * (3 * r * r + h * h) / 12 + ms * (0.4 * r * r + 0.375 * r * h + 0.25 * h * h)
+            return mc + ms, np.zeros(3), np.diag([ix, iy, iy])
+        if self.type == "convex":
+            vol, com, I = mesh.hull_volume_com_inertia(self.vertices)
+            return rho * vol, com, rho * I
+        return 0.0, np.zeros(3), np.zeros((3, 3))
+
+
+@dataclass
+class ActorRecord:
+    name: str
+    body_type: str  # dynamic | kinematic | static
+    shapes: List[ShapeRecord]
+    initial_pose: np.ndarray = field(default_factory=geom.pose)
+    mass: Optional[float] = None  # explicit override (with com / inertia)
+    com: Optional[np.ndarray] = None
+    inertia: Optional[np.ndarray] = None
+    linear_damping: float = 0.0
+    angular_damping: float = 0.0
+    disable_gravity: bool = False
+
+
+@dataclass
+class ArticulationRecord:
+    name: str
+    robot: RobotDescription
+    initial_pose: np.ndarray = field(default_factory=geom.pose)
+    fix_root_link: bool = True
+    link_shapes: Dict[str, List[ShapeRecord]] = field(default_factory=dict)
+    disable_self_collisions: bool = False
+    link_gravity: Dict[str, bool] = field(default_factory=dict)  # default True
+    # per active joint (by joint name): stiffness, damping, force_limit, mode
+    drives: Dict[str, Tuple[float, float, float, int]] = field(default_factory=dict)
+    joint_friction: Dict[str, float] = field(default_factory=dict)
+    build_mimic_joints: bool = True
+
+
+@dataclass
+class CompiledModel:
+    arrays: Dict[str, np.ndarray]
+    scalars: Dict[str, float]
+    link_names: List[str]
+    joint_names: List[str]  # all joints (one per link, root first: "" for the root)
+    active_joint_names: List[str]
+    free_names: List[str]
+    kin_names: List[str]
+    static_names: List[str]
+    shape_owner: List[str]
+    n_rows: int
+
+    @property
+    def n_dof(self):
+        return int(self.scalars["n_dof"])
+
+    @property
+    def n_link(self):
+        return int(self.scalars["n_link"])
+
+    @property
+    def n_free(self):
+        return int(self.scalars["n_free"])
+
+    @property
+    def n_kin(self):
+        return int(self.scalars["n_kin"])
+
+    @property
+    def n_pair(self):
+        return int(self.scalars["n_pair"])
+
+    def row_of(self, name: str) -> int:
+        if name in self.link_names:
+            return self.link_names.index(name)
+        if name in self.free_names:
+            return self.n_link + self.free_names.index(name)
+        if name in self.kin_names:
+            return self.n_link + self.n_free + self.kin_names.index(name)
+        return -1
+
+
+def shapes_from_urdf_link(link, materials=None, link_cfg=None, max_hull_verts=MAX_HULL_VERTS) -> List[ShapeRecord]:
+    """URDF <collision> elements -> ShapeRecords (reference: SAPIEN URDF loader; material /
+    patch-radius overrides per mani_skill/utils/sapien_utils.py:113-168 `apply_urdf_config`)."""
+    out = []
+    cfg = link_cfg or {}
+    mat = cfg.get("material", None)
+    for c in link.collisions:
+        if c.type == "box":
+            s = ShapeRecord("box", c.pose.copy(), half_size=0.5 * c.size)
+        elif c.type == "sphere":
+            s = ShapeRecord("sphere", c.pose.copy(), radius=float(c.size[0]))
+        elif c.type in ("cylinder", "capsule"):
+            # URDF axis is z; shape convention is +x: rotate x -> z
+            rot = geom.pose(q=geom.mat_to_quat(np.array([[0, 0, -1.0], [0, 1, 0], [1, 0, 0]])))
+            s = ShapeRecord(c.type, geom.compose(c.pose, rot), radius=float(c.size[0]), half_length=0.5 * float(c.size[1]))
+        elif c.type == "mesh":
+            v = mesh.cook_convex_mesh(c.filename, tuple(c.scale), max_hull_verts)
+            s = ShapeRecord("convex", c.pose.copy(), vertices=v)
+        else:
+            raise NotImplementedError(c.type)
+        if mat is not None:
+            s.static_friction = float(mat["static_friction"])
+            s.dynamic_friction = float(mat["dynamic_friction"])
+            s.restitution = float(mat["restitution"])
+        if "patch_radius" in cfg:
+            s.patch_radius = float(cfg["patch_radius"])
+        if "min_patch_radius" in cfg:
+            s.min_patch_radius = float(cfg["min_patch_radius"])
+        if "density" in cfg:
+            s.density = float(cfg["density"])
+        out.append(s)
+    return out
+
+
+class SceneModelBuilder:
+    """Accumulates one env's worth of records; `compile()` produces the shared tables."""
+
+    def __init__(self):
+        self.articulation: Optional[ArticulationRecord] = None
+        self.actors: List[ActorRecord] = []
+
+    def set_articulation(self, rec: ArticulationRecord):
+        if self.articulation is not None:
+            raise NotImplementedError("this core supports one articulation per env")
+        self.articulation = rec
+
+    def add_actor(self, rec: ActorRecord):
+        if any(a.name == rec.name for a in self.actors):
+            raise ValueError(f"duplicate actor name {rec.name}")
+        self.actors.append(rec)
+
+    # ------------------------------------------------------------------ #
+    def compile(
+        self,
+        timestep=0.01,
+        gravity=(0, 0, -9.81),
+        contact_offset=0.02,
+        rest_offset=0.0,
+        bounce_threshold=2.0,
+        position_iterations=15,
+        velocity_iterations=1,
+        erp=0.2,
+        max_depenetration_velocity=1.0,
+        sleep_threshold=0.005,
+    ) -> CompiledModel:
+        A: Dict[str, np.ndarray] = {}
+        shapes: List[dict] = []  # compiled shape dicts
+        link_names, joint_names, active_joint_names = [], [], []
+
+        # ---------------- articulation ----------------
+        art = self.articulation
+        link_body, link_frame = [], []
+        dof_parent, dof_type, dof_frame, dof_axis, dof_limit, dof_drive, dof_arm = [], [], [], [], [], [], []
+        body_inertial, body_gravity = [], []
+        tendon_dof, tendon_param = [], []
+        link_to_body: Dict[str, int] = {}
+        link_rel: Dict[str, np.ndarray] = {}
+        adjacent = set()
+        srdf_disabled = set()
+        if art is not None:
+            if not art.fix_root_link:
+                raise NotImplementedError("floating-base articulations are not supported yet")
+            rb = art.robot
+            body_items: Dict[int, list] = {}
+            joint_to_dof: Dict[str, int] = {}
+            for lname in rb.link_order:
+                link = rb.links[lname]
+                pj = rb.parent_joint.get(lname)
+                if pj is None:
+                    link_to_body[lname] = -1
+                    link_rel[lname] = geom.pose()
+                    joint_names.append("")
+                elif pj.type == "fixed":
+                    link_to_body[lname] = link_to_body[pj.parent]
+                    link_rel[lname] = geom.compose(link_rel[pj.parent], pj.origin)
+                    joint_names.append(pj.name)
+                else:
+                    j = len(dof_parent)
+                    joint_to_dof[pj.name] = j
+                    dof_parent.append(link_to_body[pj.parent])
+                    dof_type.append(JOINT_PRISMATIC if pj.type == "prismatic" else JOINT_REVOLUTE)
+                    dof_frame.append(geom.compose(link_rel[pj.parent], pj.origin))
+                    dof_axis.append(pj.axis)
+                    lo, hi = pj.limit if pj.type != "continuous" else (-np.inf, np.inf)
+                    dof_limit.append([lo, hi])
+                    # SAPIEN default drive: stiffness 0, damping = URDF joint damping
+                    # (articulation_builder.py:91-101); controllers override (pd_joint_pos.py:35-49)
+                    drv = art.drives.get(pj.name, (0.0, pj.damping, np.inf, 0))
+                    dof_drive.append([drv[0], drv[1], min(drv[2], 3.0e38), float(drv[3])])
+                    dof_arm.append(0.0)
+                    link_to_body[lname] = j
+                    link_rel[lname] = geom.pose()
+                    body_gravity.append(1 if art.link_gravity.get(lname, True) else 0)
+                    joint_names.append(pj.name)
+                    active_joint_names.append(pj.name)
+                    adjacent.add((link_to_body[pj.parent], j))
+                b = link_to_body[lname]
+                link_names.append(lname)
+                link_body.append(b)
+                link_frame.append(link_rel[lname])
+                if link.has_inertial and link.mass > 0:
+                    body_items.setdefault(b, []).append(
+                        geom.transform_inertial(link_rel[lname], link.mass, link.com, link.inertia)
+                    )
+                # fixed links inherit the gravity flag of ... each link separately in the
+                # reference; a folded body uses the flag of its joint-bearing link.
+                for s in art.link_shapes.get(lname, []):
+                    shapes.append(
+                        dict(
+                            rec=s,
+                            kind=BODY_ART,
+                            index=b,
+                            row=len(link_names) - 1,
+                            frame=geom.compose(link_rel[lname], s.pose),
+                            owner=lname,
+                            link=lname,
+                        )
+                    )
+            n_dof = len(dof_parent)
+            if n_dof > MAX_DOF:
+                raise NotImplementedError(f"n_dof={n_dof} exceeds MSSIM_MAX_DOF={MAX_DOF}")
+            for j in range(n_dof):
+                m, c, I = geom.combine_inertials(body_items.get(j, []))
+                if m <= 0:  # massless moving body: tiny default like SAPIEN's loader
+                    m, c, I = 1e-6, np.zeros(3), np.eye(3) * 1e-9
+                body_inertial.append([m, *c, *geom.inertia_mat_to_vec(I)])
+            for a, b in rb.disabled_pairs:
+                srdf_disabled.add((a, b))
+                srdf_disabled.add((b, a))
+            if art.build_mimic_joints:
+                for j in rb.joints:
+                    if j.mimic is not None and j.name in joint_to_dof and j.mimic[0] in joint_to_dof:
+                        # q_j = multiplier * q_src + offset ; fixed tendon stiffness 1e5
+                        # (articulation_builder.py:160-199)
+                        tendon_dof.append([joint_to_dof[j.mimic[0]], joint_to_dof[j.name]])
+                        tendon_param.append([-j.mimic[1], 1.0, j.mimic[2], 1e5, 0.0])
+        n_dof = len(dof_parent)
+        n_link = len(link_names)
+
+        # ---------------- actors ----------------
+        free_names, kin_names, static_names = [], [], []
+        free_inertial, free_damping, free_gravity = [], [], []
+        init_free, init_kin = [], []
+        for a in self.actors:
+            if a.body_type == "dynamic":
+                if a.mass is not None:
+                    m, c, I = a.mass, np.zeros(3) if a.com is None else a.com, a.inertia
+                else:
+                    items = []
+                    for s in a.shapes:
+                        ms, cs, Is = s.mass_properties()
+                        items.append(geom.transform_inertial(s.pose, ms, cs, Is))
+                    m, c, I = geom.combine_inertials(items)
+                    if m <= 0:
+                        m, c, I = 1.0, np.zeros(3), np.eye(3)  # PhysX default for shapeless bodies
+                idx = len(free_names)
+                free_names.append(a.name)
+                free_inertial.append([m, *c, *geom.inertia_mat_to_vec(I)])
+                free_damping.append([a.linear_damping, a.angular_damping])
+                free_gravity.append(0 if a.disable_gravity else 1)
+                init_free.append(a.initial_pose)
+                kind, row = BODY_FREE, n_link + idx
+            elif a.body_type == "kinematic":
+                idx = len(kin_names)
+                kin_names.append(a.name)
+                init_kin.append(a.initial_pose)
+                kind, row = BODY_KIN, None  # fixed up below
+            elif a.body_type == "static":
+                idx = len(static_names)
+                static_names.append(a.name)
+                kind, row = BODY_WORLD, -1
+            else:
+                raise ValueError(a.body_type)
+            for s in a.shapes:
+                frame = s.pose if kind != BODY_WORLD else geom.compose(a.initial_pose, s.pose)
+                shapes.append(dict(rec=s, kind=kind, index=idx if kind != BODY_WORLD else 0, row=row, frame=frame, owner=a.name, link=None))
+        n_free, n_kin = len(free_names), len(kin_names)
+        if n_free > MAX_FREE:
+            raise NotImplementedError(f"n_free={n_free} exceeds MSSIM_MAX_FREE={MAX_FREE}")
+        for s in shapes:
+            if s["kind"] == BODY_KIN:
+                s["row"] = n_link + n_free + s["index"]
+
+        # ---------------- shape tables ----------------
+        hull_verts = []
+        st, sk, si, srow, sframe, sparam, smat, shull, sbound = [], [], [], [], [], [], [], [], []
+        for s in shapes:
+            r: ShapeRecord = s["rec"]
+            st.append(_SHAPE_NAMES[r.type])
+            sk.append(s["kind"])
+            si.append(s["index"])
+            srow.append(s["row"])
+            sframe.append(s["frame"])
+            sparam.append(r.param())
+            smat.append([r.static_friction, r.dynamic_friction, r.restitution, r.patch_radius])
+            if r.type == "convex":
+                v = np.asarray(r.vertices, dtype=np.float64)
+                if len(v) > MAX_HULL_VERTS:
+                    v = mesh.simplify_hull(v, MAX_HULL_VERTS)
+                shull.append([len(hull_verts), len(v)])
+                hull_verts.extend(v.tolist())
+            else:
+                shull.append([0, 0])
+            c, rad = r.bound()
+            sbound.append([*c, rad])
+
+        # ---------------- candidate pairs ----------------
+        def moving(s):
+            return s["kind"] == BODY_FREE or (s["kind"] == BODY_ART and s["index"] >= 0)
+
+        pairs = []
+        for ia in range(len(shapes)):
+            for ib in range(ia + 1, len(shapes)):
+                a, b = shapes[ia], shapes[ib]
+                if not (moving(a) or moving(b)):
+                    continue
+                if a["kind"] == b["kind"] and a["index"] == b["index"] and a["kind"] != BODY_WORLD:
+                    continue
+                ga, gb = a["rec"].collision_groups, b["rec"].collision_groups
+                if ga[2] & gb[2]:
+                    continue
+                if not ((ga[0] & gb[1]) or (ga[1] & gb[0])):
+                    continue
+                if a["kind"] == BODY_ART and b["kind"] == BODY_ART:
+                    if art.disable_self_collisions:
+                        continue
+                    ba, bb = a["index"], b["index"]
+                    if (ba, bb) in adjacent or (bb, ba) in adjacent:
+                        continue
+                    if (a["link"], b["link"]) in srdf_disabled:
+                        continue
+                    # links joined directly by a (fixed) joint never collide
+                    pja = art.robot.parent_joint.get(a["link"])
+                    pjb = art.robot.parent_joint.get(b["link"])
+                    if (pja is not None and pja.parent == b["link"]) or (pjb is not None and pjb.parent == a["link"]):
+                        continue
+                if st[ia] == SHAPE_PLANE and st[ib] == SHAPE_PLANE:
+                    continue
+                # canonical order: lower shape type first (plane < box < ... < convex)
+                if st[ia] <= st[ib]:
+                    pairs.append([ia, ib])
+                else:
+                    pairs.append([ib, ia])
+
+        def arr(x, dtype, shape):
+            a = np.asarray(x, dtype=dtype)
+            if a.size == 0:
+                a = np.zeros(shape, dtype=dtype)
+            return np.ascontiguousarray(a.reshape(shape))
+
+        f32, i32 = np.float32, np.int32
+        A["dof_parent"] = arr(dof_parent, i32, (n_dof,))
+        A["dof_type"] = arr(dof_type, i32, (n_dof,))
+        A["dof_frame"] = arr(dof_frame, f32, (n_dof, 7))
+        A["dof_axis"] = arr(dof_axis, f32, (n_dof, 3))
+        lim = np.asarray(dof_limit, dtype=np.float64).reshape(n_dof, 2)
+        A["dof_limit"] = arr(np.clip(lim, -3.0e38, 3.0e38), f32, (n_dof, 2))
+        A["dof_drive"] = arr(dof_drive, f32, (n_dof, 4))
+        A["dof_armature"] = arr(dof_arm, f32, (n_dof,))
+        A["body_inertial"] = arr(body_inertial, f32, (n_dof, 10))
+        A["body_gravity"] = arr(body_gravity, i32, (n_dof,))
+        A["tendon_dof"] = arr(tendon_dof, i32, (len(tendon_dof), 2))
+        A["tendon_param"] = arr(tendon_param, f32, (len(tendon_param), 5))
+        A["link_body"] = arr(link_body, i32, (n_link,))
+        A["link_frame"] = arr(link_frame, f32, (n_link, 7))
+        A["free_inertial"] = arr(free_inertial, f32, (n_free, 10))
+        A["free_damping"] = arr(free_damping, f32, (n_free, 2))
+        A["free_gravity"] = arr(free_gravity, i32, (n_free,))
+        ns = len(shapes)
+        A["shape_type"] = arr(st, i32, (ns,))
+        A["shape_body_kind"] = arr(sk, i32, (ns,))
+        A["shape_body_index"] = arr(si, i32, (ns,))
+        A["shape_row"] = arr(srow, i32, (ns,))
+        A["shape_frame"] = arr(sframe, f32, (ns, 7))
+        A["shape_param"] = arr(sparam, f32, (ns, 4))
+        A["shape_material"] = arr(smat, f32, (ns, 4))
+        A["shape_hull"] = arr(shull, i32, (ns, 2))
+        A["shape_bound"] = arr(sbound, f32, (ns, 4))
+        A["hull_verts"] = arr(hull_verts, f32, (len(hull_verts), 3))
+        A["pair_shape"] = arr(pairs, i32, (len(pairs), 2))
+        # initial state (not part of the C model; used by the python system at gpu_init)
+        A["init_root_pose"] = arr(art.initial_pose if art is not None else geom.pose(), f32, (7,))
+        A["init_free_pose"] = arr(init_free, f32, (n_free, 7))
+        A["init_kin_pose"] = arr(init_kin, f32, (n_kin, 7))
+
+        scalars = dict(
+            n_dof=n_dof,
+            n_tendon=len(tendon_dof),
+            n_link=n_link,
+            n_free=n_free,
+            n_kin=n_kin,
+            n_shape=ns,
+            n_hull_verts=len(hull_verts),
+            n_pair=len(pairs),
+            gravity=tuple(float(g) for g in gravity),
+            timestep=float(timestep),
+            contact_offset=float(contact_offset),
+            rest_offset=float(rest_offset),
+            bounce_threshold=float(bounce_threshold),
+            position_iterations=int(position_iterations),
+            velocity_iterations=int(velocity_iterations),
+            erp=float(erp),
+            max_depenetration_velocity=float(max_depenetration_velocity),
+            sleep_threshold=float(sleep_threshold),
+        )
+        return CompiledModel(
+            arrays=A,
+            scalars=scalars,
+            link_names=link_names,
+            joint_names=joint_names,
+            active_joint_names=active_joint_names,
+            free_names=free_names,
+            kin_names=kin_names,
+            static_names=static_names,
+            shape_owner=[s["owner"] for s in shapes],
+            n_rows=n_link + n_free + n_kin,
+        )

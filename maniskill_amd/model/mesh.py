@@ -1,0 +1,106 @@
+"""Collision-mesh cooking on the host: binary/ASCII STL -> convex hull with a vertex budget.
+
+Counterpart of PhysX convex-mesh cooking that SAPIEN runs inside
+`add_convex_collision_from_file` (mani_skill/utils/building/actor_builder.py:113-131 calls
+`PhysxCollisionShapeConvexMesh`). PhysX GPU-compatible hulls are limited to 64 vertices; the
+same budget is applied here (MSSIM_MAX_HULL_VERTS).
+"""
+import struct
+from functools import lru_cache
+
+import numpy as np
+from scipy.spatial import ConvexHull
+
+
+def load_stl_vertices(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        data = f.read()
+    is_ascii = data[:5].lower() == b"solid" and b"facet" in data[:1024]
+    if is_ascii:
+        verts = []
+        for line in data.decode("ascii", errors="ignore").splitlines():
+            s = line.strip().split()
+            if len(s) == 4 and s[0] == "vertex":
+                verts.append([float(s[1]), float(s[2]), float(s[3])])
+        return np.unique(np.array(verts, dtype=np.float64), axis=0)
+    (n,) = struct.unpack("<I", data[80:84])
+    rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+    arr = np.frombuffer(data[84 : 84 + 50 * n], dtype=rec)
+    return np.unique(arr["v"].reshape(-1, 3).astype(np.float64), axis=0)
+
+
+def hull_volume_com_inertia(verts: np.ndarray):
+    """Volume, centre of mass and unit-density inertia about the COM of conv(verts)."""
+    hull = ConvexHull(verts)
+    c0 = verts[hull.vertices].mean(0)
+    vol = 0.0
+    com = np.zeros(3)
+    # covariance-style second moments integrated over tetrahedra (c0, a, b, c)
+    C = np.zeros((3, 3))
+    canon = np.full((3, 3), 1 / 120.0) + np.eye(3) / 120.0  # integral of x_i x_j over unit tet
+    for tri, eq in zip(hull.simplices, hull.equations):
+        a, b, c = verts[tri] - c0
+        if np.dot(np.cross(b - a, c - a), eq[:3]) < 0:
+            b, c = c, b
+        A = np.stack([a, b, c], axis=1)
+        det = np.linalg.det(A)
+        vol += det / 6.0
+        com += det / 24.0 * (a + b + c)
+        C += det * A @ canon @ A.T
+    com = com / vol
+    # second moment about c0 -> about com
+    C = C - vol * np.outer(com, com)
+    I = np.trace(C) * np.eye(3) - C
+    return vol, com + c0, I
+
+
+def simplify_hull(verts: np.ndarray, max_verts: int) -> np.ndarray:
+    """Reduce a convex point set to at most `max_verts` hull vertices.
+
+    Greedy: start from the 6 axis-extreme points, then repeatedly add the input vertex that is
+    farthest outside the current hull (largest plane violation). Deterministic.
+    """
+    hull = ConvexHull(verts)
+    pts = verts[hull.vertices]
+    if len(pts) <= max_verts:
+        return pts
+    chosen = []
+    for ax in range(3):
+        for idx in (int(np.argmin(pts[:, ax])), int(np.argmax(pts[:, ax]))):
+            if idx not in chosen:
+                chosen.append(idx)
+    # make sure the seed is full-dimensional
+    while len(chosen) < 4:
+        chosen.append(next(i for i in range(len(pts)) if i not in chosen))
+    while len(chosen) < max_verts:
+        try:
+            h = ConvexHull(pts[chosen], qhull_options="QJ")
+        except Exception:
+            rest = [i for i in range(len(pts)) if i not in chosen]
+            chosen.append(rest[0])
+            continue
+        # distance of every point outside the current hull
+        d = (pts @ h.equations[:, :3].T + h.equations[:, 3]).max(axis=1)
+        d[chosen] = -np.inf
+        i = int(np.argmax(d))
+        if d[i] <= 1e-9:
+            break
+        chosen.append(i)
+    return pts[sorted(chosen)]
+
+
+@lru_cache(maxsize=64)
+def _cook_cached(path: str, scale: tuple, max_verts: int):
+    v = load_stl_vertices(path) * np.array(scale)
+    return simplify_hull(v, max_verts)
+
+
+def cook_convex_mesh(path: str, scale=(1.0, 1.0, 1.0), max_verts: int = 64) -> np.ndarray:
+    return _cook_cached(path, tuple(float(s) for s in scale), int(max_verts)).copy()
+
+
+def bounding_sphere(verts: np.ndarray):
+    lo, hi = verts.min(0), verts.max(0)
+    c = 0.5 * (lo + hi)
+    r = float(np.linalg.norm(verts - c, axis=1).max())
+    return c, r

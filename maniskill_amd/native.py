@@ -1,0 +1,267 @@
+"""ctypes binding of the C ABI in include/mssim.h.
+
+`NativeLib(path, prefix)` binds any library that exports the ABI under a symbol prefix. The
+product library is `maniskill_amd/_native/libmssim.so` (prefix `mssim_`, HIP/gfx950); loading it
+fails loudly if it has not been built -- there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import PACKAGE_DIR
+from .model.compile import CompiledModel
+
+ABI_VERSION = 1
+NATIVE_LIB_PATH = os.path.join(PACKAGE_DIR, "_native", "libmssim.so")
+
+# apply / fetch selector bits (include/mssim.h)
+RIGID_DATA = 1 << 0
+ART_QPOS = 1 << 1
+ART_QVEL = 1 << 2
+ART_QF = 1 << 3
+ART_ROOT_POSE = 1 << 4
+ART_ROOT_VEL = 1 << 5
+ART_TARGET_POS = 1 << 6
+ART_TARGET_VEL = 1 << 7
+RIGID_FORCE = 1 << 8
+LINK_POSE = 1 << 9
+LINK_VEL = 1 << 10
+ART_QACC = 1 << 11
+ALL = 0xFFF
+
+_I32P = C.POINTER(C.c_int32)
+_F32P = C.POINTER(C.c_float)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_dof", C.c_int32),
+        ("dof_parent", _I32P),
+        ("dof_type", _I32P),
+        ("dof_frame", _F32P),
+        ("dof_axis", _F32P),
+        ("dof_limit", _F32P),
+        ("dof_drive", _F32P),
+        ("dof_armature", _F32P),
+        ("body_inertial", _F32P),
+        ("body_gravity", _I32P),
+        ("n_tendon", C.c_int32),
+        ("tendon_dof", _I32P),
+        ("tendon_param", _F32P),
+        ("n_link", C.c_int32),
+        ("link_body", _I32P),
+        ("link_frame", _F32P),
+        ("n_free", C.c_int32),
+        ("free_inertial", _F32P),
+        ("free_damping", _F32P),
+        ("free_gravity", _I32P),
+        ("n_kin", C.c_int32),
+        ("n_shape", C.c_int32),
+        ("shape_type", _I32P),
+        ("shape_body_kind", _I32P),
+        ("shape_body_index", _I32P),
+        ("shape_row", _I32P),
+        ("shape_frame", _F32P),
+        ("shape_param", _F32P),
+        ("shape_material", _F32P),
+        ("shape_hull", _I32P),
+        ("shape_bound", _F32P),
+        ("n_hull_verts", C.c_int32),
+        ("hull_verts", _F32P),
+        ("n_pair", C.c_int32),
+        ("pair_shape", _I32P),
+        ("gravity", C.c_float * 3),
+        ("timestep", C.c_float),
+        ("contact_offset", C.c_float),
+        ("rest_offset", C.c_float),
+        ("bounce_threshold", C.c_float),
+        ("position_iterations", C.c_int32),
+        ("velocity_iterations", C.c_int32),
+        ("erp", C.c_float),
+        ("max_depenetration_velocity", C.c_float),
+        ("sleep_threshold", C.c_float),
+    ]
+
+
+class Buffers(C.Structure):
+    _fields_ = [
+        ("rigid_body_data", C.c_void_p),
+        ("rigid_body_force", C.c_void_p),
+        ("art_qpos", C.c_void_p),
+        ("art_qvel", C.c_void_p),
+        ("art_qacc", C.c_void_p),
+        ("art_qf", C.c_void_p),
+        ("art_target_qpos", C.c_void_p),
+        ("art_target_qvel", C.c_void_p),
+    ]
+
+
+def make_model_desc(model: CompiledModel):
+    """Returns (ModelDesc, keepalive) -- keepalive must outlive the create call."""
+    d = ModelDesc()
+    keep = []
+    d.abi_version = ABI_VERSION
+    for name, ctype in ModelDesc._fields_:
+        if ctype in (_I32P, _F32P):
+            a = model.arrays[name]
+            want = np.int32 if ctype is _I32P else np.float32
+            a = np.ascontiguousarray(a, dtype=want)
+            keep.append(a)
+            setattr(d, name, a.ctypes.data_as(ctype))
+        elif name == "gravity":
+            d.gravity = (C.c_float * 3)(*model.scalars["gravity"])
+        elif name != "abi_version":
+            setattr(d, name, model.scalars[name])
+    return d, keep
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class NativeLib:
+    """One loaded library exporting the mssim ABI under `prefix`."""
+
+    _cache: Dict[tuple, "NativeLib"] = {}
+
+    def __init__(self, path: str, prefix: str = "mssim_"):
+        if not os.path.exists(path):
+            raise NativeError(
+                f"native simulation library not found: {path}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback."
+            )
+        self.path, self.prefix = path, prefix
+        self.lib = C.CDLL(path)
+        f = self._fn
+        H = C.c_void_p
+        f("create", C.c_int, [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.POINTER(H)])
+        f("destroy", None, [H])
+        f("bind_buffers", C.c_int, [H, C.POINTER(Buffers)])
+        f("set_timestep", C.c_int, [H, C.c_float])
+        f("get_timestep", C.c_float, [H])
+        f("apply", C.c_int, [H, C.c_uint32, C.c_void_p])
+        f("fetch", C.c_int, [H, C.c_uint32, C.c_void_p])
+        f("step", C.c_int, [H, C.c_int32, C.c_void_p])
+        f("update_kinematics", C.c_int, [H, C.c_void_p])
+        f("create_pair_query", C.c_int, [H, _I32P, C.c_int32, _I32P])
+        f("query_pair_impulses", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
+        f("create_body_query", C.c_int, [H, _I32P, C.c_int32, _I32P])
+        f("query_body_impulses", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
+        f("set_drive_properties", C.c_int, [H, _F32P])
+        f("read_internal", C.c_int, [H, C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p])
+        f("overflow_count", C.c_int, [H, C.c_void_p])
+        f("last_error", C.c_char_p, [H])
+        f("abi_version", C.c_int, [])
+        if self.abi_version() != ABI_VERSION:
+            raise NativeError(f"{path}: ABI version {self.abi_version()} != {ABI_VERSION}")
+
+    EXPORTS = [
+        "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
+        "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
+        "query_body_impulses", "set_drive_properties", "read_internal", "overflow_count", "last_error",
+        "abi_version",
+    ]
+
+    def _fn(self, name, restype, argtypes):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype, fn.argtypes = restype, argtypes
+        setattr(self, name, fn)
+
+    @classmethod
+    def load(cls, path: Optional[str] = None, prefix: str = "mssim_") -> "NativeLib":
+        path = path or NATIVE_LIB_PATH
+        key = (os.path.abspath(path), prefix)
+        if key not in cls._cache:
+            cls._cache[key] = cls(path, prefix)
+        return cls._cache[key]
+
+
+class NativeSim:
+    """Owns one `mssim_handle`."""
+
+    def __init__(self, lib: NativeLib, model: CompiledModel, num_envs: int, device: int):
+        self.lib, self.model, self.num_envs, self.device = lib, model, num_envs, device
+        desc, keep = make_model_desc(model)
+        h = C.c_void_p()
+        rc = lib.create(C.byref(desc), num_envs, device, C.byref(h))
+        if rc != 0:
+            msg = lib.last_error(None)
+            raise NativeError(f"mssim create failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = h
+        self._queries = {}
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.last_error(self.h)
+            raise NativeError(f"mssim {what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, **ptrs):
+        b = Buffers()
+        for k, v in ptrs.items():
+            setattr(b, k, v)
+        self._check(self.lib.bind_buffers(self.h, C.byref(b)), "bind_buffers")
+
+    def apply(self, what, stream=None):
+        self._check(self.lib.apply(self.h, what, stream), "apply")
+
+    def fetch(self, what, stream=None):
+        self._check(self.lib.fetch(self.h, what, stream), "fetch")
+
+    def step(self, n_substeps=1, stream=None):
+        self._check(self.lib.step(self.h, n_substeps, stream), "step")
+
+    def update_kinematics(self, stream=None):
+        self._check(self.lib.update_kinematics(self.h, stream), "update_kinematics")
+
+    def set_timestep(self, dt):
+        self._check(self.lib.set_timestep(self.h, dt), "set_timestep")
+
+    def get_timestep(self):
+        return float(self.lib.get_timestep(self.h))
+
+    def create_pair_query(self, body_pairs):
+        a = np.ascontiguousarray(body_pairs, dtype=np.int32).reshape(-1, 2)
+        qid = C.c_int32()
+        self._check(self.lib.create_pair_query(self.h, a.ctypes.data_as(_I32P), len(a), C.byref(qid)), "create_pair_query")
+        return qid.value
+
+    def query_pair_impulses(self, qid, out_ptr, stream=None):
+        self._check(self.lib.query_pair_impulses(self.h, qid, out_ptr, stream), "query_pair_impulses")
+
+    def create_body_query(self, rows):
+        a = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1)
+        qid = C.c_int32()
+        self._check(self.lib.create_body_query(self.h, a.ctypes.data_as(_I32P), len(a), C.byref(qid)), "create_body_query")
+        return qid.value
+
+    def query_body_impulses(self, qid, out_ptr, stream=None):
+        self._check(self.lib.query_body_impulses(self.h, qid, out_ptr, stream), "query_body_impulses")
+
+    def set_drive_properties(self, drive):
+        a = np.ascontiguousarray(drive, dtype=np.float32).reshape(-1, 4)
+        assert a.shape[0] == self.model.n_dof
+        self._check(self.lib.set_drive_properties(self.h, a.ctypes.data_as(_F32P)), "set_drive_properties")
+
+    def read_internal(self, name, out_ptr, max_items, stream=None):
+        n = self.lib.read_internal(self.h, name.encode(), out_ptr, max_items, stream)
+        if n < 0:
+            self._check(n, f"read_internal({name})")
+        return n
+
+    def overflow_count(self, stream=None):
+        return int(self.lib.overflow_count(self.h, stream))

@@ -1,0 +1,811 @@
+// oracle_sim.cpp -- CPU restatement of the batched rigid-body step (TEST INFRASTRUCTURE ONLY).
+//
+// Exports the ABI of include/mssim.h under the prefix `mssim_ref_` with HOST pointers. It is the
+// oracle the HIP kernels are checked against and the `cpu_baseline` of bench.py; nothing under
+// maniskill_amd/ links or calls it.
+//
+// PARITY UNPINNED vs PhysX: the reference (ManiSkill) contains no physics source -- the step is
+// `px.step()` into the closed SAPIEN/PhysX wheel (mani_skill/envs/scene.py:374-375), which is not
+// installed here, and none of the reference's tests hold numeric physics vectors.
+// This oracle therefore restates the stages of SURVEY.md 2.2 from the published algorithms with
+// the reference's parameters (mani_skill/utils/structs/types.py:36-67,
+// agents/robots/panda/panda.py:68-74, agents/controllers/pd_joint_pos.py:35-49) and is itself
+// pinned by closed-form / independent-algorithm tests in tests/test_oracle_*.py.
+//
+// One substep (dt = timestep), per env:
+//   1. FK                        world pose of every moving body           (Featherstone, RBDA ch.4)
+//   2. narrowphase               oracle_collide.hpp on the candidate pairs
+//   3. joint-space dynamics      CRBA mass matrix M, RNEA bias c           (RBDA ch.5, ch.6)
+//      implicit PD drives + tendon:  A = M + dt*Kd + dt^2*Kp (+ tendon), force-limit active set
+//      unconstrained velocity        qd* = A^-1 (M qd + dt (tau0 - c + qf))
+//   4. rows: joint limits, contact normal + 2 friction (pyramid) per point
+//   5. projected Gauss-Seidel: `position_iterations` with bias, then `velocity_iterations`
+//      without penetration bias (types.py:42-43: 15 + 1)
+//   6. semi-implicit Euler; FK at the new state for the link pose / velocity outputs
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define MSSIM_PREFIX mssim_ref_
+#include "../include/mssim.h"
+#include "oracle_collide.hpp"
+
+#ifndef ORACLE_REAL
+#define ORACLE_REAL double
+#endif
+typedef ORACLE_REAL Real;
+using namespace orc;
+typedef V3<Real> Vec;
+typedef Q4<Real> Quat;
+typedef M3<Real> Mat;
+
+namespace {
+
+const int MAXC = 48;  // contact points per env fed to the solver
+std::string g_create_error;
+
+struct SpatialV { Vec w, v; };           // motion: angular, linear (of the point at the origin O)
+struct SpatialF { Vec n, f; };           // force: moment about O, force
+struct SpatialI { Real m; Vec h; Mat I; };  // inertia about O: mass, m*c, rotational
+
+inline SpatialV crossm(const SpatialV& a, const SpatialV& b) { return {cross(a.w, b.w), cross(a.w, b.v) + cross(a.v, b.w)}; }
+inline SpatialF crossf(const SpatialV& a, const SpatialF& b) { return {cross(a.w, b.n) + cross(a.v, b.f), cross(a.w, b.f)}; }
+inline SpatialF imul(const SpatialI& I, const SpatialV& a) { return {I.I * a.w + cross(I.h, a.v), a.v * I.m - cross(I.h, a.w)}; }
+inline Real sdot(const SpatialV& s, const SpatialF& f) { return dot(s.w, f.n) + dot(s.v, f.f); }
+
+struct Model {
+  int n_dof = 0, n_tendon = 0, n_link = 0, n_free = 0, n_kin = 0, n_shape = 0, n_pair = 0;
+  std::vector<int32_t> dof_parent, dof_type, body_gravity, tendon_dof, link_body, free_gravity;
+  std::vector<float> dof_frame, dof_axis, dof_limit, dof_drive, dof_armature, body_inertial, tendon_param, link_frame;
+  std::vector<float> free_inertial, free_damping;
+  std::vector<int32_t> shape_type, shape_kind, shape_index, shape_row, shape_hull, pair_shape;
+  std::vector<float> shape_frame, shape_param, shape_material, shape_bound, hull_verts;
+  Real gravity[3], dt, contact_offset, rest_offset, erp, max_depen;
+  int pos_iters, vel_iters;
+};
+
+struct Contact {
+  int pair, ka, ia, kb, ib;  // pair index, body kinds / indices
+  Vec x, n;
+  Real sep, mu;
+  Real lam[3];
+};
+
+struct EnvState {
+  Pose<Real> root;
+  std::vector<Real> q, qd, qt, qdt, qf, qacc;
+  std::vector<Pose<Real>> free_pose;
+  std::vector<Vec> free_v, free_w, free_force;
+  std::vector<Pose<Real>> kin_pose;
+  // derived
+  std::vector<Pose<Real>> body_pose;  // moving bodies
+  std::vector<SpatialV> body_vel;     // about O = root position
+  std::vector<Vec> pair_impulse;
+  std::vector<int> pair_count;
+  int overflow = 0;
+};
+
+template <typename T> std::vector<T> cp(const T* p, size_t n) { return p ? std::vector<T>(p, p + n) : std::vector<T>(n); }
+inline Pose<Real> pose7(const float* f) {
+  Pose<Real> p;
+  p.p = Vec(f[0], f[1], f[2]);
+  p.q = qnormalized(Quat(f[3], f[4], f[5], f[6]));
+  return p;
+}
+
+}  // namespace
+
+struct mssim_sim {
+  Model M;
+  int N = 0;
+  std::vector<EnvState> env;
+  mssim_buffers buf{};
+  std::string err;
+  std::vector<std::vector<int32_t>> pair_queries, body_queries;
+  int overflow_total = 0;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ kinematics
+void fk(const Model& M, EnvState& E, std::vector<Vec>* axis_w, std::vector<Vec>* anchor) {
+  int n = M.n_dof;
+  E.body_pose.resize(n);
+  if (axis_w) axis_w->resize(n);
+  if (anchor) anchor->resize(n);
+  for (int j = 0; j < n; j++) {
+    const Pose<Real>& P = M.dof_parent[j] < 0 ? E.root : E.body_pose[M.dof_parent[j]];
+    Pose<Real> J = pmul(P, pose7(&M.dof_frame[7 * j]));
+    Vec al(M.dof_axis[3 * j], M.dof_axis[3 * j + 1], M.dof_axis[3 * j + 2]);
+    Vec aw = qrot(J.q, al);
+    Pose<Real> B = J;
+    if (M.dof_type[j] == MSSIM_JOINT_REVOLUTE) B.q = qnormalized(qmul(J.q, qaxis_angle(al, E.q[j])));
+    else B.p = J.p + aw * E.q[j];
+    E.body_pose[j] = B;
+    if (axis_w) (*axis_w)[j] = aw;
+    if (anchor) (*anchor)[j] = J.p;
+  }
+}
+
+inline SpatialV joint_subspace(const Model& M, int j, const Vec& aw, const Vec& anchor, const Vec& O) {
+  if (M.dof_type[j] == MSSIM_JOINT_REVOLUTE) return {aw, cross(anchor - O, aw)};
+  return {Vec(), aw};
+}
+
+void body_velocities(const Model& M, EnvState& E, const std::vector<Vec>& axis_w, const std::vector<Vec>& anchor,
+                     const std::vector<Real>& qd) {
+  int n = M.n_dof;
+  E.body_vel.resize(n);
+  Vec O = E.root.p;
+  for (int j = 0; j < n; j++) {
+    SpatialV S = joint_subspace(M, j, axis_w[j], anchor[j], O);
+    SpatialV V = M.dof_parent[j] < 0 ? SpatialV{Vec(), Vec()} : E.body_vel[M.dof_parent[j]];
+    V.w += S.w * qd[j];
+    V.v += S.v * qd[j];
+    E.body_vel[j] = V;
+  }
+}
+
+Pose<Real> body_world_pose(const Model& M, const EnvState& E, int kind, int index) {
+  switch (kind) {
+    case MSSIM_BODY_ART: return index < 0 ? E.root : E.body_pose[index];
+    case MSSIM_BODY_FREE: return E.free_pose[index];
+    case MSSIM_BODY_KIN: return E.kin_pose[index];
+    default: return Pose<Real>();
+  }
+}
+
+Shape<Real> make_shape(const Model& M, const EnvState& E, int s) {
+  Shape<Real> sh;
+  Pose<Real> W = pmul(body_world_pose(M, E, M.shape_kind[s], M.shape_index[s]), pose7(&M.shape_frame[7 * s]));
+  sh.type = M.shape_type[s];
+  sh.c = W.p;
+  sh.rot = qmat(W.q);
+  for (int k = 0; k < 4; k++) sh.param[k] = M.shape_param[4 * s + k];
+  sh.verts = M.hull_verts.data() + 3 * M.shape_hull[2 * s];
+  sh.nverts = M.shape_hull[2 * s + 1];
+  return sh;
+}
+
+// ------------------------------------------------------------------ narrowphase over the pair table
+void narrowphase(const Model& M, EnvState& E, std::vector<Contact>& out) {
+  out.clear();
+  E.pair_count.assign(M.n_pair, 0);
+  std::vector<Shape<Real>> sh(M.n_shape);
+  for (int s = 0; s < M.n_shape; s++) sh[s] = make_shape(M, E, s);
+  for (int p = 0; p < M.n_pair; p++) {
+    int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+    const Shape<Real>&A = sh[sa], &B = sh[sb];
+    // bounding-sphere cull
+    Real ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
+    Vec ca = A.c + A.rot * Vec(M.shape_bound[4 * sa], M.shape_bound[4 * sa + 1], M.shape_bound[4 * sa + 2]);
+    Vec cb = B.c + B.rot * Vec(M.shape_bound[4 * sb], M.shape_bound[4 * sb + 1], M.shape_bound[4 * sb + 2]);
+    if (A.type == SH_PLANE) {
+      if (dot(A.rot.col(0), cb - A.c) > rb + M.contact_offset) continue;
+    } else {
+      Vec d = cb - ca;
+      Real rr = ra + rb + M.contact_offset;
+      if (dot(d, d) > rr * rr) continue;
+    }
+    Manifold<Real> m;
+    collide(A, B, M.contact_offset, m);
+    E.pair_count[p] = m.count;
+    Real mu = Real(0.5) * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
+    for (int k = 0; k < m.count; k++) {
+      if ((int)out.size() >= MAXC) { E.overflow = 1; break; }
+      Contact c;
+      c.pair = p;
+      c.ka = M.shape_kind[sa]; c.ia = M.shape_index[sa];
+      c.kb = M.shape_kind[sb]; c.ib = M.shape_index[sb];
+      c.x = m.x[k]; c.n = m.n; c.sep = m.sep[k] - M.rest_offset; c.mu = mu;
+      c.lam[0] = c.lam[1] = c.lam[2] = 0;
+      out.push_back(c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dense SPD solve (LDL^T)
+bool ldl_factor(int n, std::vector<Real>& A) {  // in place, lower: L (unit) below diag, D on diag
+  for (int j = 0; j < n; j++) {
+    Real d = A[j * n + j];
+    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k] * A[k * n + k];
+    if (!(d > Real(0))) return false;
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      Real v = A[i * n + j];
+      for (int k = 0; k < j; k++) v -= A[i * n + k] * A[j * n + k] * A[k * n + k];
+      A[i * n + j] = v / d;
+    }
+  }
+  return true;
+}
+void ldl_solve(int n, const std::vector<Real>& L, Real* b) {
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < i; k++) b[i] -= L[i * n + k] * b[k];
+  for (int i = 0; i < n; i++) b[i] /= L[i * n + i];
+  for (int i = n - 1; i >= 0; i--)
+    for (int k = i + 1; k < n; k++) b[i] -= L[k * n + i] * b[k];
+}
+
+struct Row {
+  // sparse-dense row: articulation part (n_dof) + up to two free bodies
+  std::vector<Real> Ja, Wa;
+  int f[2];
+  Vec Jl[2], Jw[2], Wl[2], Ww[2];
+  Real diag, bias_pos, bias_vel, lo, hi, lam;
+  int friction_of;  // index of the normal row bounding this friction row, -1 otherwise
+  Real mu;
+  int contact, dirk;  // contact index / direction (0 n, 1 t1, 2 t2), -1 for limits
+};
+
+// ------------------------------------------------------------------ one substep
+void substep(mssim_sim* S, EnvState& E) {
+  const Model& M = S->M;
+  const int n = M.n_dof, nf = M.n_free;
+  const Real dt = M.dt;
+  Vec g(M.gravity[0], M.gravity[1], M.gravity[2]);
+  Vec O = E.root.p;
+
+  // 1. FK
+  std::vector<Vec> axis_w, anchor;
+  fk(M, E, &axis_w, &anchor);
+  // 2. narrowphase
+  std::vector<Contact> contacts;
+  narrowphase(M, E, contacts);
+
+  // 3. joint-space dynamics
+  std::vector<SpatialV> Sj(n);
+  std::vector<SpatialI> I(n), Ic(n);
+  std::vector<SpatialV> V(n), Ab(n);
+  std::vector<SpatialF> F(n);
+  for (int j = 0; j < n; j++) {
+    Sj[j] = joint_subspace(M, j, axis_w[j], anchor[j], O);
+    const float* in = &M.body_inertial[10 * j];
+    Mat Rm = qmat(E.body_pose[j].q);
+    Real Iv[6] = {in[4], in[5], in[6], in[7], in[8], in[9]};
+    Mat Iw = mmul(mmul(Rm, sym3(Iv)), mtranspose(Rm));
+    Vec c = E.body_pose[j].p + Rm * Vec(in[1], in[2], in[3]) - O;
+    Real m = in[0];
+    Real cc = dot(c, c);
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) Iw.m[a][b] += m * ((a == b ? cc : Real(0)) - c[a] * c[b]);
+    I[j] = {m, c * m, Iw};
+  }
+  for (int j = 0; j < n; j++) {
+    int p = M.dof_parent[j];
+    SpatialV Vp = p < 0 ? SpatialV{Vec(), Vec()} : V[p];
+    SpatialV Ap = p < 0 ? SpatialV{Vec(), Vec()} : Ab[p];
+    V[j] = {Vp.w + Sj[j].w * E.qd[j], Vp.v + Sj[j].v * E.qd[j]};
+    SpatialV cr = crossm(V[j], Sj[j]);
+    Ab[j] = {Ap.w + cr.w * E.qd[j], Ap.v + cr.v * E.qd[j]};
+    SpatialF f1 = imul(I[j], Ab[j]);
+    SpatialF f2 = crossf(V[j], imul(I[j], V[j]));
+    F[j] = {f1.n + f2.n, f1.f + f2.f};
+    if (M.body_gravity[j]) {  // external force m*g at the COM
+      F[j].f -= g * I[j].m;
+      F[j].n -= cross(I[j].h, g);
+    }
+  }
+  std::vector<Real> bias(n), Mq(n * n, Real(0));
+  for (int j = 0; j < n; j++) Ic[j] = I[j];
+  for (int j = n - 1; j >= 0; j--) {
+    bias[j] = sdot(Sj[j], F[j]);
+    int p = M.dof_parent[j];
+    if (p >= 0) {
+      F[p].n += F[j].n; F[p].f += F[j].f;
+      Ic[p].m += Ic[j].m; Ic[p].h += Ic[j].h;
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Ic[p].I.m[a][b] += Ic[j].I.m[a][b];
+    }
+  }
+  for (int j = 0; j < n; j++) {
+    SpatialF Fc = imul(Ic[j], Sj[j]);
+    Mq[j * n + j] = sdot(Sj[j], Fc) + M.dof_armature[j];
+    for (int i = M.dof_parent[j]; i >= 0; i = M.dof_parent[i]) Mq[j * n + i] = Mq[i * n + j] = sdot(Sj[i], Fc);
+  }
+  // drives, tendons (implicit)
+  std::vector<Real> A(Mq), rhs(n), tau0(n), Dj(n), kp(n), kd(n);
+  for (int j = 0; j < n; j++) {
+    kp[j] = M.dof_drive[4 * j]; kd[j] = M.dof_drive[4 * j + 1];
+    if ((int)M.dof_drive[4 * j + 3] == MSSIM_DRIVE_ACCELERATION) { kp[j] *= Mq[j * n + j]; kd[j] *= Mq[j * n + j]; }
+    tau0[j] = kp[j] * (E.qt[j] - E.q[j]) + kd[j] * E.qdt[j];
+    Dj[j] = dt * kd[j] + dt * dt * kp[j];
+    A[j * n + j] += Dj[j];
+  }
+  std::vector<Real> tau_t(n, Real(0));
+  for (int t = 0; t < M.n_tendon; t++) {
+    int a = M.tendon_dof[2 * t], b = M.tendon_dof[2 * t + 1];
+    const float* tp = &M.tendon_param[5 * t];
+    Real ca = tp[0], cb = tp[1], c = ca * E.q[a] + cb * E.q[b] - tp[2];
+    Real k = tp[3], d = tp[4], w = dt * dt * k + dt * d;
+    tau_t[a] -= k * c * ca; tau_t[b] -= k * c * cb;
+    A[a * n + a] += w * ca * ca; A[b * n + b] += w * cb * cb;
+    A[a * n + b] += w * ca * cb; A[b * n + a] += w * ca * cb;
+  }
+  for (int j = 0; j < n; j++) {
+    Real mv = 0;
+    for (int k = 0; k < n; k++) mv += Mq[j * n + k] * E.qd[k];
+    rhs[j] = mv + dt * (tau0[j] + tau_t[j] - bias[j] + E.qf[j]);
+  }
+  std::vector<Real> L(A), qds(rhs);
+  std::vector<Real> Ainv(n * n, Real(0));
+  if (n > 0) {
+    ldl_factor(n, L);
+    ldl_solve(n, L, qds.data());
+    // force-limit active set (one pass)
+    bool any = false;
+    for (int j = 0; j < n; j++) {
+      Real fmax = M.dof_drive[4 * j + 2];
+      if (!(fmax < Real(1e30))) continue;
+      Real td = kp[j] * (E.qt[j] - E.q[j] - dt * qds[j]) + kd[j] * (E.qdt[j] - qds[j]);
+      if (std::fabs(td) > fmax) {
+        Real sat = td > 0 ? fmax : -fmax;
+        A[j * n + j] -= Dj[j];
+        rhs[j] += dt * (sat - tau0[j]);
+        any = true;
+      }
+    }
+    if (any) {
+      L = A; qds = rhs;
+      ldl_factor(n, L);
+      ldl_solve(n, L, qds.data());
+    }
+    for (int c = 0; c < n; c++) {
+      std::vector<Real> e(n, Real(0));
+      e[c] = 1;
+      ldl_solve(n, L, e.data());
+      for (int r = 0; r < n; r++) Ainv[r * n + c] = e[r];
+    }
+  }
+  // free bodies: unconstrained velocity
+  std::vector<Vec> fv(nf), fw(nf), fcom(nf);
+  std::vector<Mat> fIinv(nf);
+  std::vector<Real> fminv(nf);
+  for (int b = 0; b < nf; b++) {
+    const float* in = &M.free_inertial[10 * b];
+    Mat Rm = qmat(E.free_pose[b].q);
+    Real Iv[6] = {in[4], in[5], in[6], in[7], in[8], in[9]};
+    Mat Iw = mmul(mmul(Rm, sym3(Iv)), mtranspose(Rm));
+    fIinv[b] = minverse(Iw);
+    fminv[b] = Real(1) / in[0];
+    fcom[b] = E.free_pose[b].p + Rm * Vec(in[1], in[2], in[3]);
+    Vec acc = E.free_force[b] * fminv[b];
+    if (M.free_gravity[b]) acc += g;
+    Vec v = E.free_v[b] + acc * dt;
+    Vec w = E.free_w[b] - fIinv[b] * cross(E.free_w[b], Iw * E.free_w[b]) * dt;
+    Real ld = Real(1) - dt * M.free_damping[2 * b], ad = Real(1) - dt * M.free_damping[2 * b + 1];
+    fv[b] = v * (ld > 0 ? ld : Real(0));
+    fw[b] = w * (ad > 0 ? ad : Real(0));
+  }
+
+  // 4. rows
+  std::vector<Row> rows;
+  auto art_point_jac = [&](int body, const Vec& x, const Vec& d, Real sign, std::vector<Real>& Ja) {
+    for (int i = body; i >= 0; i = M.dof_parent[i]) {
+      Vec col = M.dof_type[i] == MSSIM_JOINT_REVOLUTE ? cross(axis_w[i], x - anchor[i]) : axis_w[i];
+      Ja[i] += sign * dot(d, col);
+    }
+  };
+  for (int j = 0; j < n; j++) {
+    Real lo = M.dof_limit[2 * j], hi = M.dof_limit[2 * j + 1];
+    if (!(lo > Real(-1e30)) && !(hi < Real(1e30))) continue;
+    Real dlo = E.q[j] - lo, dhi = hi - E.q[j];
+    Real side = dlo <= dhi ? Real(1) : Real(-1);
+    Real C = dlo <= dhi ? dlo : dhi;
+    Row r;
+    r.Ja.assign(n, 0); r.Wa.assign(n, 0);
+    r.Ja[j] = side;
+    for (int k = 0; k < n; k++) r.Wa[k] = side * Ainv[k * n + j];
+    r.f[0] = r.f[1] = -1;
+    r.diag = Ainv[j * n + j];
+    r.bias_pos = C >= 0 ? C / dt : std::max(M.erp * C / dt, -M.max_depen);
+    r.bias_vel = C >= 0 ? C / dt : Real(0);
+    r.lo = 0; r.hi = Real(1e30); r.lam = 0; r.friction_of = -1; r.mu = 0; r.contact = -1; r.dirk = -1;
+    rows.push_back(r);
+  }
+  for (size_t ci = 0; ci < contacts.size(); ci++) {
+    Contact& c = contacts[ci];
+    Vec nrm = c.n;
+    Vec t1 = std::fabs(nrm.x) < Real(0.57735) ? normalized(cross(nrm, Vec(1, 0, 0))) : normalized(cross(nrm, Vec(0, 1, 0)));
+    Vec t2 = cross(nrm, t1);
+    Vec dirs[3] = {nrm, t1, t2};
+    int nrow = (int)rows.size();
+    for (int k = 0; k < 3; k++) {
+      Row r;
+      r.Ja.assign(n, 0); r.Wa.assign(n, 0);
+      r.f[0] = r.f[1] = -1;
+      int nfree = 0;
+      bool hasart = false;
+      const int kinds[2] = {c.ka, c.kb}, idx[2] = {c.ia, c.ib};
+      for (int s = 0; s < 2; s++) {
+        Real sign = s == 0 ? Real(1) : Real(-1);
+        if (kinds[s] == MSSIM_BODY_ART && idx[s] >= 0) { art_point_jac(idx[s], c.x, dirs[k], sign, r.Ja); hasart = true; }
+        else if (kinds[s] == MSSIM_BODY_FREE) {
+          int b = idx[s];
+          r.f[nfree] = b;
+          r.Jl[nfree] = dirs[k] * sign;
+          r.Jw[nfree] = cross(c.x - fcom[b], dirs[k]) * sign;
+          r.Wl[nfree] = r.Jl[nfree] * fminv[b];
+          r.Ww[nfree] = fIinv[b] * r.Jw[nfree];
+          nfree++;
+        }
+      }
+      Real diag = 0;
+      if (hasart)
+        for (int i = 0; i < n; i++) {
+          Real w = 0;
+          for (int j = 0; j < n; j++) w += Ainv[i * n + j] * r.Ja[j];
+          r.Wa[i] = w;
+          diag += r.Ja[i] * w;
+        }
+      for (int s = 0; s < nfree; s++) diag += dot(r.Jl[s], r.Wl[s]) + dot(r.Jw[s], r.Ww[s]);
+      r.diag = diag;
+      r.lam = 0; r.contact = (int)ci; r.dirk = k; r.mu = c.mu;
+      if (k == 0) {
+        r.bias_pos = c.sep >= 0 ? c.sep / dt : std::max(M.erp * c.sep / dt, -M.max_depen);
+        r.bias_vel = c.sep >= 0 ? c.sep / dt : Real(0);
+        r.lo = 0; r.hi = Real(1e30); r.friction_of = -1;
+      } else {
+        r.bias_pos = r.bias_vel = 0; r.lo = r.hi = 0; r.friction_of = nrow;
+      }
+      rows.push_back(r);
+    }
+  }
+
+  // 5. PGS
+  std::vector<Real> v(qds);
+  auto sweep = [&](bool use_bias) {
+    for (size_t ri = 0; ri < rows.size(); ri++) {
+      Row& r = rows[ri];
+      if (!(r.diag > Real(1e-12))) continue;
+      Real jv = 0;
+      for (int i = 0; i < n; i++) jv += r.Ja[i] * v[i];
+      for (int s = 0; s < 2; s++)
+        if (r.f[s] >= 0) jv += dot(r.Jl[s], fv[r.f[s]]) + dot(r.Jw[s], fw[r.f[s]]);
+      Real lo = r.lo, hi = r.hi;
+      if (r.friction_of >= 0) { hi = r.mu * rows[r.friction_of].lam; lo = -hi; }
+      Real b = use_bias ? r.bias_pos : r.bias_vel;
+      Real nl = r.lam - (jv + b) / r.diag;
+      nl = nl < lo ? lo : (nl > hi ? hi : nl);
+      Real dl = nl - r.lam;
+      r.lam = nl;
+      if (dl != Real(0)) {
+        for (int i = 0; i < n; i++) v[i] += r.Wa[i] * dl;
+        for (int s = 0; s < 2; s++)
+          if (r.f[s] >= 0) { fv[r.f[s]] += r.Wl[s] * dl; fw[r.f[s]] += r.Ww[s] * dl; }
+      }
+    }
+  };
+  for (int it = 0; it < M.pos_iters; it++) sweep(true);
+  std::vector<Real> v_pos(v);
+  std::vector<Vec> fv_pos(fv), fw_pos(fw);
+  for (int it = 0; it < M.vel_iters; it++) sweep(false);
+
+  // contact impulses per pair (world frame, on shape A's body)
+  E.pair_impulse.assign(M.n_pair, Vec());
+  for (const Row& r : rows) {
+    if (r.contact < 0) continue;
+    const Contact& c = contacts[r.contact];
+    Vec nrm = c.n;
+    Vec t1 = std::fabs(nrm.x) < Real(0.57735) ? normalized(cross(nrm, Vec(1, 0, 0))) : normalized(cross(nrm, Vec(0, 1, 0)));
+    Vec t2 = cross(nrm, t1);
+    Vec d = r.dirk == 0 ? nrm : (r.dirk == 1 ? t1 : t2);
+    E.pair_impulse[c.pair] += d * r.lam;
+  }
+
+  // 6. integrate
+  for (int j = 0; j < n; j++) {
+    E.qacc[j] = (v[j] - E.qd[j]) / dt;
+    E.q[j] += dt * v_pos[j];
+    E.qd[j] = v[j];
+  }
+  for (int b = 0; b < nf; b++) {
+    const float* in = &M.free_inertial[10 * b];
+    Vec com = fcom[b] + fv_pos[b] * dt;
+    Quat q = E.free_pose[b].q;
+    Vec w = fw_pos[b];
+    Quat dq = qmul(Quat(0, w.x, w.y, w.z), q);
+    q = qnormalized(Quat(q.w + Real(0.5) * dt * dq.w, q.x + Real(0.5) * dt * dq.x, q.y + Real(0.5) * dt * dq.y,
+                         q.z + Real(0.5) * dt * dq.z));
+    E.free_pose[b].q = q;
+    E.free_pose[b].p = com - qrot(q, Vec(in[1], in[2], in[3]));
+    E.free_v[b] = fv[b];
+    E.free_w[b] = fw[b];
+    E.free_force[b] = Vec();
+  }
+  fk(M, E, &axis_w, &anchor);
+  body_velocities(M, E, axis_w, anchor, E.qd);
+}
+
+void refresh_kinematics(mssim_sim* S, EnvState& E) {
+  std::vector<Vec> axis_w, anchor;
+  fk(S->M, E, &axis_w, &anchor);
+  body_velocities(S->M, E, axis_w, anchor, E.qd);
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" {
+
+int mssim_ref_abi_version(void) { return MSSIM_ABI_VERSION; }
+
+const char* mssim_ref_last_error(mssim_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mssim_ref_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, mssim_handle* out) {
+  (void)device;
+  if (!d || !out || num_envs <= 0) { g_create_error = "bad arguments"; return 1; }
+  if (d->abi_version != MSSIM_ABI_VERSION) { g_create_error = "ABI version mismatch"; return 2; }
+  if (d->n_dof > MSSIM_MAX_DOF || d->n_free > MSSIM_MAX_FREE) { g_create_error = "model exceeds MSSIM_MAX_DOF / MSSIM_MAX_FREE"; return 3; }
+  mssim_sim* S = new mssim_sim();
+  Model& M = S->M;
+  M.n_dof = d->n_dof; M.n_tendon = d->n_tendon; M.n_link = d->n_link; M.n_free = d->n_free; M.n_kin = d->n_kin;
+  M.n_shape = d->n_shape; M.n_pair = d->n_pair;
+  int n = d->n_dof;
+  M.dof_parent = cp(d->dof_parent, n); M.dof_type = cp(d->dof_type, n); M.body_gravity = cp(d->body_gravity, n);
+  M.dof_frame = cp(d->dof_frame, 7 * n); M.dof_axis = cp(d->dof_axis, 3 * n); M.dof_limit = cp(d->dof_limit, 2 * n);
+  M.dof_drive = cp(d->dof_drive, 4 * n); M.dof_armature = cp(d->dof_armature, n); M.body_inertial = cp(d->body_inertial, 10 * n);
+  M.tendon_dof = cp(d->tendon_dof, 2 * d->n_tendon); M.tendon_param = cp(d->tendon_param, 5 * d->n_tendon);
+  M.link_body = cp(d->link_body, d->n_link); M.link_frame = cp(d->link_frame, 7 * d->n_link);
+  M.free_inertial = cp(d->free_inertial, 10 * d->n_free); M.free_damping = cp(d->free_damping, 2 * d->n_free);
+  M.free_gravity = cp(d->free_gravity, d->n_free);
+  int ns = d->n_shape;
+  M.shape_type = cp(d->shape_type, ns); M.shape_kind = cp(d->shape_body_kind, ns); M.shape_index = cp(d->shape_body_index, ns);
+  M.shape_row = cp(d->shape_row, ns); M.shape_frame = cp(d->shape_frame, 7 * ns); M.shape_param = cp(d->shape_param, 4 * ns);
+  M.shape_material = cp(d->shape_material, 4 * ns); M.shape_hull = cp(d->shape_hull, 2 * ns); M.shape_bound = cp(d->shape_bound, 4 * ns);
+  M.hull_verts = cp(d->hull_verts, 3 * d->n_hull_verts); M.pair_shape = cp(d->pair_shape, 2 * d->n_pair);
+  for (int k = 0; k < 3; k++) M.gravity[k] = d->gravity[k];
+  M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
+  M.max_depen = d->max_depenetration_velocity; M.pos_iters = d->position_iterations; M.vel_iters = d->velocity_iterations;
+  for (int j = 0; j < n; j++)
+    if (M.dof_parent[j] >= j) { g_create_error = "dof_parent must be topologically sorted"; delete S; return 4; }
+  S->N = num_envs;
+  S->env.resize(num_envs);
+  for (auto& E : S->env) {
+    E.q.assign(n, 0); E.qd.assign(n, 0); E.qt.assign(n, 0); E.qdt.assign(n, 0); E.qf.assign(n, 0); E.qacc.assign(n, 0);
+    E.free_pose.resize(M.n_free); E.free_v.resize(M.n_free); E.free_w.resize(M.n_free); E.free_force.resize(M.n_free);
+    E.kin_pose.resize(M.n_kin);
+    E.pair_impulse.assign(M.n_pair, Vec()); E.pair_count.assign(M.n_pair, 0);
+    refresh_kinematics(S, E);
+  }
+  *out = S;
+  return 0;
+}
+
+void mssim_ref_destroy(mssim_handle h) { delete h; }
+
+int mssim_ref_bind_buffers(mssim_handle h, const mssim_buffers* b) {
+  if (!h || !b) return 1;
+  h->buf = *b;
+  return 0;
+}
+
+int mssim_ref_set_timestep(mssim_handle h, float dt) {
+  if (!(dt > 0)) { h->err = "timestep must be positive"; return 1; }
+  h->M.dt = dt;
+  return 0;
+}
+float mssim_ref_get_timestep(mssim_handle h) { return (float)h->M.dt; }
+
+int mssim_ref_set_drive_properties(mssim_handle h, const float* drive) {
+  h->M.dof_drive.assign(drive, drive + 4 * h->M.n_dof);
+  return 0;
+}
+
+int mssim_ref_apply(mssim_handle h, uint32_t what, void*) {
+  const Model& M = h->M;
+  const int N = h->N, n = M.n_dof;
+  const mssim_buffers& B = h->buf;
+  for (int e = 0; e < N; e++) {
+    EnvState& E = h->env[e];
+    if ((what & MSSIM_RIGID_DATA) && B.rigid_body_data) {
+      for (int b = 0; b < M.n_free; b++) {
+        const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
+        E.free_pose[b] = pose7(r);
+        E.free_v[b] = Vec(r[7], r[8], r[9]);
+        E.free_w[b] = Vec(r[10], r[11], r[12]);
+      }
+      for (int k = 0; k < M.n_kin; k++) E.kin_pose[k] = pose7(B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e));
+    }
+    if ((what & MSSIM_ART_ROOT_POSE) && B.rigid_body_data && M.n_link > 0) E.root = pose7(B.rigid_body_data + 13 * (size_t)e);
+    if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) E.q[j] = B.art_qpos[(size_t)e * n + j];
+    if ((what & MSSIM_ART_QVEL) && B.art_qvel) for (int j = 0; j < n; j++) E.qd[j] = B.art_qvel[(size_t)e * n + j];
+    if ((what & MSSIM_ART_QF) && B.art_qf) for (int j = 0; j < n; j++) E.qf[j] = B.art_qf[(size_t)e * n + j];
+    if ((what & MSSIM_ART_TARGET_POS) && B.art_target_qpos) for (int j = 0; j < n; j++) E.qt[j] = B.art_target_qpos[(size_t)e * n + j];
+    if ((what & MSSIM_ART_TARGET_VEL) && B.art_target_qvel) for (int j = 0; j < n; j++) E.qdt[j] = B.art_target_qvel[(size_t)e * n + j];
+    if ((what & MSSIM_RIGID_FORCE) && B.rigid_body_force)
+      for (int b = 0; b < M.n_free; b++) {
+        const float* f = B.rigid_body_force + 4 * ((size_t)(M.n_link + b) * N + e);
+        E.free_force[b] = Vec(f[0], f[1], f[2]);
+      }
+  }
+  return 0;
+}
+
+int mssim_ref_fetch(mssim_handle h, uint32_t what, void*) {
+  const Model& M = h->M;
+  const int N = h->N, n = M.n_dof;
+  const mssim_buffers& B = h->buf;
+  for (int e = 0; e < N; e++) {
+    EnvState& E = h->env[e];
+    if (B.rigid_body_data) {
+      if (what & MSSIM_RIGID_DATA) {
+        for (int b = 0; b < M.n_free; b++) {
+          float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
+          const Pose<Real>& P = E.free_pose[b];
+          r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z;
+          r[7] = E.free_v[b].x; r[8] = E.free_v[b].y; r[9] = E.free_v[b].z;
+          r[10] = E.free_w[b].x; r[11] = E.free_w[b].y; r[12] = E.free_w[b].z;
+        }
+        for (int k = 0; k < M.n_kin; k++) {
+          float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
+          const Pose<Real>& P = E.kin_pose[k];
+          r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z;
+          for (int c = 7; c < 13; c++) r[c] = 0;
+        }
+      }
+      if (what & (MSSIM_LINK_POSE | MSSIM_LINK_VEL)) {
+        Vec O = E.root.p;
+        for (int l = 0; l < M.n_link; l++) {
+          float* r = B.rigid_body_data + 13 * ((size_t)l * N + e);
+          int b = M.link_body[l];
+          Pose<Real> P = pmul(b < 0 ? E.root : E.body_pose[b], pose7(&M.link_frame[7 * l]));
+          if (what & MSSIM_LINK_POSE) { r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z; }
+          if (what & MSSIM_LINK_VEL) {
+            Vec w, v;
+            if (b >= 0) { w = E.body_vel[b].w; v = E.body_vel[b].v + cross(w, P.p - O); }
+            r[7] = v.x; r[8] = v.y; r[9] = v.z; r[10] = w.x; r[11] = w.y; r[12] = w.z;
+          }
+        }
+      }
+    }
+    if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) B.art_qpos[(size_t)e * n + j] = (float)E.q[j];
+    if ((what & MSSIM_ART_QVEL) && B.art_qvel) for (int j = 0; j < n; j++) B.art_qvel[(size_t)e * n + j] = (float)E.qd[j];
+    if ((what & MSSIM_ART_QACC) && B.art_qacc) for (int j = 0; j < n; j++) B.art_qacc[(size_t)e * n + j] = (float)E.qacc[j];
+    if ((what & MSSIM_ART_TARGET_POS) && B.art_target_qpos) for (int j = 0; j < n; j++) B.art_target_qpos[(size_t)e * n + j] = (float)E.qt[j];
+    if ((what & MSSIM_ART_TARGET_VEL) && B.art_target_qvel) for (int j = 0; j < n; j++) B.art_target_qvel[(size_t)e * n + j] = (float)E.qdt[j];
+  }
+  return 0;
+}
+
+int mssim_ref_step(mssim_handle h, int32_t n_substeps, void*) {
+  for (int s = 0; s < n_substeps; s++)
+    for (auto& E : h->env) substep(h, E);
+  return 0;
+}
+
+int mssim_ref_update_kinematics(mssim_handle h, void*) {
+  for (auto& E : h->env) refresh_kinematics(h, E);
+  return 0;
+}
+
+int mssim_ref_create_pair_query(mssim_handle h, const int32_t* body_pairs, int32_t n_pairs, int32_t* qid) {
+  h->pair_queries.emplace_back(body_pairs, body_pairs + 2 * n_pairs);
+  *qid = (int)h->pair_queries.size() - 1;
+  return 0;
+}
+
+int mssim_ref_query_pair_impulses(mssim_handle h, int32_t qid, float* out, void*) {
+  if (qid < 0 || qid >= (int)h->pair_queries.size()) { h->err = "bad query id"; return 1; }
+  const Model& M = h->M;
+  const auto& Q = h->pair_queries[qid];
+  int nq = (int)Q.size() / 2;
+  for (int k = 0; k < nq; k++)
+    for (int e = 0; e < h->N; e++) {
+      Vec s;
+      for (int p = 0; p < M.n_pair; p++) {
+        int ra = M.shape_row[M.pair_shape[2 * p]], rb = M.shape_row[M.pair_shape[2 * p + 1]];
+        if (ra == Q[2 * k] && rb == Q[2 * k + 1]) s += h->env[e].pair_impulse[p];
+        else if (ra == Q[2 * k + 1] && rb == Q[2 * k]) s -= h->env[e].pair_impulse[p];
+      }
+      float* o = out + 3 * ((size_t)k * h->N + e);
+      o[0] = (float)s.x; o[1] = (float)s.y; o[2] = (float)s.z;
+    }
+  return 0;
+}
+
+int mssim_ref_create_body_query(mssim_handle h, const int32_t* rows, int32_t n, int32_t* qid) {
+  h->body_queries.emplace_back(rows, rows + n);
+  *qid = (int)h->body_queries.size() - 1;
+  return 0;
+}
+
+int mssim_ref_query_body_impulses(mssim_handle h, int32_t qid, float* out, void*) {
+  if (qid < 0 || qid >= (int)h->body_queries.size()) { h->err = "bad query id"; return 1; }
+  const Model& M = h->M;
+  const auto& Q = h->body_queries[qid];
+  for (size_t k = 0; k < Q.size(); k++)
+    for (int e = 0; e < h->N; e++) {
+      Vec s;
+      for (int p = 0; p < M.n_pair; p++) {
+        int ra = M.shape_row[M.pair_shape[2 * p]], rb = M.shape_row[M.pair_shape[2 * p + 1]];
+        if (ra == Q[k]) s += h->env[e].pair_impulse[p];
+        if (rb == Q[k]) s -= h->env[e].pair_impulse[p];
+      }
+      float* o = out + 3 * (k * h->N + e);
+      o[0] = (float)s.x; o[1] = (float)s.y; o[2] = (float)s.z;
+    }
+  return 0;
+}
+
+int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_t max_items, void*) {
+  const Model& M = h->M;
+  const int N = h->N;
+  std::string s(name);
+  int items = 0;
+  auto put = [&](int item, int e, Real v) { if (item < max_items) out[(size_t)item * N + e] = (float)v; };
+  if (s == "q" || s == "qd") {
+    items = M.n_dof;
+    for (int e = 0; e < N; e++) for (int j = 0; j < items; j++) put(j, e, s == "q" ? h->env[e].q[j] : h->env[e].qd[j]);
+  } else if (s == "free") {
+    items = 13 * M.n_free;
+    for (int e = 0; e < N; e++)
+      for (int b = 0; b < M.n_free; b++) {
+        const EnvState& E = h->env[e];
+        Real v[13] = {E.free_pose[b].p.x, E.free_pose[b].p.y, E.free_pose[b].p.z, E.free_pose[b].q.w, E.free_pose[b].q.x,
+                      E.free_pose[b].q.y, E.free_pose[b].q.z, E.free_v[b].x, E.free_v[b].y, E.free_v[b].z,
+                      E.free_w[b].x, E.free_w[b].y, E.free_w[b].z};
+        for (int c = 0; c < 13; c++) put(13 * b + c, e, v[c]);
+      }
+  } else if (s == "bodypose") {
+    items = 7 * M.n_dof;
+    for (int e = 0; e < N; e++)
+      for (int b = 0; b < M.n_dof; b++) {
+        const Pose<Real>& P = h->env[e].body_pose[b];
+        Real v[7] = {P.p.x, P.p.y, P.p.z, P.q.w, P.q.x, P.q.y, P.q.z};
+        for (int c = 0; c < 7; c++) put(7 * b + c, e, v[c]);
+      }
+  } else if (s == "contact_count") {
+    items = M.n_pair;
+    for (int e = 0; e < N; e++) for (int p = 0; p < items; p++) put(p, e, h->env[e].pair_count[p]);
+  } else if (s == "pair_impulse") {
+    items = 3 * M.n_pair;
+    for (int e = 0; e < N; e++)
+      for (int p = 0; p < M.n_pair; p++) {
+        const Vec& v = h->env[e].pair_impulse[p];
+        put(3 * p, e, v.x); put(3 * p + 1, e, v.y); put(3 * p + 2, e, v.z);
+      }
+  } else if (s == "overflow") {
+    items = 1;
+    for (int e = 0; e < N; e++) put(0, e, h->env[e].overflow);
+  } else {
+    h->err = "unknown internal array: " + s;
+    return -1;
+  }
+  return items;
+}
+
+int mssim_ref_overflow_count(mssim_handle h, void*) {
+  int c = 0;
+  for (auto& E : h->env) { c += E.overflow; E.overflow = 0; }
+  return c;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// test hook (not part of the mssim ABI): run the narrowphase on one explicit shape pair.
+// pose = p(3) q(4); out = count, n(3), then 4 x (x(3), sep)
+extern "C" int mssim_ref_test_collide(int type_a, const float* pose_a, const float* param_a, const float* verts_a, int nverts_a,
+                                      int type_b, const float* pose_b, const float* param_b, const float* verts_b, int nverts_b,
+                                      float offset, int force_mpr, float* out) {
+  Shape<Real> A, B;
+  auto fill = [](Shape<Real>& s, int type, const float* pose, const float* param, const float* verts, int nv) {
+    Pose<Real> P = pose7(pose);
+    s.type = type; s.c = P.p; s.rot = qmat(P.q);
+    for (int k = 0; k < 4; k++) s.param[k] = param[k];
+    s.verts = verts; s.nverts = nv;
+  };
+  fill(A, type_a, pose_a, param_a, verts_a, nverts_a);
+  fill(B, type_b, pose_b, param_b, verts_b, nverts_b);
+  Manifold<Real> m;
+  m.count = 0;
+  if (force_mpr) collide_mpr(A, B, (Real)offset, m);
+  else collide(A, B, (Real)offset, m);
+  out[0] = (float)m.count; out[1] = (float)m.n.x; out[2] = (float)m.n.y; out[3] = (float)m.n.z;
+  for (int k = 0; k < m.count; k++) {
+    out[4 + 4 * k] = (float)m.x[k].x; out[5 + 4 * k] = (float)m.x[k].y; out[6 + 4 * k] = (float)m.x[k].z; out[7 + 4 * k] = (float)m.sep[k];
+  }
+  return m.count;
+}

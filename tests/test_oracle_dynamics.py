@@ -1,0 +1,212 @@
+"""Pins the CPU oracle's articulated dynamics against independent algorithms / closed forms.
+
+The reference holds no numeric physics vectors ("parity unpinned" vs PhysX), so the
+oracle is pinned by: FK == plain URDF matrix-chain product; forward dynamics == an independent
+body-frame ABA; implicit-PD step response == its closed-form recurrence and -> the continuous
+solution; force-limit and joint-limit known answers.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.model import geom
+from maniskill_amd.model.compile import ArticulationRecord, SceneModelBuilder
+from maniskill_amd.model.scenes import PANDA_URDF, panda_record
+from maniskill_amd.model.urdf import parse_urdf
+from tests import oracle_backend as ob
+from tests.indep_dynamics import aba_forward_dynamics, urdf_link_poses
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def robot_only_model(gravity_on=True, drives=False, mimic=False, dt=1e-3):
+    rec = panda_record()
+    rec.link_shapes = {}
+    rec.build_mimic_joints = mimic
+    if gravity_on:
+        rec.link_gravity = {}
+    if not drives:
+        rec.drives = {j.name: (0.0, 0.0, np.inf, 0) for j in rec.robot.joints if j.type != "fixed"}
+    b = SceneModelBuilder()
+    b.set_articulation(rec)
+    return b.compile(timestep=dt), rec
+
+
+def rand_q(rng, rb, n):
+    lims = np.array([j.limit for j in rb.joints if j.type != "fixed"])
+    return rng.uniform(lims[:, 0] * 0.9, lims[:, 1] * 0.9, size=(n, len(lims)))
+
+
+def test_fk_matches_urdf_chain_product():
+    model, rec = robot_only_model()
+    N = 16
+    rng = np.random.default_rng(0)
+    q = rand_q(rng, rec.robot, N)
+    px = ob.make_system(model, N)
+    px.cuda_articulation_qpos.torch()[:] = torch.from_numpy(q).float()
+    px.gpu_apply_articulation_qpos()
+    px.gpu_update_articulation_kinematics()
+    px.gpu_fetch_articulation_link_pose()
+    rb = px.cuda_rigid_body_data.torch().reshape(model.n_rows, N, 13).numpy()
+    root_T = np.eye(4)
+    root_T[:3, 3] = [-0.615, 0, 0]
+    for e in range(N):
+        T = urdf_link_poses(rec.robot, q[e].astype(np.float32).astype(np.float64), root_T)
+        for i, name in enumerate(model.link_names):
+            np.testing.assert_allclose(rb[i, e, :3], T[name][:3, 3], atol=2e-6)
+            R = geom.quat_to_mat(rb[i, e, 3:7])
+            np.testing.assert_allclose(R, T[name][:3, :3], atol=2e-6)
+
+
+@pytest.mark.parametrize("gravity_on", [True, False])
+def test_forward_dynamics_matches_independent_aba(gravity_on):
+    dt = 1e-4
+    model, rec = robot_only_model(gravity_on=gravity_on, dt=dt)
+    # remove joint limits so no limit row can interfere with the unconstrained acceleration
+    model.arrays["dof_limit"][:] = np.array([-3e38, 3e38], dtype=np.float32)
+    N = 12
+    rng = np.random.default_rng(1)
+    q = rand_q(rng, rec.robot, N).astype(np.float32)
+    qd = rng.uniform(-1, 1, size=q.shape).astype(np.float32)
+    qd[:, 7:] *= 0.05
+    tau = rng.uniform(-5, 5, size=q.shape).astype(np.float32)
+    px = ob.make_system(model, N, timestep=dt)
+    px.cuda_articulation_qpos.torch()[:] = torch.from_numpy(q)
+    px.cuda_articulation_qvel.torch()[:] = torch.from_numpy(qd)
+    px.cuda_articulation_qf.torch()[:] = torch.from_numpy(tau)
+    px.gpu_apply_all()
+    px.step(1)
+    px.gpu_fetch_all()
+    qacc = px.cuda_articulation_qacc.torch().numpy()
+    root_T = np.eye(4)
+    root_T[:3, 3] = [-0.615, 0, 0]
+    lg = None if gravity_on else {n: False for n in rec.robot.links}
+    for e in range(N):
+        ref = aba_forward_dynamics(rec.robot, q[e].astype(np.float64), qd[e].astype(np.float64), tau[e].astype(np.float64), link_gravity=lg, root_T=root_T)
+        scale = np.maximum(1.0, np.abs(ref))
+        assert np.max(np.abs(qacc[e] - ref) / scale) < 2e-3, (e, qacc[e], ref)
+
+
+def _single_joint_urdf(tmp_path, jtype="prismatic", mass=2.0, lower=-10.0, upper=10.0):
+    p = tmp_path / f"one_{jtype}.urdf"
+    p.write_text(
+        f"""<?xml version="1.0"?>
+<robot name="one">
+  <link name="base"/>
+  <link name="slider">
+    <inertial><origin xyz="0 0 0"/><mass value="{mass}"/>
+      <inertia ixx="0.01" iyy="0.01" izz="0.01" ixy="0" ixz="0" iyz="0"/></inertial>
+  </link>
+  <joint name="j" type="{jtype}">
+    <parent link="base"/><child link="slider"/><origin xyz="0 0 0"/><axis xyz="1 0 0"/>
+    <limit lower="{lower}" upper="{upper}" effort="1000" velocity="100"/>
+  </joint>
+</robot>
+"""
+    )
+    return str(p)
+
+
+def _one_joint_system(tmp_path, kp, kd, fmax, dt, gravity=False, jtype="prismatic", mass=2.0, lower=-10.0, upper=10.0, precision="f64"):
+    rb = parse_urdf(_single_joint_urdf(tmp_path, jtype, mass, lower, upper))
+    rec = ArticulationRecord("one", rb, drives={"j": (kp, kd, fmax, 0)}, link_gravity={} if gravity else {n: False for n in rb.links})
+    b = SceneModelBuilder()
+    b.set_articulation(rec)
+    model = b.compile(timestep=dt)
+    return ob.make_system(model, 1, precision=precision, timestep=dt), model
+
+
+def test_implicit_pd_step_response_closed_form(tmp_path):
+    m, kp, kd, dt, target = 2.0, 1e3, 1e2, 0.01, 0.3
+    px, _ = _one_joint_system(tmp_path, kp, kd, np.inf, dt, mass=m)
+    px.cuda_articulation_target_qpos.torch()[:] = target
+    px.gpu_apply_all()
+    q, v = 0.0, 0.0
+    for _ in range(200):
+        px.step(1)
+        px.gpu_fetch_all()
+        v = (m * v + dt * kp * (target - q)) / (m + dt * kd + dt * dt * kp)  # backward-Euler PD
+        q = q + dt * v
+        assert abs(px.cuda_articulation_qpos.torch()[0, 0].item() - q) < 1e-6
+        assert abs(px.cuda_articulation_qvel.torch()[0, 0].item() - v) < 1e-5
+    # continuous overdamped solution  m x'' + kd x' + kp x = kp * target at t = 2 s (settled)
+    assert abs(q - target) < 1e-3
+
+
+def test_implicit_pd_converges_to_continuous_solution(tmp_path):
+    m, kp, kd, target, T = 2.0, 50.0, 4.0, 0.2, 0.5
+    errs = []
+    for dt in (2e-3, 1e-3):
+        px, _ = _one_joint_system(tmp_path, kp, kd, np.inf, dt, mass=m)
+        px.cuda_articulation_target_qpos.torch()[:] = target
+        px.gpu_apply_all()
+        px.step(int(round(T / dt)))
+        px.gpu_fetch_all()
+        wn, zeta = np.sqrt(kp / m), kd / (2 * np.sqrt(kp * m))
+        wd = wn * np.sqrt(1 - zeta**2)
+        x = target * (1 - np.exp(-zeta * wn * T) * (np.cos(wd * T) + zeta * wn / wd * np.sin(wd * T)))
+        errs.append(abs(px.cuda_articulation_qpos.torch()[0, 0].item() - x))
+    assert errs[0] < 2e-3 and errs[1] < 0.6 * errs[0]  # first-order convergence
+
+
+def test_drive_force_limit_saturates(tmp_path):
+    m, dt, fmax = 2.0, 0.01, 10.0
+    px, _ = _one_joint_system(tmp_path, 1e4, 1e1, fmax, dt, mass=m)
+    px.cuda_articulation_target_qpos.torch()[:] = 5.0
+    px.gpu_apply_all()
+    px.step(1)
+    px.gpu_fetch_all()
+    assert abs(px.cuda_articulation_qacc.torch()[0, 0].item() - fmax / m) < 1e-6
+
+
+def test_joint_limit_stops_motion(tmp_path):
+    dt = 0.01
+    px, _ = _one_joint_system(tmp_path, 0.0, 0.0, np.inf, dt, mass=1.0, lower=-0.05, upper=0.05)
+    px.cuda_articulation_qf.torch()[:] = 20.0  # constant push towards the upper limit
+    px.gpu_apply_all()
+    for _ in range(100):
+        px.step(1)
+    px.gpu_fetch_all()
+    q = px.cuda_articulation_qpos.torch()[0, 0].item()
+    v = px.cuda_articulation_qvel.torch()[0, 0].item()
+    assert 0.05 - 1e-4 < q < 0.05 + 1e-3 and abs(v) < 1e-3
+
+
+def test_pendulum_period_and_energy(tmp_path):
+    # point-like bob: revolute joint about x, COM 0.5 m below the axis
+    p = tmp_path / "pend.urdf"
+    L, mass = 0.5, 1.0
+    p.write_text(
+        f"""<?xml version="1.0"?>
+<robot name="pend"><link name="base"/>
+  <link name="bob"><inertial><origin xyz="0 0 {-L}"/><mass value="{mass}"/>
+    <inertia ixx="1e-9" iyy="1e-9" izz="1e-9" ixy="0" ixz="0" iyz="0"/></inertial></link>
+  <joint name="j" type="continuous"><parent link="base"/><child link="bob"/><origin xyz="0 0 0"/><axis xyz="1 0 0"/></joint>
+</robot>"""
+    )
+    rb = parse_urdf(str(p))
+    rec = ArticulationRecord("pend", rb, drives={"j": (0.0, 0.0, np.inf, 0)})
+    b = SceneModelBuilder()
+    b.set_articulation(rec)
+    dt = 1e-3
+    model = b.compile(timestep=dt)
+    px = ob.make_system(model, 1, timestep=dt)
+    th0 = 0.1
+    px.cuda_articulation_qpos.torch()[:] = th0
+    px.gpu_apply_all()
+    g = 9.81
+    period = 2 * np.pi * np.sqrt(L / g) * (1 + th0**2 / 16)
+    qs = []
+    for _ in range(int(2.5 * period / dt)):
+        px.step(1)
+        px.gpu_fetch_all()
+        qs.append(px.cuda_articulation_qpos.torch()[0, 0].item())
+    qs = np.array(qs)
+    # upward zero crossings
+    idx = np.where((qs[:-1] < 0) & (qs[1:] >= 0))[0]
+    t = (idx + qs[idx] / (qs[idx] - qs[idx + 1])) * dt
+    assert abs((t[1] - t[0]) - period) < 2e-3 * period
+    # amplitude (energy) drift of semi-implicit Euler stays small
+    assert abs(qs[-int(period / dt):].max() - th0) < 5e-3 * th0 + 1e-4
