@@ -1,0 +1,423 @@
+// mssim_collide.h -- per-lane narrowphase for gfx950 (one (env, shape pair) per lane).
+//
+// Replaces the contact generation hidden in `px.step()` (mani_skill/envs/scene.py:374-375; shape
+// types mani_skill/utils/building/actor_builder.py:73-155; contact_offset / rest_offset
+// mani_skill/utils/structs/types.py:40-41).
+//
+// Launch shape (see k_narrow): blockIdx.y = pair, so all 64 lanes of a wave work on the SAME
+// shape pair -- shape types, sizes and hull vertex addresses are wave-uniform (SGPR / scalar
+// loads), only poses differ per lane. Variable-length per-lane lists (clip polygons) live in
+// LDS as [slot][lane] so a lane-varying slot index is conflict-free (bank = lane % 32).
+//
+//   plane  vs X      analytic, 4 deepest vertices
+//   box    vs box    SAT over 15 axes + reference-face clipping, <= 4 points
+//   convex vs convex Minkowski Portal Refinement, shape A inflated by the contact offset, 1 point
+//
+// Contact convention: n points from shape B to shape A, sep = signed gap, x = mid point.
+#pragma once
+#include "mssim_dev.h"
+
+enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5 };
+
+struct shape_t {
+  int type;  // wave-uniform
+  f3 c;
+  m3 rot;
+  float p0, p1, p2;                 // params
+  const float* __restrict__ verts;  // wave-uniform
+  int nverts;                       // wave-uniform
+};
+
+struct manifold_t {
+  int count;
+  f3 n;
+  f3 x[4];
+  float sep[4];
+};
+
+MS_DEV f3 support(const shape_t& s, f3 d) {
+  f3 dl = mtmulv(s.rot, d);
+  f3 pl;
+  switch (s.type) {
+    case SH_BOX:
+      pl = f3{dl.x >= 0.f ? s.p0 : -s.p0, dl.y >= 0.f ? s.p1 : -s.p1, dl.z >= 0.f ? s.p2 : -s.p2};
+      break;
+    case SH_SPHERE:
+      pl = normalized(dl) * s.p0;
+      break;
+    case SH_CAPSULE: {
+      f3 u = normalized(dl) * s.p0;
+      pl = f3{(dl.x >= 0.f ? s.p1 : -s.p1) + u.x, u.y, u.z};
+      break;
+    }
+    case SH_CYLINDER: {
+      float rr = sqrtf(dl.y * dl.y + dl.z * dl.z);
+      float k = rr > 1e-12f ? s.p0 / rr : 0.f;
+      pl = f3{dl.x >= 0.f ? s.p1 : -s.p1, dl.y * k, dl.z * k};
+      break;
+    }
+    case SH_CONVEX: {
+      const float* __restrict__ v = s.verts;
+      float bx = v[0], by = v[1], bz = v[2];
+      float bd = bx * dl.x + by * dl.y + bz * dl.z;
+      for (int i = 1; i < s.nverts; i++) {
+        float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+        float t = x * dl.x + y * dl.y + z * dl.z;
+        bool g = t > bd;
+        bd = g ? t : bd;
+        bx = g ? x : bx; by = g ? y : by; bz = g ? z : bz;
+      }
+      pl = f3{bx, by, bz};
+      break;
+    }
+    default:
+      pl = f3{0.f, 0.f, 0.f};
+  }
+  return s.c + mmulv(s.rot, pl);
+}
+
+// streaming "4 smallest separations" (stable: earlier index wins ties)
+MS_DEV void keep4_insert(manifold_t& m, f3 p, float s) {
+  // find insertion position: after all entries with sep <= s
+  int pos = m.count;
+#pragma unroll
+  for (int k = 3; k >= 0; k--)
+    if (k < m.count && s < m.sep[k]) pos = k;
+  if (pos >= 4) return;
+#pragma unroll
+  for (int k = 3; k > 0; k--)
+    if (k > pos && k <= m.count) { m.x[k] = m.x[k - 1]; m.sep[k] = m.sep[k - 1]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (k == pos) { m.x[k] = p; m.sep[k] = s; }
+  m.count = m.count < 4 ? m.count + 1 : 4;
+}
+
+MS_DEV void collide_plane(const shape_t& pl, const shape_t& b, float offset, manifold_t& m) {
+  m.count = 0;
+  f3 np = mcol(pl.rot, 0);
+  m.n = -np;
+  auto add = [&](f3 p, float radius) {
+    float s = dot(np, p - pl.c) - radius;
+    if (s < offset) keep4_insert(m, p - np * (radius + 0.5f * s), s);
+  };
+  if (b.type == SH_BOX) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      f3 l = f3{(i & 1) ? b.p0 : -b.p0, (i & 2) ? b.p1 : -b.p1, (i & 4) ? b.p2 : -b.p2};
+      add(b.c + mmulv(b.rot, l), 0.f);
+    }
+  } else if (b.type == SH_SPHERE) {
+    add(b.c, b.p0);
+  } else if (b.type == SH_CAPSULE) {
+    f3 ax = mcol(b.rot, 0) * b.p1;
+    add(b.c - ax, b.p0);
+    add(b.c + ax, b.p0);
+  } else if (b.type == SH_CONVEX) {
+    int nv = b.nverts < 64 ? b.nverts : 64;
+    for (int i = 0; i < nv; i++) add(b.c + mmulv(b.rot, f3{b.verts[3 * i], b.verts[3 * i + 1], b.verts[3 * i + 2]}), 0.f);
+  } else {
+    add(support(b, -np), 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// box-box.  LDS scratch: 2 polygon buffers of 16 points (x,y,z) -> 96 slots, [slot][64 lanes]
+#define CLIP_SLOTS 96
+struct lds_poly {
+  float* base;  // already offset by lane
+  int buf;
+  MS_DEV f3 get(int i) const { float* p = base + (size_t)(buf * 48 + 3 * i) * 64; return f3{p[0], p[64], p[128]}; }
+  MS_DEV void put(int i, f3 v) { float* p = base + (size_t)(buf * 48 + 3 * i) * 64; p[0] = v.x; p[64] = v.y; p[128] = v.z; }
+};
+
+MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
+  lds_poly in{lds, src}, out{lds, src ^ 1};
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    f3 a = in.get(i);
+    f3 b = in.get(i + 1 < n ? i + 1 : 0);
+    float da = dot(pn, a) - pd, db = dot(pn, b) - pd;
+    if (da <= 0.f) out.put(m++, a);
+    if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+      float t = da / (da - db);
+      out.put(m++, a + (b - a) * t);
+    }
+  }
+  return m;
+}
+
+MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, manifold_t& m, float* lds) {
+  m.count = 0;
+  const float eps = 1e-6f;
+  f3 a[3] = {mcol(A.rot, 0), mcol(A.rot, 1), mcol(A.rot, 2)};
+  f3 b[3] = {mcol(B.rot, 0), mcol(B.rot, 1), mcol(B.rot, 2)};
+  float hA[3] = {A.p0, A.p1, A.p2}, hB[3] = {B.p0, B.p1, B.p2};
+  f3 tw = B.c - A.c;
+  float T[3] = {dot(tw, a[0]), dot(tw, a[1]), dot(tw, a[2])};
+  float Rm[3][3], Ra[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { Rm[i][j] = dot(a[i], b[j]); Ra[i][j] = fabsf(Rm[i][j]) + eps; }
+  float sA = -1e30f; int iA = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float s = fabsf(T[i]) - (hA[i] + hB[0] * Ra[i][0] + hB[1] * Ra[i][1] + hB[2] * Ra[i][2]);
+    if (s > sA) { sA = s; iA = i; }
+  }
+  float sB = -1e30f; int iB = 0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float tb = T[0] * Rm[0][j] + T[1] * Rm[1][j] + T[2] * Rm[2][j];
+    float s = fabsf(tb) - (hB[j] + hA[0] * Ra[0][j] + hA[1] * Ra[1][j] + hA[2] * Ra[2][j]);
+    if (s > sB) { sB = s; iB = j; }
+  }
+  float sE = -1e30f; int eI = -1, eJ = -1;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float l2 = 1.f - Rm[i][j] * Rm[i][j];
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float ra = hA[i1] * Ra[i2][j] + hA[i2] * Ra[i1][j];
+      float rb = hB[j1] * Ra[i][j2] + hB[j2] * Ra[i][j1];
+      float s = (fabsf(T[i2] * Rm[i1][j] - T[i1] * Rm[i2][j]) - (ra + rb)) / sqrtf(fmaxf(l2, 1e-12f));
+      if (l2 >= 1e-6f && s > sE) { sE = s; eI = i; eJ = j; }
+    }
+  float sF = sA > sB ? sA : sB;
+  float smax = sF > sE ? sF : sE;
+  if (smax > offset) return;
+
+  if (eI >= 0 && sE > sF + 1e-3f) {
+    f3 aE = eI == 0 ? a[0] : (eI == 1 ? a[1] : a[2]);
+    f3 bE = eJ == 0 ? b[0] : (eJ == 1 ? b[1] : b[2]);
+    f3 ax = normalized(cross(aE, bE));
+    if (dot(ax, tw) < 0.f) ax = -ax;
+    f3 pa = A.c, pb = B.c;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k != eI) pa += a[k] * (dot(ax, a[k]) >= 0.f ? hA[k] : -hA[k]);
+      if (k != eJ) pb -= b[k] * (dot(ax, b[k]) >= 0.f ? hB[k] : -hB[k]);
+    }
+    float hAe = eI == 0 ? hA[0] : (eI == 1 ? hA[1] : hA[2]);
+    float hBe = eJ == 0 ? hB[0] : (eJ == 1 ? hB[1] : hB[2]);
+    f3 w0 = pa - pb;
+    float uv = dot(aE, bE), uw = dot(aE, w0), vw = dot(bE, w0);
+    float den = 1.f - uv * uv;
+    float sa = den > 1e-9f ? (uv * vw - uw) / den : 0.f;
+    float sb = den > 1e-9f ? (vw - uv * uw) / den : 0.f;
+    sa = fminf(fmaxf(sa, -hAe), hAe);
+    sb = fminf(fmaxf(sb, -hBe), hBe);
+    f3 qa = pa + aE * sa, qb = pb + bE * sb;
+    m.count = 1;
+    m.n = -ax;
+    m.sep[0] = dot(qb - qa, ax);
+    m.x[0] = (qa + qb) * 0.5f;
+    return;
+  }
+  bool refA = sA >= sB - 1e-5f;
+  // select reference (X) / incident (Y) data without dynamic register indexing
+  f3 xa[3], ya[3];
+  float hX[3], hY[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    xa[k] = refA ? a[k] : b[k];
+    ya[k] = refA ? b[k] : a[k];
+    hX[k] = refA ? hA[k] : hB[k];
+    hY[k] = refA ? hB[k] : hA[k];
+  }
+  f3 Xc = refA ? A.c : B.c, Yc = refA ? B.c : A.c;
+  int ir = refA ? iA : iB;
+  f3 xr = ir == 0 ? xa[0] : (ir == 1 ? xa[1] : xa[2]);
+  float hXr = ir == 0 ? hX[0] : (ir == 1 ? hX[1] : hX[2]);
+  f3 nref = dot(xr, Yc - Xc) >= 0.f ? xr : -xr;
+  int jinc = 0;
+  float bestd = -1.f;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    float d = fabsf(dot(nref, ya[j]));
+    if (d > bestd) { bestd = d; jinc = j; }
+  }
+  f3 yi = jinc == 0 ? ya[0] : (jinc == 1 ? ya[1] : ya[2]);
+  f3 y1 = jinc == 0 ? ya[1] : (jinc == 1 ? ya[2] : ya[0]);
+  f3 y2 = jinc == 0 ? ya[2] : (jinc == 1 ? ya[0] : ya[1]);
+  float hYi = jinc == 0 ? hY[0] : (jinc == 1 ? hY[1] : hY[2]);
+  float hY1 = jinc == 0 ? hY[1] : (jinc == 1 ? hY[2] : hY[0]);
+  float hY2 = jinc == 0 ? hY[2] : (jinc == 1 ? hY[0] : hY[1]);
+  f3 ninc = dot(nref, yi) > 0.f ? -yi : yi;
+  f3 fc = Yc + ninc * hYi;
+  lds_poly P{lds, 0};
+  P.put(0, fc + y1 * hY1 + y2 * hY2);
+  P.put(1, fc - y1 * hY1 + y2 * hY2);
+  P.put(2, fc - y1 * hY1 - y2 * hY2);
+  P.put(3, fc + y1 * hY1 - y2 * hY2);
+  f3 x1 = ir == 0 ? xa[1] : (ir == 1 ? xa[2] : xa[0]);
+  f3 x2 = ir == 0 ? xa[2] : (ir == 1 ? xa[0] : xa[1]);
+  float hX1 = ir == 0 ? hX[1] : (ir == 1 ? hX[2] : hX[0]);
+  float hX2 = ir == 0 ? hX[2] : (ir == 1 ? hX[0] : hX[1]);
+  int np = 4;
+  np = clip_poly(lds, 0, np, x1, dot(x1, Xc) + hX1);
+  np = clip_poly(lds, 1, np, -x1, -dot(x1, Xc) + hX1);
+  np = clip_poly(lds, 0, np, x2, dot(x2, Xc) + hX2);
+  np = clip_poly(lds, 1, np, -x2, -dot(x2, Xc) + hX2);
+  // result polygon is in buffer 0; compact the points within the offset into buffer 1 (x,y,z) and
+  // their separations into the tail slots of buffer 1
+  lds_poly Q{lds, 0}, Rb{lds, 1};
+  float* seps = lds + (size_t)(48 + 32) * 64;  // slots 80..95 of the scratch
+  int n = 0;
+  for (int i = 0; i < np; i++) {
+    f3 p = Q.get(i);
+    float s = dot(p - Xc, nref) - hXr;
+    if (s <= offset) { Rb.put(n, p - nref * (0.5f * s)); seps[(size_t)n * 64] = s; n++; }
+  }
+  m.n = refA ? -nref : nref;
+  if (n <= 4) {
+    m.count = n;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < n) { m.x[k] = Rb.get(k); m.sep[k] = seps[(size_t)k * 64]; }
+    return;
+  }
+  int i0 = 0;
+  float s0 = seps[0];
+  for (int i = 1; i < n; i++) { float s = seps[(size_t)i * 64]; if (s < s0) { s0 = s; i0 = i; } }
+  f3 p0 = Rb.get(i0);
+  int i1 = -1; float best = -1.f;
+  for (int i = 0; i < n; i++) {
+    if (i == i0) continue;
+    f3 d = Rb.get(i) - p0; float v = dot(d, d);
+    if (v > best) { best = v; i1 = i; }
+  }
+  f3 e = Rb.get(i1) - p0;
+  int i2 = -1; best = -1.f; float sgn2 = 0.f;
+  for (int i = 0; i < n; i++) {
+    if (i == i0 || i == i1) continue;
+    float ar = dot(cross(e, Rb.get(i) - p0), nref);
+    if (fabsf(ar) > best) { best = fabsf(ar); i2 = i; sgn2 = ar; }
+  }
+  int i3 = -1; best = 0.f;
+  for (int i = 0; i < n; i++) {
+    if (i == i0 || i == i1 || i == i2) continue;
+    float ar = dot(cross(e, Rb.get(i) - p0), nref);
+    float v = sgn2 >= 0.f ? -ar : ar;
+    if (v > best) { best = v; i3 = i; }
+  }
+  int idx[4] = {i0, i1, i2, i3};
+  m.count = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (idx[k] >= 0) {
+      f3 p = Rb.get(idx[k]);
+      float s = seps[(size_t)idx[k] * 64];
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (t == m.count) { m.x[t] = p; m.sep[t] = s; }
+      m.count++;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MPR on A' (-) B, A' = A inflated by `margin`
+struct mvert {
+  f3 v, a, b;
+};
+MS_DEV mvert msupport(const shape_t& A, const shape_t& B, f3 d, float margin) {
+  mvert r;
+  f3 dn = normalized(d);
+  r.a = support(A, dn);
+  r.b = support(B, -dn);
+  r.v = r.a + dn * margin - r.b;
+  return r;
+}
+
+MS_DEV void closest_on_triangle(f3 a, f3 b, f3 c, float w[3]) {
+  f3 ab = b - a, ac = c - a, ap = -a;
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.f && d2 <= 0.f) { w[0] = 1.f; w[1] = 0.f; w[2] = 0.f; return; }
+  f3 bp = -b;
+  float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.f && d4 <= d3) { w[0] = 0.f; w[1] = 1.f; w[2] = 0.f; return; }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 / (d1 - d3); w[0] = 1.f - v; w[1] = v; w[2] = 0.f; return; }
+  f3 cp = -c;
+  float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.f && d5 <= d6) { w[0] = 0.f; w[1] = 0.f; w[2] = 1.f; return; }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float v = d2 / (d2 - d6); w[0] = 1.f - v; w[1] = 0.f; w[2] = v; return; }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+    float v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    w[0] = 0.f; w[1] = 1.f - v; w[2] = v; return;
+  }
+  float den = 1.f / (va + vb + vc);
+  w[1] = vb * den; w[2] = vc * den; w[0] = 1.f - w[1] - w[2];
+}
+
+MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifold_t& m) {
+  m.count = 0;
+  const float margin = offset;
+  const float tol = 1e-5f;
+  mvert v0, v1, v2, v3, v4;
+  v0.a = A.c; v0.b = B.c; v0.v = A.c - B.c;
+  if (dot(v0.v, v0.v) < 1e-12f) v0.v = f3{1e-5f, 0.f, 0.f};
+  f3 dir = -v0.v;
+  v1 = msupport(A, B, dir, margin);
+  if (dot(v1.v, dir) <= 0.f) return;
+  dir = cross(v1.v, v0.v);
+  if (dot(dir, dir) < 1e-14f) {
+    f3 w = v1.v; float D = norm(w);
+    m.count = 1;
+    m.n = D > 1e-9f ? w * (-1.f / D) : normalized(v0.v);
+    m.sep[0] = margin - D;
+    m.x[0] = (v1.a + v1.b) * 0.5f;
+    return;
+  }
+  v2 = msupport(A, B, dir, margin);
+  if (dot(v2.v, dir) <= 0.f) return;
+  dir = cross(v1.v - v0.v, v2.v - v0.v);
+  if (dot(dir, v0.v) > 0.f) { mvert t = v1; v1 = v2; v2 = t; dir = -dir; }
+  bool found = false;
+  for (int it = 0; it < 32; it++) {
+    v3 = msupport(A, B, dir, margin);
+    if (dot(v3.v, dir) <= 0.f) return;
+    if (dot(cross(v1.v, v3.v), v0.v) < 0.f) { v2 = v3; dir = cross(v1.v - v0.v, v3.v - v0.v); continue; }
+    if (dot(cross(v3.v, v2.v), v0.v) < 0.f) { v1 = v3; dir = cross(v3.v - v0.v, v2.v - v0.v); continue; }
+    found = true;
+    break;
+  }
+  if (!found) return;
+  bool hit = false;
+  for (int it = 0; it < 48; it++) {
+    dir = cross(v2.v - v1.v, v3.v - v1.v);
+    float dl = norm(dir);
+    if (dl < 1e-14f) break;
+    dir = dir * (1.f / dl);
+    if (dot(dir, v1.v) >= 0.f) hit = true;
+    v4 = msupport(A, B, dir, margin);
+    float reach = dot(v4.v, dir);
+    if (reach < 0.f && !hit) return;
+    if (reach - dot(v3.v, dir) <= tol || it == 47) {
+      if (!hit) return;
+      break;
+    }
+    f3 cr = cross(v4.v, v0.v);
+    if (dot(v1.v, cr) > 0.f) {
+      if (dot(v2.v, cr) > 0.f) v1 = v4; else v3 = v4;
+    } else {
+      if (dot(v3.v, cr) > 0.f) v2 = v4; else v1 = v4;
+    }
+  }
+  if (!hit) return;
+  float w[3];
+  closest_on_triangle(v1.v, v2.v, v3.v, w);
+  f3 wp = v1.v * w[0] + v2.v * w[1] + v3.v * w[2];
+  float D = norm(wp);
+  f3 pn = normalized(cross(v2.v - v1.v, v3.v - v1.v));
+  m.count = 1;
+  m.n = D > 1e-7f ? wp * (-1.f / D) : -pn;
+  m.sep[0] = margin - D;
+  f3 pa = v1.a * w[0] + v2.a * w[1] + v3.a * w[2];
+  f3 pb = v1.b * w[0] + v2.b * w[1] + v3.b * w[2];
+  m.x[0] = (pa + pb) * 0.5f;
+}

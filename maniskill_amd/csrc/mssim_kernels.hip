@@ -1,0 +1,1129 @@
+// mssim_kernels.hip -- gfx950 kernels + C ABI (include/mssim.h) of the batched rigid-body step.
+//
+// Replaces `px.step()` and the px.gpu_apply_* / px.gpu_fetch_* / contact-query calls of
+// ManiSkill's GPU path (mani_skill/envs/scene.py:374-375, 736-796, 941-977).
+//
+// Data layout in HBM: every per-env quantity is struct-of-arrays `[item][N]` with the env index
+// fastest, so lane e of a wave touches address base + e*4: one 256-B coalesced request per
+// wave-instruction. Constant model tables are env-shared and wave-uniform (scalar loads, L2
+// resident).
+//
+// Kernels per substep (all launched on the caller's stream, no host sync):
+//   k_narrow  grid (N/64, n_pair)  one (env, shape pair) per lane; blockIdx.y = pair so the pair's
+//                                  shape types / hull vertices are wave-uniform
+//   k_solve   grid (N/64)          one env per lane: FK, CRBA + RNEA, implicit PD (dense LDL^T),
+//                                  row assembly, projected Gauss-Seidel, integration, FK(new)
+// `Topo` selects compile-time (Panda: 9-DoF tree fully unrolled into VGPRs) or run-time topology.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mssim.h"
+#include "mssim_collide.h"
+
+#define MAXC 48  // contact points per env fed to the solver (overflow is reported, never silent)
+
+struct DevModel {
+  int n_dof, n_tendon, n_link, n_free, n_kin, n_shape, n_pair, n_words;
+  const int *dof_parent, *dof_type, *body_gravity, *tendon_dof, *link_body, *free_gravity;
+  const unsigned* dof_anc;  // bitmask of strict ancestors of each dof
+  const float *dof_frame, *dof_axis, *dof_limit, *dof_drive, *dof_armature, *body_inertial, *tendon_param, *link_frame;
+  const float *free_inertial, *free_damping;
+  const int *shape_type, *shape_kind, *shape_index, *shape_row, *shape_hull, *pair_shape;
+  const float *shape_frame, *shape_param, *shape_material, *shape_bound, *hull_verts;
+  float gx, gy, gz, dt, contact_offset, rest_offset, erp, max_depen;
+  int pos_iters, vel_iters;
+};
+
+struct DevState {
+  int N;
+  float *root, *q, *qd, *qt, *qdt, *qf, *qacc;  // [7][N], [n_dof][N] ...
+  float *free_s, *free_force, *kin;             // [n_free*13][N], [n_free*3][N], [n_kin*7][N]
+  float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
+  int* pair_cnt;                                // [n_pair][N]
+  float* pair_data;                             // [n_pair*19][N]: n(3), 4 x (x(3), sep)
+  float* pair_imp;                              // [n_pair*3][N]
+  unsigned* hit_mask;                           // [n_words][N]
+  float* rows;                                  // [3*MAXC * RF][N] solver scratch
+  int* overflow;                                // [N]
+};
+
+// ------------------------------------------------------------------------------------------------
+// topology policies
+struct TopoDyn {
+  static constexpr int MAXD = MSSIM_MAX_DOF;
+  static constexpr bool STATIC = false;
+  static constexpr int UNROLL = 1;
+  int nd;
+  const int* par;
+  const int* typ;
+  const unsigned* ancm;
+  MS_DEV TopoDyn(const DevModel& M) : nd(M.n_dof), par(M.dof_parent), typ(M.dof_type), ancm(M.dof_anc) {}
+  MS_DEV int n() const { return nd; }
+  MS_DEV int parent(int j) const { return par[j]; }
+  MS_DEV bool revolute(int j) const { return typ[j] == MSSIM_JOINT_REVOLUTE; }
+  MS_DEV unsigned anc(int j) const { return ancm[j]; }
+};
+struct TopoPanda {  // panda_v2/v3: 7 revolute chain + 2 prismatic fingers on body 6
+  static constexpr int MAXD = 9;
+  static constexpr bool STATIC = true;
+  static constexpr int UNROLL = 9;
+  MS_DEV TopoPanda(const DevModel&) {}
+  MS_DEV constexpr int n() const { return 9; }
+  MS_DEV constexpr int parent(int j) const { return j == 0 ? -1 : (j <= 7 ? j - 1 : 6); }
+  MS_DEV constexpr bool revolute(int j) const { return j < 7; }
+  MS_DEV constexpr unsigned anc(int j) const { return j <= 7 ? ((1u << j) - 1u) : 0x7Fu; }
+};
+static const int kPandaParent[9] = {-1, 0, 1, 2, 3, 4, 5, 6, 6};
+static const int kPandaType[9] = {0, 0, 0, 0, 0, 0, 0, 1, 1};
+
+// spatial helpers (world frame, about the origin O = articulation root position)
+struct sv6 { f3 w, v; };                    // motion
+struct sf6 { f3 n, f; };                    // force
+struct si10 { float m; f3 h; s3 I; };       // inertia
+MS_DEV sv6 crossm(sv6 a, sv6 b) { return sv6{cross(a.w, b.w), cross(a.w, b.v) + cross(a.v, b.w)}; }
+MS_DEV sf6 crossf(sv6 a, sf6 b) { return sf6{cross(a.w, b.n) + cross(a.v, b.f), cross(a.w, b.f)}; }
+MS_DEV sf6 imul(const si10& I, sv6 a) { return sf6{smulv(I.I, a.w) + cross(I.h, a.v), a.v * I.m - cross(I.h, a.w)}; }
+MS_DEV float sdot(sv6 s, sf6 f) { return dot(s.w, f.n) + dot(s.v, f.f); }
+
+#define SOA(ptr, item) ((ptr)[(size_t)(item) * N + e])
+
+template <class T>
+MS_DEV void fk_bodies(const T& topo, const DevModel& M, pose_t root, const float* q, pose_t* bp, f3* aw, f3* anchor) {
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= topo.n()) break;
+    int p = topo.parent(j);
+    pose_t P = root;
+    if (T::STATIC) {
+#pragma unroll
+      for (int k = 0; k < T::MAXD; k++)
+        if (k == p) P = bp[k];
+    } else if (p >= 0) {
+      P = bp[p];
+    }
+    pose_t J = pmul(P, pose_from(M.dof_frame + 7 * j));
+    f3 al = f3{M.dof_axis[3 * j], M.dof_axis[3 * j + 1], M.dof_axis[3 * j + 2]};
+    f3 a = qrot(J.q, al);
+    pose_t B = J;
+    if (topo.revolute(j)) B.q = qnormalized(qmul(J.q, qaxis_angle(al, q[j])));
+    else B.p = J.p + a * q[j];
+    bp[j] = B;
+    aw[j] = a;
+    anchor[j] = J.p;
+  }
+}
+
+template <class T>
+MS_DEV sv6 subspace(const T& topo, int j, f3 a, f3 r) {  // r = anchor - O
+  if (topo.revolute(j)) return sv6{a, cross(r, a)};
+  return sv6{f3{0.f, 0.f, 0.f}, a};
+}
+
+// body spatial velocities about O from qd; writes bodypose / bodyvel SoA
+template <class T>
+MS_DEV void write_kinematics(const T& topo, const DevModel& M, const DevState& S, int e, pose_t root, const float* qd,
+                             const pose_t* bp, const f3* aw, const f3* anchor) {
+  const int N = S.N;
+  sv6 V[T::MAXD];
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= topo.n()) break;
+    int p = topo.parent(j);
+    sv6 Vp = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+    if (T::STATIC) {
+#pragma unroll
+      for (int k = 0; k < T::MAXD; k++)
+        if (k == p) Vp = V[k];
+    } else if (p >= 0) {
+      Vp = V[p];
+    }
+    sv6 Sj = subspace(topo, j, aw[j], anchor[j] - root.p);
+    V[j] = sv6{Vp.w + Sj.w * qd[j], Vp.v + Sj.v * qd[j]};
+    pose_store_soa(S.bodypose, 7 * j, N, e, bp[j]);
+    float* o = S.bodyvel + (size_t)(6 * j) * N + e;
+    o[0] = V[j].w.x; o[(size_t)N] = V[j].w.y; o[2 * (size_t)N] = V[j].w.z;
+    o[3 * (size_t)N] = V[j].v.x; o[4 * (size_t)N] = V[j].v.y; o[5 * (size_t)N] = V[j].v.z;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(64) void k_fk(DevModel M, DevState S) {
+  const int N = S.N;
+  int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= N) return;
+  T topo(M);
+  pose_t root = pose_soa(S.root, 0, N, e);
+  float q[T::MAXD], qd[T::MAXD];
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= topo.n()) break;
+    q[j] = SOA(S.q, j);
+    qd[j] = SOA(S.qd, j);
+  }
+  pose_t bp[T::MAXD];
+  f3 aw[T::MAXD], anchor[T::MAXD];
+  fk_bodies(topo, M, root, q, bp, aw, anchor);
+  write_kinematics(topo, M, S, e, root, qd, bp, aw, anchor);
+  for (int w = 0; w < M.n_words; w++) S.hit_mask[(size_t)w * N + e] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+MS_DEV pose_t body_pose_of(const DevModel& M, const DevState& S, int kind, int index, int e) {
+  const int N = S.N;
+  if (kind == MSSIM_BODY_ART) return index < 0 ? pose_soa(S.root, 0, N, e) : pose_soa(S.bodypose, 7 * index, N, e);
+  if (kind == MSSIM_BODY_FREE) return pose_soa(S.free_s, 13 * index, N, e);
+  if (kind == MSSIM_BODY_KIN) return pose_soa(S.kin, 7 * index, N, e);
+  return pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
+}
+
+MS_DEV shape_t make_shape(const DevModel& M, const DevState& S, int s, int e) {
+  shape_t sh;
+  pose_t W = pmul(body_pose_of(M, S, M.shape_kind[s], M.shape_index[s], e), pose_from(M.shape_frame + 7 * s));
+  sh.type = M.shape_type[s];
+  sh.c = W.p;
+  sh.rot = qmat(W.q);
+  sh.p0 = M.shape_param[4 * s]; sh.p1 = M.shape_param[4 * s + 1]; sh.p2 = M.shape_param[4 * s + 2];
+  sh.verts = M.hull_verts + 3 * M.shape_hull[2 * s];
+  sh.nverts = M.shape_hull[2 * s + 1];
+  return sh;
+}
+
+__global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
+  __shared__ float lds[CLIP_SLOTS * 64];
+  const int N = S.N;
+  const int p = blockIdx.y;
+  int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= N) return;
+  const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+  shape_t A = make_shape(M, S, sa, e), B = make_shape(M, S, sb, e);
+  float ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
+  f3 cb = B.c + mmulv(B.rot, f3{M.shape_bound[4 * sb], M.shape_bound[4 * sb + 1], M.shape_bound[4 * sb + 2]});
+  bool cull;
+  if (A.type == SH_PLANE) {
+    cull = dot(mcol(A.rot, 0), cb - A.c) > rb + M.contact_offset;
+  } else {
+    f3 ca = A.c + mmulv(A.rot, f3{M.shape_bound[4 * sa], M.shape_bound[4 * sa + 1], M.shape_bound[4 * sa + 2]});
+    f3 d = cb - ca;
+    float rr = ra + rb + M.contact_offset;
+    cull = dot(d, d) > rr * rr;
+  }
+  manifold_t m;
+  m.count = 0;
+  if (!cull) {
+    if (A.type == SH_PLANE) collide_plane(A, B, M.contact_offset, m);
+    else if (A.type == SH_BOX && B.type == SH_BOX) collide_box_box(A, B, M.contact_offset, m, lds + threadIdx.x);
+    else collide_mpr(A, B, M.contact_offset, m);
+  }
+  S.pair_cnt[(size_t)p * N + e] = m.count;
+  if (m.count > 0) {
+    float* o = S.pair_data + (size_t)(19 * p) * N + e;
+    o[0] = m.n.x; o[(size_t)N] = m.n.y; o[2 * (size_t)N] = m.n.z;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < m.count) {
+        o[(size_t)(3 + 4 * k) * N] = m.x[k].x; o[(size_t)(4 + 4 * k) * N] = m.x[k].y; o[(size_t)(5 + 4 * k) * N] = m.x[k].z;
+        o[(size_t)(6 + 4 * k) * N] = m.sep[k] - M.rest_offset;
+      }
+    atomicOr(&S.hit_mask[(size_t)(p >> 5) * N + e], 1u << (p & 31));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// solver row layout in the scratch buffer (fields of one row, each [N] floats)
+template <int MAXD>
+struct RowF {
+  static constexpr int JA = 0, WA = MAXD, F0 = 2 * MAXD, F1 = 2 * MAXD + 11;  // free side: idx, minv, Jl3, Jw3, Ww3
+  static constexpr int INVD = 2 * MAXD + 22, BPOS = INVD + 1, BVEL = INVD + 2, MU = INVD + 3, LAM = INVD + 4, FLAGS = INVD + 5,
+                       PAIR = INVD + 6, DIR = INVD + 7;
+  static constexpr int COUNT = INVD + 10;
+};
+#define ROW_HAS_ART 1
+#define ROW_FRICTION 2
+#define ROW_VALID 4
+
+// per-lane free-body data kept in LDS as [item][64]: 16 items per body
+#define FB_V 0   // linear velocity (3)
+#define FB_W 3   // angular velocity (3)
+#define FB_MINV 6
+#define FB_IINV 7  // 6
+#define FB_COM 13  // 3
+#define FB_ITEMS 16
+
+template <class T>
+__global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
+  __shared__ float fb[MSSIM_MAX_FREE * FB_ITEMS * 64];
+  typedef RowF<T::MAXD> RF;
+  const int N = S.N;
+  const int lane = threadIdx.x;
+  int e = blockIdx.x * 64 + lane;
+  if (e >= N) return;
+  T topo(M);
+  const int n = topo.n();
+  const float dt = M.dt;
+  const f3 g = f3{M.gx, M.gy, M.gz};
+  float* fbl = fb + lane;
+#define FB(b, item) fbl[(size_t)((b) * FB_ITEMS + (item)) * 64]
+
+  // ---- state
+  pose_t root = pose_soa(S.root, 0, N, e);
+  const f3 O = root.p;
+  float q[T::MAXD], qd[T::MAXD];
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= n) break;
+    q[j] = SOA(S.q, j);
+    qd[j] = SOA(S.qd, j);
+  }
+  // ---- 1. FK
+  pose_t bp[T::MAXD];
+  f3 aw[T::MAXD], anchor[T::MAXD];
+  fk_bodies(topo, M, root, q, bp, aw, anchor);
+
+  // ---- 3. joint-space dynamics: RNEA bias + CRBA
+  float Mq[T::MAXD][T::MAXD];
+  float bias[T::MAXD];
+  {
+    si10 Ic[T::MAXD];
+    sv6 V[T::MAXD], Ab[T::MAXD];
+    sf6 F[T::MAXD];
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      const float* in = M.body_inertial + 10 * j;
+      m3 R = qmat(bp[j].q);
+      s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
+      f3 c = bp[j].p + mmulv(R, f3{in[1], in[2], in[3]}) - O;
+      float m = in[0], cc = dot(c, c);
+      Iw.xx += m * (cc - c.x * c.x); Iw.yy += m * (cc - c.y * c.y); Iw.zz += m * (cc - c.z * c.z);
+      Iw.xy -= m * c.x * c.y; Iw.xz -= m * c.x * c.z; Iw.yz -= m * c.y * c.z;
+      si10 I = si10{m, c * m, Iw};
+      Ic[j] = I;
+      int p = topo.parent(j);
+      sv6 Vp = sv6{f3{0, 0, 0}, f3{0, 0, 0}}, Ap = Vp;
+      if (T::STATIC) {
+#pragma unroll
+        for (int k = 0; k < T::MAXD; k++)
+          if (k == p) { Vp = V[k]; Ap = Ab[k]; }
+      } else if (p >= 0) {
+        Vp = V[p]; Ap = Ab[p];
+      }
+      sv6 Sj = subspace(topo, j, aw[j], anchor[j] - O);
+      V[j] = sv6{Vp.w + Sj.w * qd[j], Vp.v + Sj.v * qd[j]};
+      sv6 cr = crossm(V[j], Sj);
+      Ab[j] = sv6{Ap.w + cr.w * qd[j], Ap.v + cr.v * qd[j]};
+      sf6 f1 = imul(I, Ab[j]);
+      sf6 f2 = crossf(V[j], imul(I, V[j]));
+      F[j] = sf6{f1.n + f2.n, f1.f + f2.f};
+      if (M.body_gravity[j]) {
+        F[j].f -= g * m;
+        F[j].n -= cross(I.h, g);
+      }
+    }
+#pragma unroll T::UNROLL
+    for (int jj = 0; jj < T::MAXD; jj++) {
+      int j = T::STATIC ? (T::MAXD - 1 - jj) : (n - 1 - jj);
+      if (j < 0) break;
+      sv6 Sj = subspace(topo, j, aw[j], anchor[j] - O);
+      bias[j] = sdot(Sj, F[j]);
+      int p = topo.parent(j);
+      if (T::STATIC) {
+#pragma unroll
+        for (int k = 0; k < T::MAXD; k++)
+          if (k == p) {
+            F[k].n += F[j].n; F[k].f += F[j].f;
+            Ic[k].m += Ic[j].m; Ic[k].h += Ic[j].h; Ic[k].I = sadd(Ic[k].I, Ic[j].I);
+          }
+      } else if (p >= 0) {
+        F[p].n += F[j].n; F[p].f += F[j].f;
+        Ic[p].m += Ic[j].m; Ic[p].h += Ic[j].h; Ic[p].I = sadd(Ic[p].I, Ic[j].I);
+      }
+    }
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      sv6 Sj = subspace(topo, j, aw[j], anchor[j] - O);
+      sf6 Fc = imul(Ic[j], Sj);
+      unsigned am = topo.anc(j);
+#pragma unroll T::UNROLL
+      for (int i = 0; i < T::MAXD; i++) {
+        if (i >= n) break;
+        if (i == j) Mq[j][j] = sdot(Sj, Fc) + M.dof_armature[j];
+        else if (i < j) {
+          float v = 0.f;
+          if ((am >> i) & 1u) v = sdot(subspace(topo, i, aw[i], anchor[i] - O), Fc);
+          Mq[j][i] = v;
+          Mq[i][j] = v;
+        }
+      }
+    }
+  }
+  // ---- implicit PD drives + tendons
+  float A[T::MAXD][T::MAXD], rhs[T::MAXD], tau0[T::MAXD], Dj[T::MAXD], kp[T::MAXD], kd[T::MAXD], qt[T::MAXD], qdt[T::MAXD];
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= n) break;
+    qt[j] = SOA(S.qt, j);
+    qdt[j] = SOA(S.qdt, j);
+    kp[j] = M.dof_drive[4 * j];
+    kd[j] = M.dof_drive[4 * j + 1];
+    if ((int)M.dof_drive[4 * j + 3] == MSSIM_DRIVE_ACCELERATION) { kp[j] *= Mq[j][j]; kd[j] *= Mq[j][j]; }
+    tau0[j] = kp[j] * (qt[j] - q[j]) + kd[j] * qdt[j];
+    Dj[j] = dt * kd[j] + dt * dt * kp[j];
+#pragma unroll T::UNROLL
+    for (int i = 0; i < T::MAXD; i++) {
+      if (i >= n) break;
+      A[j][i] = Mq[j][i] + (i == j ? Dj[j] : 0.f);
+    }
+    rhs[j] = 0.f;
+  }
+  for (int t = 0; t < M.n_tendon; t++) {
+    int a = M.tendon_dof[2 * t], b = M.tendon_dof[2 * t + 1];
+    const float* tp = M.tendon_param + 5 * t;
+    float ca = tp[0], cb = tp[1], qa = 0.f, qb = 0.f;
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      if (j == a) qa = q[j];
+      if (j == b) qb = q[j];
+    }
+    float c = ca * qa + cb * qb - tp[2];
+    float k = tp[3], w = dt * dt * k + dt * tp[4];
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      float cj = j == a ? ca : (j == b ? cb : 0.f);
+      rhs[j] -= k * c * cj;  // tendon torque, folded into rhs below
+#pragma unroll T::UNROLL
+      for (int i = 0; i < T::MAXD; i++) {
+        if (i >= n) break;
+        float ci = i == a ? ca : (i == b ? cb : 0.f);
+        A[j][i] += w * cj * ci;
+      }
+    }
+  }
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= n) break;
+    float mv = 0.f;
+#pragma unroll T::UNROLL
+    for (int k = 0; k < T::MAXD; k++) {
+      if (k >= n) break;
+      mv += Mq[j][k] * qd[k];
+    }
+    rhs[j] = mv + dt * (tau0[j] + rhs[j] - bias[j] + SOA(S.qf, j));
+  }
+  // LDL^T, solve, force-limit active set, explicit inverse
+  float L[T::MAXD][T::MAXD], v[T::MAXD], Ainv[T::MAXD][T::MAXD];
+  auto factor = [&]() {
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      float d = A[j][j];
+#pragma unroll T::UNROLL
+      for (int k = 0; k < T::MAXD; k++) {
+        if (k >= j) break;
+        d -= L[j][k] * L[j][k] * L[k][k];
+      }
+      L[j][j] = d;
+      float id = 1.f / d;
+#pragma unroll T::UNROLL
+      for (int i = 0; i < T::MAXD; i++) {
+        if (i >= n) break;
+        if (i > j) {
+          float t = A[i][j];
+#pragma unroll T::UNROLL
+          for (int k = 0; k < T::MAXD; k++) {
+            if (k >= j) break;
+            t -= L[i][k] * L[j][k] * L[k][k];
+          }
+          L[i][j] = t * id;
+        }
+      }
+    }
+  };
+  auto solve = [&](float* b) {
+#pragma unroll T::UNROLL
+    for (int i = 0; i < T::MAXD; i++) {
+      if (i >= n) break;
+#pragma unroll T::UNROLL
+      for (int k = 0; k < T::MAXD; k++) {
+        if (k >= i) break;
+        b[i] -= L[i][k] * b[k];
+      }
+    }
+#pragma unroll T::UNROLL
+    for (int i = 0; i < T::MAXD; i++) {
+      if (i >= n) break;
+      b[i] /= L[i][i];
+    }
+#pragma unroll T::UNROLL
+    for (int ii = 0; ii < T::MAXD; ii++) {
+      int i = T::STATIC ? (T::MAXD - 1 - ii) : (n - 1 - ii);
+      if (i < 0) break;
+#pragma unroll T::UNROLL
+      for (int k = 0; k < T::MAXD; k++) {
+        if (k >= n) break;
+        if (k > i) b[i] -= L[k][i] * b[k];
+      }
+    }
+  };
+  if (n > 0) {
+    factor();
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; v[j] = rhs[j]; }
+    solve(v);
+    bool any = false;
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      float fmax = M.dof_drive[4 * j + 2];
+      float td = kp[j] * (qt[j] - q[j] - dt * v[j]) + kd[j] * (qdt[j] - v[j]);
+      if (fmax < 1e30f && fabsf(td) > fmax) {
+        float sat = td > 0.f ? fmax : -fmax;
+        A[j][j] -= Dj[j];
+        rhs[j] += dt * (sat - tau0[j]);
+        any = true;
+      }
+    }
+    if (any) {
+      factor();
+#pragma unroll T::UNROLL
+      for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; v[j] = rhs[j]; }
+      solve(v);
+    }
+#pragma unroll T::UNROLL
+    for (int c = 0; c < T::MAXD; c++) {
+      if (c >= n) break;
+      float ecol[T::MAXD];
+#pragma unroll T::UNROLL
+      for (int r = 0; r < T::MAXD; r++) { if (r >= n) break; ecol[r] = r == c ? 1.f : 0.f; }
+      solve(ecol);
+#pragma unroll T::UNROLL
+      for (int r = 0; r < T::MAXD; r++) { if (r >= n) break; Ainv[r][c] = ecol[r]; }
+    }
+  }
+  // ---- free bodies: unconstrained velocities into LDS
+  for (int b = 0; b < M.n_free; b++) {
+    const float* in = M.free_inertial + 10 * b;
+    pose_t P = pose_soa(S.free_s, 13 * b, N, e);
+    m3 R = qmat(P.q);
+    s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
+    s3 Ii = sinverse(Iw);
+    float minv = 1.f / in[0];
+    f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
+    f3 v0 = f3{SOA(S.free_s, 13 * b + 7), SOA(S.free_s, 13 * b + 8), SOA(S.free_s, 13 * b + 9)};
+    f3 w0 = f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)};
+    f3 acc = f3{SOA(S.free_force, 3 * b), SOA(S.free_force, 3 * b + 1), SOA(S.free_force, 3 * b + 2)} * minv;
+    if (M.free_gravity[b]) acc += g;
+    f3 vv = v0 + acc * dt;
+    f3 ww = w0 - smulv(Ii, cross(w0, smulv(Iw, w0))) * dt;
+    float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
+    vv = vv * (ld > 0.f ? ld : 0.f);
+    ww = ww * (ad > 0.f ? ad : 0.f);
+    FB(b, FB_V) = vv.x; FB(b, FB_V + 1) = vv.y; FB(b, FB_V + 2) = vv.z;
+    FB(b, FB_W) = ww.x; FB(b, FB_W + 1) = ww.y; FB(b, FB_W + 2) = ww.z;
+    FB(b, FB_MINV) = minv;
+    FB(b, FB_IINV) = Ii.xx; FB(b, FB_IINV + 1) = Ii.yy; FB(b, FB_IINV + 2) = Ii.zz;
+    FB(b, FB_IINV + 3) = Ii.xy; FB(b, FB_IINV + 4) = Ii.xz; FB(b, FB_IINV + 5) = Ii.yz;
+    FB(b, FB_COM) = com.x; FB(b, FB_COM + 1) = com.y; FB(b, FB_COM + 2) = com.z;
+  }
+
+  // ---- 4a. joint-limit rows (registers)
+  float lim_side[T::MAXD], lim_bpos[T::MAXD], lim_bvel[T::MAXD], lim_lam[T::MAXD];
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= n) break;
+    float lo = M.dof_limit[2 * j], hi = M.dof_limit[2 * j + 1];
+    bool has = lo > -1e30f || hi < 1e30f;
+    float dlo = q[j] - lo, dhi = hi - q[j];
+    float C = dlo <= dhi ? dlo : dhi;
+    lim_side[j] = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
+    lim_bpos[j] = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
+    lim_bvel[j] = C >= 0.f ? C / dt : 0.f;
+    lim_lam[j] = 0.f;
+  }
+
+  // ---- 4b. contact rows -> scratch
+  int nrows = 0;
+  {
+    int ncontacts = 0;
+    for (int w = 0; w < M.n_words; w++) {
+      unsigned bits = S.hit_mask[(size_t)w * N + e];
+      while (bits) {
+        int bit = __ffs(bits) - 1;
+        bits &= bits - 1;
+        int p = w * 32 + bit;
+        int cnt = S.pair_cnt[(size_t)p * N + e];
+        const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
+        SOA(S.pair_imp, 3 * p) = 0.f; SOA(S.pair_imp, 3 * p + 1) = 0.f; SOA(S.pair_imp, 3 * p + 2) = 0.f;
+        int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+        int kinds[2] = {M.shape_kind[sa], M.shape_kind[sb]};
+        int idxs[2] = {M.shape_index[sa], M.shape_index[sb]};
+        float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
+        f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
+        f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
+        f3 t2 = cross(nrm, t1);
+        for (int k = 0; k < cnt; k++) {
+          if (ncontacts >= MAXC) { S.overflow[e] = 1; break; }
+          ncontacts++;
+          f3 x = f3{pd[(size_t)(3 + 4 * k) * N], pd[(size_t)(4 + 4 * k) * N], pd[(size_t)(5 + 4 * k) * N]};
+          float sep = pd[(size_t)(6 + 4 * k) * N];
+          for (int dk = 0; dk < 3; dk++) {
+            f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
+            float* row = S.rows + (size_t)nrows * RF::COUNT * N + e;
+#define RW(f) row[(size_t)(f) * N]
+            float Ja[T::MAXD];
+#pragma unroll T::UNROLL
+            for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; Ja[i] = 0.f; }
+            bool hasart = false;
+            int nfree = 0;
+            float diag = 0.f;
+            RW(RF::F0) = __int_as_float(-1);
+            RW(RF::F1) = __int_as_float(-1);
+            for (int s = 0; s < 2; s++) {
+              float sign = s == 0 ? 1.f : -1.f;
+              if (kinds[s] == MSSIM_BODY_ART && idxs[s] >= 0) {
+                hasart = true;
+                unsigned am = M.dof_anc[idxs[s]] | (1u << idxs[s]);
+#pragma unroll T::UNROLL
+                for (int i = 0; i < T::MAXD; i++) {
+                  if (i >= n) break;
+                  if ((am >> i) & 1u) {
+                    f3 col = topo.revolute(i) ? cross(aw[i], x - anchor[i]) : aw[i];
+                    Ja[i] += sign * dot(d, col);
+                  }
+                }
+              } else if (kinds[s] == MSSIM_BODY_FREE) {
+                int b = idxs[s];
+                f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)};
+                s3 Ii = s3{FB(b, FB_IINV), FB(b, FB_IINV + 1), FB(b, FB_IINV + 2), FB(b, FB_IINV + 3), FB(b, FB_IINV + 4), FB(b, FB_IINV + 5)};
+                float minv = FB(b, FB_MINV);
+                f3 Jl = d * sign, Jw = cross(x - com, d) * sign;
+                f3 Ww = smulv(Ii, Jw);
+                int base = nfree == 0 ? RF::F0 : RF::F1;
+                RW(base) = __int_as_float(b); RW(base + 1) = minv;
+                RW(base + 2) = Jl.x; RW(base + 3) = Jl.y; RW(base + 4) = Jl.z;
+                RW(base + 5) = Jw.x; RW(base + 6) = Jw.y; RW(base + 7) = Jw.z;
+                RW(base + 8) = Ww.x; RW(base + 9) = Ww.y; RW(base + 10) = Ww.z;
+                diag += dot(Jl, Jl) * minv + dot(Jw, Ww);
+                nfree++;
+              }
+            }
+            if (hasart) {
+#pragma unroll T::UNROLL
+              for (int i = 0; i < T::MAXD; i++) {
+                if (i >= n) break;
+                float wv = 0.f;
+#pragma unroll T::UNROLL
+                for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; wv += Ainv[i][j] * Ja[j]; }
+                RW(RF::JA + i) = Ja[i];
+                RW(RF::WA + i) = wv;
+                diag += Ja[i] * wv;
+              }
+            }
+            int flags = (hasart ? ROW_HAS_ART : 0) | (dk > 0 ? ROW_FRICTION : 0) | (diag > 1e-12f ? ROW_VALID : 0);
+            RW(RF::INVD) = diag > 1e-12f ? 1.f / diag : 0.f;
+            RW(RF::BPOS) = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
+            RW(RF::BVEL) = dk == 0 ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
+            RW(RF::MU) = mu;
+            RW(RF::LAM) = 0.f;
+            RW(RF::FLAGS) = __int_as_float(flags);
+            RW(RF::PAIR) = __int_as_float(p);
+            RW(RF::DIR) = d.x; RW(RF::DIR + 1) = d.y; RW(RF::DIR + 2) = d.z;
+            nrows++;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- 5. projected Gauss-Seidel
+  auto sweep = [&](bool use_bias) {
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      if (lim_side[j] != 0.f && Ainv[j][j] > 1e-12f) {
+        float jv = lim_side[j] * v[j];
+        float b = use_bias ? lim_bpos[j] : lim_bvel[j];
+        float nl = lim_lam[j] - (jv + b) / Ainv[j][j];
+        nl = nl < 0.f ? 0.f : nl;
+        float dl = nl - lim_lam[j];
+        lim_lam[j] = nl;
+        if (dl != 0.f) {
+#pragma unroll T::UNROLL
+          for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += lim_side[j] * Ainv[i][j] * dl; }
+        }
+      }
+    }
+    float lam_n = 0.f;
+    for (int r = 0; r < nrows; r++) {
+      float* row = S.rows + (size_t)r * RF::COUNT * N + e;
+      int flags = __float_as_int(RW(RF::FLAGS));
+      float lam = RW(RF::LAM);
+      if (!(flags & ROW_FRICTION)) lam_n = lam;
+      if (!(flags & ROW_VALID)) continue;
+      float jv = 0.f;
+      float Wa[T::MAXD];
+      if (flags & ROW_HAS_ART) {
+#pragma unroll T::UNROLL
+        for (int i = 0; i < T::MAXD; i++) {
+          if (i >= n) break;
+          jv += RW(RF::JA + i) * v[i];
+          Wa[i] = RW(RF::WA + i);
+        }
+      }
+      int b0 = __float_as_int(RW(RF::F0)), b1 = __float_as_int(RW(RF::F1));
+      f3 Jl0, Jw0, Jl1, Jw1;
+      if (b0 >= 0) {
+        Jl0 = f3{RW(RF::F0 + 2), RW(RF::F0 + 3), RW(RF::F0 + 4)};
+        Jw0 = f3{RW(RF::F0 + 5), RW(RF::F0 + 6), RW(RF::F0 + 7)};
+        jv += dot(Jl0, f3{FB(b0, FB_V), FB(b0, FB_V + 1), FB(b0, FB_V + 2)}) + dot(Jw0, f3{FB(b0, FB_W), FB(b0, FB_W + 1), FB(b0, FB_W + 2)});
+      }
+      if (b1 >= 0) {
+        Jl1 = f3{RW(RF::F1 + 2), RW(RF::F1 + 3), RW(RF::F1 + 4)};
+        Jw1 = f3{RW(RF::F1 + 5), RW(RF::F1 + 6), RW(RF::F1 + 7)};
+        jv += dot(Jl1, f3{FB(b1, FB_V), FB(b1, FB_V + 1), FB(b1, FB_V + 2)}) + dot(Jw1, f3{FB(b1, FB_W), FB(b1, FB_W + 1), FB(b1, FB_W + 2)});
+      }
+      float lo = 0.f, hi = 1e30f;
+      if (flags & ROW_FRICTION) { hi = RW(RF::MU) * lam_n; lo = -hi; }
+      float b = use_bias ? RW(RF::BPOS) : RW(RF::BVEL);
+      float nl = lam - (jv + b) * RW(RF::INVD);
+      nl = nl < lo ? lo : (nl > hi ? hi : nl);
+      float dl = nl - lam;
+      if (!(flags & ROW_FRICTION)) lam_n = nl;
+      if (dl != 0.f) {
+        RW(RF::LAM) = nl;
+        if (flags & ROW_HAS_ART) {
+#pragma unroll T::UNROLL
+          for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += Wa[i] * dl; }
+        }
+        if (b0 >= 0) {
+          float minv = RW(RF::F0 + 1);
+          f3 Ww = f3{RW(RF::F0 + 8), RW(RF::F0 + 9), RW(RF::F0 + 10)};
+          FB(b0, FB_V) += Jl0.x * minv * dl; FB(b0, FB_V + 1) += Jl0.y * minv * dl; FB(b0, FB_V + 2) += Jl0.z * minv * dl;
+          FB(b0, FB_W) += Ww.x * dl; FB(b0, FB_W + 1) += Ww.y * dl; FB(b0, FB_W + 2) += Ww.z * dl;
+        }
+        if (b1 >= 0) {
+          float minv = RW(RF::F1 + 1);
+          f3 Ww = f3{RW(RF::F1 + 8), RW(RF::F1 + 9), RW(RF::F1 + 10)};
+          FB(b1, FB_V) += Jl1.x * minv * dl; FB(b1, FB_V + 1) += Jl1.y * minv * dl; FB(b1, FB_V + 2) += Jl1.z * minv * dl;
+          FB(b1, FB_W) += Ww.x * dl; FB(b1, FB_W + 1) += Ww.y * dl; FB(b1, FB_W + 2) += Ww.z * dl;
+        }
+      }
+    }
+  };
+  for (int it = 0; it < M.pos_iters; it++) sweep(true);
+  float vpos[T::MAXD];
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; vpos[j] = v[j]; }
+  // free-body position-iteration velocities: integrate poses now, velocities after the velocity sweep
+  for (int b = 0; b < M.n_free; b++) {
+    const float* in = M.free_inertial + 10 * b;
+    f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)} + f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)} * dt;
+    f3 w = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
+    q4 qq = q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)};
+    qq = qnormalized(qq);
+    q4 dq = qmul(q4{0.f, w.x, w.y, w.z}, qq);
+    qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
+    f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
+    SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
+    SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
+  }
+  for (int it = 0; it < M.vel_iters; it++) sweep(false);
+
+  // ---- contact impulses per pair
+  for (int r = 0; r < nrows; r++) {
+    float* row = S.rows + (size_t)r * RF::COUNT * N + e;
+    float lam = RW(RF::LAM);
+    int p = __float_as_int(RW(RF::PAIR));
+    SOA(S.pair_imp, 3 * p) += RW(RF::DIR) * lam;
+    SOA(S.pair_imp, 3 * p + 1) += RW(RF::DIR + 1) * lam;
+    SOA(S.pair_imp, 3 * p + 2) += RW(RF::DIR + 2) * lam;
+  }
+
+  // ---- 6. integrate + FK at the new state
+#pragma unroll T::UNROLL
+  for (int j = 0; j < T::MAXD; j++) {
+    if (j >= n) break;
+    SOA(S.qacc, j) = (v[j] - qd[j]) / dt;
+    q[j] += dt * vpos[j];
+    SOA(S.q, j) = q[j];
+    SOA(S.qd, j) = v[j];
+  }
+  for (int b = 0; b < M.n_free; b++) {
+    SOA(S.free_s, 13 * b + 7) = FB(b, FB_V); SOA(S.free_s, 13 * b + 8) = FB(b, FB_V + 1); SOA(S.free_s, 13 * b + 9) = FB(b, FB_V + 2);
+    SOA(S.free_s, 13 * b + 10) = FB(b, FB_W); SOA(S.free_s, 13 * b + 11) = FB(b, FB_W + 1); SOA(S.free_s, 13 * b + 12) = FB(b, FB_W + 2);
+    SOA(S.free_force, 3 * b) = 0.f; SOA(S.free_force, 3 * b + 1) = 0.f; SOA(S.free_force, 3 * b + 2) = 0.f;
+  }
+  fk_bodies(topo, M, root, q, bp, aw, anchor);
+  write_kinematics(topo, M, S, e, root, v, bp, aw, anchor);
+  for (int w = 0; w < M.n_words; w++) S.hit_mask[(size_t)w * N + e] = 0u;
+#undef RW
+#undef FB
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply / fetch: transposes between the user-visible AoS buffers and the SoA state
+__global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) {
+  const int N = S.N;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  if ((what & MSSIM_RIGID_DATA) && B.rigid_body_data) {
+    for (int b = 0; b < M.n_free; b++) {
+      const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
+      for (int c = 0; c < 13; c++) SOA(S.free_s, 13 * b + c) = r[c];
+    }
+    for (int k = 0; k < M.n_kin; k++) {
+      const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
+      for (int c = 0; c < 7; c++) SOA(S.kin, 7 * k + c) = r[c];
+    }
+  }
+  if ((what & MSSIM_ART_ROOT_POSE) && B.rigid_body_data && M.n_link > 0) {
+    const float* r = B.rigid_body_data + 13 * (size_t)e;
+    for (int c = 0; c < 7; c++) SOA(S.root, c) = r[c];
+  }
+  if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) SOA(S.q, j) = B.art_qpos[(size_t)e * n + j];
+  if ((what & MSSIM_ART_QVEL) && B.art_qvel) for (int j = 0; j < n; j++) SOA(S.qd, j) = B.art_qvel[(size_t)e * n + j];
+  if ((what & MSSIM_ART_QF) && B.art_qf) for (int j = 0; j < n; j++) SOA(S.qf, j) = B.art_qf[(size_t)e * n + j];
+  if ((what & MSSIM_ART_TARGET_POS) && B.art_target_qpos) for (int j = 0; j < n; j++) SOA(S.qt, j) = B.art_target_qpos[(size_t)e * n + j];
+  if ((what & MSSIM_ART_TARGET_VEL) && B.art_target_qvel) for (int j = 0; j < n; j++) SOA(S.qdt, j) = B.art_target_qvel[(size_t)e * n + j];
+  if ((what & MSSIM_RIGID_FORCE) && B.rigid_body_force)
+    for (int b = 0; b < M.n_free; b++) {
+      const float* f = B.rigid_body_force + 4 * ((size_t)(M.n_link + b) * N + e);
+      for (int c = 0; c < 3; c++) SOA(S.free_force, 3 * b + c) = f[c];
+    }
+}
+
+__global__ void k_fetch(DevModel M, DevState S, mssim_buffers B, unsigned what) {
+  const int N = S.N;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  if (B.rigid_body_data) {
+    if (what & MSSIM_RIGID_DATA) {
+      for (int b = 0; b < M.n_free; b++) {
+        float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
+        for (int c = 0; c < 13; c++) r[c] = SOA(S.free_s, 13 * b + c);
+      }
+      for (int k = 0; k < M.n_kin; k++) {
+        float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
+        pose_t P = pose_soa(S.kin, 7 * k, N, e);
+        r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z;
+        for (int c = 7; c < 13; c++) r[c] = 0.f;
+      }
+    }
+    if (what & (MSSIM_LINK_POSE | MSSIM_LINK_VEL)) {
+      pose_t root = pose_soa(S.root, 0, N, e);
+      for (int l = 0; l < M.n_link; l++) {
+        float* r = B.rigid_body_data + 13 * ((size_t)l * N + e);
+        int b = M.link_body[l];
+        pose_t P = pmul(b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e), pose_from(M.link_frame + 7 * l));
+        if (what & MSSIM_LINK_POSE) { r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z; }
+        if (what & MSSIM_LINK_VEL) {
+          f3 w = f3{0, 0, 0}, vv = f3{0, 0, 0};
+          if (b >= 0) {
+            w = f3{SOA(S.bodyvel, 6 * b), SOA(S.bodyvel, 6 * b + 1), SOA(S.bodyvel, 6 * b + 2)};
+            vv = f3{SOA(S.bodyvel, 6 * b + 3), SOA(S.bodyvel, 6 * b + 4), SOA(S.bodyvel, 6 * b + 5)} + cross(w, P.p - root.p);
+          }
+          r[7] = vv.x; r[8] = vv.y; r[9] = vv.z; r[10] = w.x; r[11] = w.y; r[12] = w.z;
+        }
+      }
+    }
+  }
+  if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) B.art_qpos[(size_t)e * n + j] = SOA(S.q, j);
+  if ((what & MSSIM_ART_QVEL) && B.art_qvel) for (int j = 0; j < n; j++) B.art_qvel[(size_t)e * n + j] = SOA(S.qd, j);
+  if ((what & MSSIM_ART_QACC) && B.art_qacc) for (int j = 0; j < n; j++) B.art_qacc[(size_t)e * n + j] = SOA(S.qacc, j);
+  if ((what & MSSIM_ART_TARGET_POS) && B.art_target_qpos) for (int j = 0; j < n; j++) B.art_target_qpos[(size_t)e * n + j] = SOA(S.qt, j);
+  if ((what & MSSIM_ART_TARGET_VEL) && B.art_target_qvel) for (int j = 0; j < n; j++) B.art_target_qvel[(size_t)e * n + j] = SOA(S.qdt, j);
+}
+
+// contact impulse queries: q = [nq][2] body rows (pair query) or [nq] rows (body query)
+__global__ void k_query(DevModel M, DevState S, const int* q, int nq, int body_query, float* out) {
+  const int N = S.N;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (e >= N || k >= nq) return;
+  f3 s = f3{0, 0, 0};
+  int qa = body_query ? q[k] : q[2 * k], qb = body_query ? -2 : q[2 * k + 1];
+  for (int p = 0; p < M.n_pair; p++) {
+    int ra = M.shape_row[M.pair_shape[2 * p]], rb = M.shape_row[M.pair_shape[2 * p + 1]];
+    float sign = 0.f;
+    if (body_query) sign = (ra == qa ? 1.f : 0.f) - (rb == qa ? 1.f : 0.f);
+    else if (ra == qa && rb == qb) sign = 1.f;
+    else if (ra == qb && rb == qa) sign = -1.f;
+    if (sign != 0.f && S.pair_cnt[(size_t)p * N + e] > 0)
+      s += f3{SOA(S.pair_imp, 3 * p), SOA(S.pair_imp, 3 * p + 1), SOA(S.pair_imp, 3 * p + 2)} * sign;
+  }
+  float* o = out + 3 * ((size_t)k * N + e);
+  o[0] = s.x; o[1] = s.y; o[2] = s.z;
+}
+
+__global__ void k_i2f(const int* src, float* dst, size_t count) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = (float)src[i];
+}
+
+// =================================================================================================
+// host side
+struct mssim_sim {
+  int device = 0;
+  int N = 0;
+  DevModel M{};
+  DevState S{};
+  mssim_buffers buf{};
+  std::vector<void*> allocs;
+  std::vector<float> drive_host;
+  float* d_drive = nullptr;
+  bool panda = false;
+  bool dirty = true;
+  std::vector<int*> queries;
+  std::vector<int> query_n;
+  std::vector<int> query_kind;
+  std::string err;
+  int row_fields = 0;
+};
+
+static std::string g_create_error;
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t _e = (call);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      std::string _m = std::string(#call) + ": " + hipGetErrorString(_e);                 \
+      if (h) (h)->err = _m; else g_create_error = _m;                                     \
+      return 100 + (int)_e;                                                               \
+    }                                                                                     \
+  } while (0)
+
+template <typename Tt>
+static int upload(mssim_sim* S, const Tt* src, size_t count, const Tt** dst) {
+  void* d = nullptr;
+  size_t bytes = (count > 0 ? count : 1) * sizeof(Tt);
+  HIPCHK(S, hipMalloc(&d, bytes));
+  S->allocs.push_back(d);
+  if (count > 0 && src) HIPCHK(S, hipMemcpy(d, src, count * sizeof(Tt), hipMemcpyHostToDevice));
+  else HIPCHK(S, hipMemset(d, 0, bytes));
+  *dst = (const Tt*)d;
+  return 0;
+}
+template <typename Tt>
+static int dalloc(mssim_sim* S, size_t count, Tt** dst) {
+  void* d = nullptr;
+  size_t bytes = (count > 0 ? count : 1) * sizeof(Tt);
+  HIPCHK(S, hipMalloc(&d, bytes));
+  HIPCHK(S, hipMemset(d, 0, bytes));
+  S->allocs.push_back(d);
+  *dst = (Tt*)d;
+  return 0;
+}
+
+extern "C" {
+
+int mssim_abi_version(void) { return MSSIM_ABI_VERSION; }
+const char* mssim_last_error(mssim_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void mssim_destroy(mssim_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+}
+
+int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, mssim_handle* out) {
+  if (!d || !out || num_envs <= 0) { g_create_error = "bad arguments"; return 1; }
+  if (d->abi_version != MSSIM_ABI_VERSION) { g_create_error = "ABI version mismatch"; return 2; }
+  if (d->n_dof > MSSIM_MAX_DOF || d->n_free > MSSIM_MAX_FREE) { g_create_error = "model exceeds MSSIM_MAX_DOF / MSSIM_MAX_FREE"; return 3; }
+  for (int j = 0; j < d->n_dof; j++)
+    if (d->dof_parent[j] >= j) { g_create_error = "dof_parent must be topologically sorted"; return 4; }
+  for (int s = 0; s < d->n_shape; s++)
+    if (d->shape_type[s] == MSSIM_SHAPE_CONVEX && (d->shape_hull[2 * s + 1] < 4 || d->shape_hull[2 * s + 1] > MSSIM_MAX_HULL_VERTS)) {
+      g_create_error = "convex hull vertex count out of range";
+      return 5;
+    }
+  mssim_sim* S = new mssim_sim();
+  S->device = device;
+  S->N = num_envs;
+  hipError_t e0 = hipSetDevice(device);
+  if (e0 != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e0); delete S; return 6; }
+  DevModel& M = S->M;
+  M.n_dof = d->n_dof; M.n_tendon = d->n_tendon; M.n_link = d->n_link; M.n_free = d->n_free; M.n_kin = d->n_kin;
+  M.n_shape = d->n_shape; M.n_pair = d->n_pair; M.n_words = (d->n_pair + 31) / 32;
+  const int n = d->n_dof, ns = d->n_shape;
+  std::vector<unsigned> anc(n > 0 ? n : 1, 0u);
+  for (int j = 0; j < n; j++)
+    for (int i = d->dof_parent[j]; i >= 0; i = d->dof_parent[i]) anc[j] |= 1u << i;
+  int rc = 0;
+#define UP(field, count) if ((rc = upload(S, d->field, (size_t)(count), &M.field))) { mssim_destroy(S); return rc; }
+  UP(dof_parent, n) UP(dof_type, n) UP(body_gravity, n) UP(tendon_dof, 2 * d->n_tendon) UP(link_body, d->n_link) UP(free_gravity, d->n_free)
+  UP(dof_frame, 7 * n) UP(dof_axis, 3 * n) UP(dof_limit, 2 * n) UP(dof_drive, 4 * n) UP(dof_armature, n) UP(body_inertial, 10 * n)
+  UP(tendon_param, 5 * d->n_tendon) UP(link_frame, 7 * d->n_link) UP(free_inertial, 10 * d->n_free) UP(free_damping, 2 * d->n_free)
+  UP(shape_type, ns) UP(shape_row, ns) UP(shape_hull, 2 * ns) UP(pair_shape, 2 * d->n_pair)
+  UP(shape_frame, 7 * ns) UP(shape_param, 4 * ns) UP(shape_material, 4 * ns) UP(shape_bound, 4 * ns) UP(hull_verts, 3 * d->n_hull_verts)
+#undef UP
+  if ((rc = upload(S, d->shape_body_kind, (size_t)ns, &M.shape_kind))) { mssim_destroy(S); return rc; }
+  if ((rc = upload(S, d->shape_body_index, (size_t)ns, &M.shape_index))) { mssim_destroy(S); return rc; }
+  if ((rc = upload(S, anc.data(), (size_t)n, &M.dof_anc))) { mssim_destroy(S); return rc; }
+  S->d_drive = const_cast<float*>(M.dof_drive);
+  M.gx = d->gravity[0]; M.gy = d->gravity[1]; M.gz = d->gravity[2];
+  M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
+  M.max_depen = d->max_depenetration_velocity; M.pos_iters = d->position_iterations; M.vel_iters = d->velocity_iterations;
+  S->panda = (n == 9);
+  for (int j = 0; j < n && S->panda; j++)
+    if (d->dof_parent[j] != kPandaParent[j] || d->dof_type[j] != kPandaType[j]) S->panda = false;
+  S->row_fields = S->panda ? RowF<TopoPanda::MAXD>::COUNT : RowF<TopoDyn::MAXD>::COUNT;
+  DevState& D = S->S;
+  D.N = num_envs;
+  const size_t N = (size_t)num_envs;
+#define AL(field, count) if ((rc = dalloc(S, (size_t)(count) * N, &D.field))) { mssim_destroy(S); return rc; }
+  AL(root, 7) AL(q, n) AL(qd, n) AL(qt, n) AL(qdt, n) AL(qf, n) AL(qacc, n)
+  AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin)
+  AL(bodypose, 7 * n) AL(bodyvel, 6 * n)
+  AL(pair_cnt, d->n_pair) AL(pair_data, 19 * d->n_pair) AL(pair_imp, 3 * d->n_pair) AL(hit_mask, M.n_words)
+  AL(rows, 3 * MAXC * S->row_fields) AL(overflow, 1)
+#undef AL
+  // identity quaternions
+  std::vector<float> ones(N, 1.0f);
+  hipMemcpy(D.root + 3 * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
+  for (int b = 0; b < d->n_free; b++) hipMemcpy(D.free_s + (13 * b + 3) * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
+  for (int k = 0; k < d->n_kin; k++) hipMemcpy(D.kin + (7 * k + 3) * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
+  *out = S;
+  return 0;
+}
+
+int mssim_bind_buffers(mssim_handle h, const mssim_buffers* b) {
+  if (!h || !b) return 1;
+  h->buf = *b;
+  return 0;
+}
+
+int mssim_set_timestep(mssim_handle h, float dt) {
+  if (!(dt > 0.f)) { h->err = "timestep must be positive"; return 1; }
+  h->M.dt = dt;
+  return 0;
+}
+float mssim_get_timestep(mssim_handle h) { return h->M.dt; }
+
+int mssim_set_drive_properties(mssim_handle h, const float* drive) {
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(h->d_drive, drive, sizeof(float) * 4 * h->M.n_dof, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static inline dim3 env_grid(int N, int block) { return dim3((N + block - 1) / block); }
+
+int mssim_apply(mssim_handle h, uint32_t what, void* stream) {
+  hipLaunchKernelGGL(k_apply, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
+  h->dirty = true;
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_fetch(mssim_handle h, uint32_t what, void* stream) {
+  hipLaunchKernelGGL(k_fetch, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+static void launch_fk(mssim_handle h, hipStream_t st) {
+  if (h->panda) hipLaunchKernelGGL(k_fk<TopoPanda>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+  else hipLaunchKernelGGL(k_fk<TopoDyn>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+}
+
+int mssim_update_kinematics(mssim_handle h, void* stream) {
+  launch_fk(h, (hipStream_t)stream);
+  h->dirty = false;
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+  for (int s = 0; s < n_substeps; s++) {
+    if (h->M.n_pair > 0) hipLaunchKernelGGL(k_narrow, dim3((h->N + 63) / 64, h->M.n_pair), dim3(64), 0, st, h->M, h->S);
+    if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+    else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+  }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+static int make_query(mssim_handle h, const int32_t* data, int count_ints, int nq, int kind, int32_t* qid) {
+  HIPCHK(h, hipSetDevice(h->device));
+  int* d = nullptr;
+  HIPCHK(h, hipMalloc((void**)&d, sizeof(int) * (count_ints > 0 ? count_ints : 1)));
+  h->allocs.push_back(d);
+  if (count_ints > 0) HIPCHK(h, hipMemcpy(d, data, sizeof(int) * count_ints, hipMemcpyHostToDevice));
+  h->queries.push_back(d);
+  h->query_n.push_back(nq);
+  h->query_kind.push_back(kind);
+  *qid = (int)h->queries.size() - 1;
+  return 0;
+}
+
+int mssim_create_pair_query(mssim_handle h, const int32_t* body_pairs, int32_t n_pairs, int32_t* qid) {
+  return make_query(h, body_pairs, 2 * n_pairs, n_pairs, 0, qid);
+}
+int mssim_create_body_query(mssim_handle h, const int32_t* rows, int32_t n, int32_t* qid) { return make_query(h, rows, n, n, 1, qid); }
+
+static int run_query(mssim_handle h, int32_t qid, int kind, float* out, void* stream) {
+  if (qid < 0 || qid >= (int)h->queries.size() || h->query_kind[qid] != kind) { h->err = "bad query id"; return 1; }
+  int nq = h->query_n[qid];
+  if (nq == 0) return 0;
+  hipLaunchKernelGGL(k_query, dim3((h->N + 255) / 256, nq), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->queries[qid], nq, kind, out);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+int mssim_query_pair_impulses(mssim_handle h, int32_t qid, float* out, void* stream) { return run_query(h, qid, 0, out, stream); }
+int mssim_query_body_impulses(mssim_handle h, int32_t qid, float* out, void* stream) { return run_query(h, qid, 1, out, stream); }
+
+int mssim_read_internal(mssim_handle h, const char* name, float* out, int32_t max_items, void* stream) {
+  std::string s(name);
+  const size_t N = (size_t)h->N;
+  const float* src = nullptr;
+  int items = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (s == "q") { src = h->S.q; items = h->M.n_dof; }
+  else if (s == "qd") { src = h->S.qd; items = h->M.n_dof; }
+  else if (s == "free") { src = h->S.free_s; items = 13 * h->M.n_free; }
+  else if (s == "kin") { src = h->S.kin; items = 7 * h->M.n_kin; }
+  else if (s == "root") { src = h->S.root; items = 7; }
+  else if (s == "bodypose") { src = h->S.bodypose; items = 7 * h->M.n_dof; }
+  else if (s == "pair_impulse") { src = h->S.pair_imp; items = 3 * h->M.n_pair; }
+  else if (s == "contact_count" || s == "overflow") {
+    const int* isrc = s == "overflow" ? h->S.overflow : h->S.pair_cnt;
+    items = s == "overflow" ? 1 : h->M.n_pair;
+    int take = items < max_items ? items : max_items;
+    size_t cnt = (size_t)take * N;
+    if (cnt > 0) hipLaunchKernelGGL(k_i2f, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, isrc, out, cnt);
+    HIPCHK(h, hipGetLastError());
+    return items;
+  } else {
+    h->err = "unknown internal array: " + s;
+    return -1;
+  }
+  int take = items < max_items ? items : max_items;
+  if (take > 0) HIPCHK(h, hipMemcpyAsync(out, src, sizeof(float) * (size_t)take * N, hipMemcpyDeviceToDevice, st));
+  return items;
+}
+
+int mssim_overflow_count(mssim_handle h, void* stream) {
+  std::vector<int> host(h->N);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  if (hipMemcpy(host.data(), h->S.overflow, sizeof(int) * h->N, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  (void)hipMemset(h->S.overflow, 0, sizeof(int) * h->N);
+  int c = 0;
+  for (int v : host) c += v;
+  return c;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Physical known-answer tests for the oracle's narrowphase + contact solver.
+
+rest / slide-threshold / drop tests, box-box manifold shape, and MPR cross-checked against
+analytic distances and against the SAT path.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.model import geom
+from maniskill_amd.model.compile import ActorRecord, SceneModelBuilder, ShapeRecord
+from maniskill_amd.model.scenes import cube_record, ground_record, panda_tabletop_model, table_record
+from tests import oracle_backend as ob
+
+
+def cube_on_table_model(gravity=(0, 0, -9.81), dt=0.01, **kw):
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(cube_record())
+    return b.compile(timestep=dt, gravity=gravity, **kw)
+
+
+def cube_state(px, model, N):
+    r = model.row_of("cube")
+    return px.cuda_rigid_body_data.torch()[r * N : (r + 1) * N]
+
+
+def test_cube_rests_on_table():
+    model = cube_on_table_model()
+    N = 4
+    px = ob.make_system(model, N)
+    s = cube_state(px, model, N)
+    s[:, 0] = torch.tensor([0.0, 0.05, -0.05, 0.1])
+    s[:, 2] = 0.02
+    yaw = torch.tensor([0.0, 0.3, 1.0, 2.0])
+    s[:, 3], s[:, 6] = torch.cos(yaw / 2), torch.sin(yaw / 2)
+    p0 = s[:, :3].clone()
+    px.gpu_apply_all()
+    px.step(100)  # 1 s
+    px.gpu_fetch_all()
+    s = cube_state(px, model, N)
+    assert torch.max(torch.abs(s[:, :3] - p0)) < 1e-4
+    assert torch.max(torch.abs(s[:, 7:13])) < 1e-3
+    cnt = px.read_internal("contact_count", model.n_pair)
+    assert torch.all(cnt.sum(0) == 4)
+
+
+@pytest.mark.parametrize("theta_deg,slides", [(14.0, False), (16.0, False), (17.5, True), (25.0, True)])
+def test_slide_threshold_mu_0p3(theta_deg, slides):
+    # tilt gravity instead of the table: slides iff tan(theta) > mu = 0.3  (theta* = 16.7 deg)
+    th = np.deg2rad(theta_deg)
+    g = 9.81 * np.array([np.sin(th), 0, -np.cos(th)])
+    model = cube_on_table_model(gravity=tuple(g))
+    px = ob.make_system(model, 1)
+    px.step(100)
+    px.gpu_fetch_all()
+    s = cube_state(px, model, 1)
+    if slides:
+        a = 9.81 * (np.sin(th) - 0.3 * np.cos(th))
+        assert s[0, 0].item() > 0.5 * 0.5 * a * 1.0  # at least half of the ideal travel
+        assert s[0, 0].item() < 1.2 * 0.5 * a * 1.0 + 1e-3
+    else:
+        assert abs(s[0, 0].item()) < 2e-3
+
+
+def test_drop_no_bounce():
+    model = cube_on_table_model()
+    px = ob.make_system(model, 1)
+    s = cube_state(px, model, 1)
+    s[:, 2] = 0.12
+    px.gpu_apply_all()
+    zmin_after_landing = []
+    for i in range(100):
+        px.step(1)
+        px.gpu_fetch_all()
+        z = cube_state(px, model, 1)[0, 2].item()
+        vz = cube_state(px, model, 1)[0, 9].item()
+        if i > 20:
+            zmin_after_landing.append((z, vz))
+    z = np.array(zmin_after_landing)
+    assert np.all(np.abs(z[-40:, 0] - 0.02) < 5e-4)  # at rest on the table
+    assert z[:, 1].max() < 0.05  # restitution 0: no upward rebound
+
+
+def test_stack_two_cubes_is_stable():
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(cube_record(name="c0", p=(0, 0, 0.02)))
+    b.add_actor(cube_record(name="c1", p=(0.005, 0.003, 0.06)))
+    model = b.compile()
+    px = ob.make_system(model, 1)
+    px.step(200)
+    px.gpu_fetch_all()
+    rb = px.cuda_rigid_body_data.torch()
+    assert abs(rb[model.row_of("c1"), 2].item() - 0.06) < 1e-3
+    assert abs(rb[model.row_of("c1"), 0].item() - 0.005) < 2e-3
+
+
+# ----------------------------------------------------------------------------- narrowphase hooks
+def _collide(lib, ta, pa, prm_a, tb, pb, prm_b, offset=0.02, force_mpr=0, va=None, vb=None):
+    fn = lib.lib.mssim_ref_test_collide
+    fn.restype = C.c_int
+    F = C.POINTER(C.c_float)
+
+    def arr(x, n=None):
+        a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        return a, a.ctypes.data_as(F)
+
+    a1, p1 = arr(pa)
+    a2, p2 = arr(list(prm_a) + [0] * (4 - len(prm_a)))
+    a3, p3 = arr(pb)
+    a4, p4 = arr(list(prm_b) + [0] * (4 - len(prm_b)))
+    va_ = np.zeros(3, np.float32) if va is None else np.ascontiguousarray(va, np.float32)
+    vb_ = np.zeros(3, np.float32) if vb is None else np.ascontiguousarray(vb, np.float32)
+    out = np.zeros(20, np.float32)
+    fn(
+        C.c_int(ta), p1, p2, va_.ctypes.data_as(F), C.c_int(0 if va is None else len(va_)),
+        C.c_int(tb), p3, p4, vb_.ctypes.data_as(F), C.c_int(0 if vb is None else len(vb_)),
+        C.c_float(offset), C.c_int(force_mpr), out.ctypes.data_as(F),
+    )
+    cnt = int(out[0])
+    return cnt, out[1:4].astype(np.float64), out[4 : 4 + 4 * cnt].reshape(cnt, 4).astype(np.float64)
+
+
+BOX, SPHERE, CONVEX = 1, 2, 5
+
+
+def test_box_box_face_manifold(oracle_lib):
+    # 4 cm cube resting 1 mm above a big box: 4 corner points, normal +z (from B=table to A=cube)
+    cube = geom.pose([0.01, 0.02, 0.021], geom.rpy_to_quat([0, 0, 0.4]))
+    table = geom.pose([0, 0, -0.5])
+    cnt, n, pts = _collide(oracle_lib, BOX, cube, [0.02] * 3, BOX, table, [1, 1, 0.5])
+    assert cnt == 4
+    np.testing.assert_allclose(n, [0, 0, 1], atol=1e-6)
+    np.testing.assert_allclose(pts[:, 3], 0.001, atol=1e-6)
+    R = geom.quat_to_mat(cube[3:])
+    corners = np.array([cube[:3] + R @ np.array([sx * 0.02, sy * 0.02, -0.02]) for sx in (-1, 1) for sy in (-1, 1)])
+    for c in corners:
+        assert np.min(np.linalg.norm(pts[:, :2] - c[:2], axis=1)) < 1e-6
+
+
+def test_box_box_edge_edge(oracle_lib):
+    # two cubes, edges crossing at 90 degrees (A rotated 45deg about x, B rotated 45deg about y)
+    a = geom.pose([0, 0, 0.0], geom.rpy_to_quat([np.pi / 4, 0, 0]))
+    h = 0.02 * np.sqrt(2)
+    b = geom.pose([0, 0, -2 * h - 0.003], geom.rpy_to_quat([0, np.pi / 4, 0]))
+    cnt, n, pts = _collide(oracle_lib, BOX, a, [0.02] * 3, BOX, b, [0.02] * 3)
+    assert cnt == 1
+    np.testing.assert_allclose(n, [0, 0, 1], atol=1e-5)
+    assert abs(pts[0, 3] - 0.003) < 1e-5
+    np.testing.assert_allclose(pts[0, :3], [0, 0, -h - 0.0015], atol=1e-5)
+
+
+def test_mpr_sphere_sphere_and_sphere_box(oracle_lib):
+    for d in (0.05, 0.061, 0.069):
+        cnt, n, pts = _collide(oracle_lib, SPHERE, geom.pose([0, 0, d]), [0.03], SPHERE, geom.pose(), [0.03])
+        assert cnt == 1
+        np.testing.assert_allclose(n, [0, 0, 1], atol=1e-4)
+        assert abs(pts[0, 3] - (d - 0.06)) < 1e-4
+    cnt, _, _ = _collide(oracle_lib, SPHERE, geom.pose([0, 0, 0.09]), [0.03], SPHERE, geom.pose(), [0.03])
+    assert cnt == 0
+    # sphere above a box face
+    cnt, n, pts = _collide(oracle_lib, BOX, geom.pose([0, 0, -0.5]), [1, 1, 0.5], SPHERE, geom.pose([0.1, 0.2, 0.035]), [0.03])
+    assert cnt == 1
+    np.testing.assert_allclose(n, [0, 0, -1], atol=1e-4)  # from B (sphere) to A (box)
+    assert abs(pts[0, 3] - 0.005) < 1e-4
+
+
+def test_mpr_agrees_with_sat_on_box_faces(oracle_lib):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        yaw = rng.uniform(-np.pi, np.pi)
+        tilt = rng.uniform(-0.05, 0.05, size=2)
+        gap = rng.uniform(-0.004, 0.015)
+        qa = geom.rpy_to_quat([tilt[0], tilt[1], yaw])
+        R = geom.quat_to_mat(qa)
+        # lowest corner of the cube sits `gap` above z = 0
+        low = min((R @ np.array([sx, sy, sz]) * 0.02)[2] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1))
+        a = geom.pose([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), gap - low], qa)
+        b = geom.pose([0, 0, -0.5])
+        c1, n1, p1 = _collide(oracle_lib, BOX, a, [0.02] * 3, BOX, b, [1, 1, 0.5])
+        c2, n2, p2 = _collide(oracle_lib, BOX, a, [0.02] * 3, BOX, b, [1, 1, 0.5], force_mpr=1)
+        assert c1 >= 1 and c2 == 1
+        np.testing.assert_allclose(n1, n2, atol=2e-3)
+        assert abs(p1[:, 3].min() - p2[0, 3]) < 2e-4
+        assert abs(p2[0, 3] - gap) < 2e-4
+
+
+def test_convex_hull_vs_box_matches_box_box(oracle_lib):
+    # a hull made of a cube's 8 corners must behave like the box
+    verts = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float32) * 0.02
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        q = geom.rpy_to_quat(rng.uniform(-np.pi, np.pi, size=3))
+        R = geom.quat_to_mat(q)
+        low = (verts.astype(np.float64) @ R.T)[:, 2].min()
+        gap = rng.uniform(-0.003, 0.015)
+        pose_h = geom.pose([0.05, -0.03, gap - low], q)
+        cnt, n, pts = _collide(oracle_lib, BOX, geom.pose([0, 0, -0.5]), [1, 1, 0.5], CONVEX, pose_h, [0, 0, 0], vb=verts)
+        assert cnt == 1
+        np.testing.assert_allclose(n, [0, 0, -1], atol=5e-3)
+        assert abs(pts[0, 3] - gap) < 3e-4
+
+
+def test_panda_grasp_holds_cube():
+    """close the gripper on the cube, lift: the cube must follow (friction 2.0 pads)."""
+    model = panda_tabletop_model()
+    N = 1
+    px = ob.make_system(model, N)
+    rest = np.array([0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, np.pi / 4, 0.04, 0.04], dtype=np.float32)
+    tcp = model.link_names.index("panda_hand_tcp")
+
+    def tcp_pos(qv):
+        px.cuda_articulation_qpos.torch()[:] = qv
+        px.gpu_apply_articulation_qpos()
+        px.gpu_update_articulation_kinematics()
+        px.gpu_fetch_articulation_link_pose()
+        return px.cuda_rigid_body_data.torch()[tcp * N, :3].clone()
+
+    def ik(q0, target):
+        # a few Gauss-Newton steps on joints 2, 4, 6 (keeps the hand pointing down approximately)
+        q = q0.clone()
+        idx = [1, 3, 5]
+        for _ in range(30):
+            p = tcp_pos(q)
+            J = torch.zeros(3, 3)
+            for k, j in enumerate(idx):
+                dq = q.clone()
+                dq[0, j] += 1e-4
+                J[:, k] = (tcp_pos(dq) - p) / 1e-4
+            step = torch.linalg.solve(J.T @ J + 1e-6 * torch.eye(3), J.T @ (target - p))
+            for k, j in enumerate(idx):
+                q[0, j] += step[k]
+        assert torch.norm(tcp_pos(q) - target) < 1e-3
+        return q
+
+    q = ik(torch.from_numpy(rest).clone()[None], torch.tensor([0.0, 0.0, 0.02]))
+    q_lift = ik(q, torch.tensor([0.0, 0.0, 0.15]))
+    px.cuda_articulation_qpos.torch()[:] = q
+    px.cuda_articulation_target_qpos.torch()[:] = q
+    px.gpu_apply_all()
+    # close
+    tq = q.clone()
+    tq[0, 7:] = -0.01
+    px.cuda_articulation_target_qpos.torch()[:] = tq
+    px.gpu_apply_articulation_target_position()
+    px.step(50)
+    px.gpu_fetch_all()
+    fingers = px.cuda_articulation_qpos.torch()[0, 7:]
+    assert torch.all(fingers > 0.015) and torch.all(fingers < 0.0215), fingers
+    steps = 100
+    for i in range(steps):
+        a = (i + 1) / steps
+        tq = q * (1 - a) + q_lift * a
+        tq[0, 7:] = -0.01
+        px.cuda_articulation_target_qpos.torch()[:] = tq
+        px.gpu_apply_articulation_target_position()
+        px.step(1)
+    px.step(50)
+    px.gpu_fetch_all()
+    cube = px.cuda_rigid_body_data.torch()[model.row_of("cube") * N]
+    assert cube[2].item() > 0.12, cube
