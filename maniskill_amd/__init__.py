@@ -10,3 +10,7 @@ __version__ = "0.1.0"
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
 PACKAGE_ASSET_DIR = os.path.join(PACKAGE_DIR, "assets")
 ASSET_DIR = PACKAGE_ASSET_DIR
+
+from .compat import install as _install_compat
+
+_install_compat()  # stand-ins for gymnasium / sapien / transforms3d only where the real module is absent

@@ -1,0 +1,574 @@
+"""BaseEnv: the env runtime that drives the native simulation core.
+
+API counterpart of mani_skill/envs/sapien_env.py (constructor :185-327, reset :776-879, RNG rules
+:881-917, step :943-972, substep loop `_step_action` :974-1025, get_info/get_obs/get_reward
+:483-521, :603-616, :1039-1049, state get/set :1153-1199). Differences by design:
+  * one batched scene, no per-env sub-scenes, always the tensor ("GPU sim") code path;
+  * when neither the task nor the controller needs per-substep hooks, the
+    `sim_freq // control_freq` substeps of one control step are issued as ONE native call;
+  * no renderer: obs modes are "state", "state_dict", "none".
+"""
+import copy
+import gc
+from functools import cached_property
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import gymnasium as gym
+import numpy as np
+import torch
+from gymnasium.vector.utils import batch_space
+
+from maniskill_amd.agents import REGISTERED_AGENTS
+from maniskill_amd.agents.base_agent import BaseAgent
+from maniskill_amd.envs.scene import ManiSkillScene
+from maniskill_amd.envs.utils.observations import parse_obs_mode_to_struct
+from maniskill_amd.envs.utils.randomization.batched_rng import BatchedRNG
+from maniskill_amd.envs.utils.system.backend import CPU_SIM_BACKENDS, parse_sim_and_render_backend
+from maniskill_amd.utils import common, gym_utils
+from maniskill_amd.utils.structs.actor import Actor
+from maniskill_amd.utils.structs.articulation import Articulation
+from maniskill_amd.utils.structs.pose import Pose
+from maniskill_amd.utils.structs.types import SimConfig, strict_from_dict
+
+
+class BaseEnv(gym.Env):
+    SUPPORTED_ROBOTS: List[Union[str, Tuple[str]]] = None
+    SUPPORTED_OBS_MODES = ("state", "state_dict", "none")
+    SUPPORTED_REWARD_MODES = ("normalized_dense", "dense", "sparse", "none")
+    SUPPORTED_RENDER_MODES = ("human", "rgb_array", "sensors", "all")
+    metadata = {"render_modes": SUPPORTED_RENDER_MODES}
+
+    scene: ManiSkillScene = None
+    agent: BaseAgent = None
+    _hidden_objects: List[Union[Actor, Articulation]] = []
+    _main_rng: np.random.RandomState = None
+    _batched_main_rng: BatchedRNG = None
+    _main_seed: List[int] = None
+    _episode_rng: np.random.RandomState = None
+    _batched_episode_rng: BatchedRNG = None
+    _episode_seed: np.ndarray = None
+    _batched_rng_backend = "numpy:random_state"
+    _enhanced_determinism: bool = False
+
+    def __init__(
+        self,
+        num_envs: int = 1,
+        obs_mode: Optional[str] = None,
+        reward_mode: Optional[str] = None,
+        control_mode: Optional[str] = None,
+        render_mode: Optional[str] = None,
+        shader_dir: Optional[str] = None,
+        enable_shadow: bool = False,
+        sensor_configs: Optional[dict] = None,
+        human_render_camera_configs: Optional[dict] = None,
+        viewer_camera_configs: Optional[dict] = None,
+        robot_uids: Union[str, BaseAgent, List[Union[str, BaseAgent]]] = None,
+        sim_config: Union[SimConfig, dict] = None,
+        reconfiguration_freq: Optional[int] = None,
+        sim_backend: str = "auto",
+        render_backend: str = "gpu",
+        parallel_in_single_scene: bool = False,
+        enhanced_determinism: bool = False,
+    ):
+        self._enhanced_determinism = enhanced_determinism
+        self.num_envs = num_envs
+        self.reconfiguration_freq = reconfiguration_freq if reconfiguration_freq is not None else 0
+        self._reconfig_counter = 0
+        self._parallel_in_single_scene = parallel_in_single_scene
+        self.robot_uids = robot_uids
+        if isinstance(robot_uids, tuple) and len(robot_uids) == 1:
+            self.robot_uids = robot_uids[0]
+
+        if sim_backend == "auto":
+            # the reference picks physx_cpu for num_envs == 1; this build has a single (HIP) backend
+            sim_backend = "physx_cuda"
+        self.backend = parse_sim_and_render_backend(sim_backend, render_backend)
+        self.device = self.backend.device
+        self._sim_device = self.backend.sim_device
+        if self.backend.sim_backend in CPU_SIM_BACKENDS and num_envs > 1:
+            from maniskill_amd.physx.system import _BACKENDS
+
+            if self.backend.sim_backend not in _BACKENDS:
+                raise RuntimeError(
+                    "Cannot set the sim backend to 'cpu' and have multiple environments. "
+                    "(this build ships no CPU physics backend at all; sim_backend must be physx_cuda)"
+                )
+
+        sim_config = {} if sim_config is None else (sim_config.dict() if isinstance(sim_config, SimConfig) else sim_config)
+        merged = self._default_sim_config.dict()
+        common.dict_merge(merged, sim_config)
+        self.sim_config: SimConfig = strict_from_dict(SimConfig, merged)
+
+        self._sim_freq = self.sim_config.sim_freq
+        self._control_freq = self.sim_config.control_freq
+        assert self._sim_freq % self._control_freq == 0, f"sim_freq({self._sim_freq}) is not divisible by control_freq({self._control_freq})."
+        self._sim_steps_per_control = self._sim_freq // self._control_freq
+
+        if obs_mode is None:
+            obs_mode = self.SUPPORTED_OBS_MODES[0]
+        if obs_mode not in self.SUPPORTED_OBS_MODES:
+            raise NotImplementedError(
+                f"Unsupported obs mode: {obs_mode}. Must be one of {self.SUPPORTED_OBS_MODES} (this build has no renderer: state observations only)"
+            )
+        self._obs_mode = obs_mode
+        self.obs_mode_struct = parse_obs_mode_to_struct(self._obs_mode)
+
+        if reward_mode is None:
+            reward_mode = self.SUPPORTED_REWARD_MODES[0]
+        if reward_mode not in self.SUPPORTED_REWARD_MODES:
+            raise NotImplementedError("Unsupported reward mode: {}".format(reward_mode))
+        self._reward_mode = reward_mode
+
+        self._control_mode = control_mode
+        if control_mode == "*":
+            raise NotImplementedError("Multiple controllers are not supported yet.")
+        self.render_mode = render_mode
+        self._sensors = dict()
+
+        self._main_seed = None
+        self._set_main_rng([2022 + i for i in range(self.num_envs)])
+        self._elapsed_steps = torch.zeros(self.num_envs, device=self.device, dtype=torch.int32)
+        obs, _ = self.reset(seed=[2022 + i for i in range(self.num_envs)], options=dict(reconfigure=True))
+
+        self._init_raw_obs = common.to_cpu_tensor(obs)
+        self._init_raw_state = common.to_cpu_tensor(self.get_state_dict())
+        if self.agent is not None:
+            self.action_space = self.agent.action_space
+            self.single_action_space = self.agent.single_action_space
+            self._orig_single_action_space = copy.deepcopy(self.single_action_space)
+        else:
+            self.action_space = None
+        self.single_observation_space
+        self.observation_space
+
+    # ------------------------------------------------------------------ spaces
+    def update_obs_space(self, obs):
+        self._init_raw_obs = obs
+        self.__dict__.pop("single_observation_space", None)
+        self.__dict__.pop("observation_space", None)
+        self.single_observation_space
+        self.observation_space
+
+    @cached_property
+    def single_observation_space(self) -> gym.Space:
+        return gym_utils.convert_observation_to_space(common.to_numpy(self._init_raw_obs), unbatched=True)
+
+    @cached_property
+    def observation_space(self) -> gym.Space:
+        return batch_space(self.single_observation_space, n=self.num_envs)
+
+    @property
+    def gpu_sim_enabled(self):
+        return self.scene.gpu_sim_enabled
+
+    @property
+    def _default_sim_config(self):
+        return SimConfig()
+
+    @property
+    def _default_sensor_configs(self):
+        return []
+
+    @property
+    def _default_human_render_camera_configs(self):
+        return []
+
+    # ------------------------------------------------------------------ loading
+    def _load_agent(self, options: dict, initial_agent_poses=None, build_separate: bool = False):
+        robot_uids = self.robot_uids
+        if not isinstance(initial_agent_poses, list):
+            initial_agent_poses = [initial_agent_poses]
+        if robot_uids == "none" or robot_uids == ("none",):
+            self.agent = None
+            return
+        agents = []
+        if robot_uids is not None:
+            if not isinstance(robot_uids, tuple):
+                robot_uids = [robot_uids]
+            if len(robot_uids) > 1:
+                raise NotImplementedError("multi-agent tasks are out of scope of this build (one articulation per env)")
+            for i, robot_uid in enumerate(robot_uids):
+                if isinstance(robot_uid, type) and issubclass(robot_uid, BaseAgent):
+                    agent_cls = robot_uid
+                else:
+                    if robot_uid not in REGISTERED_AGENTS:
+                        raise RuntimeError(
+                            f"Agent {robot_uid} not found in the dict of registered agents. If the id is not a typo then make sure to apply the @register_agent() decorator."
+                        )
+                    agent_cls = REGISTERED_AGENTS[robot_uid].agent_cls
+                agents.append(
+                    agent_cls(
+                        self.scene,
+                        self._control_freq,
+                        self._control_mode,
+                        agent_idx=None,
+                        initial_pose=initial_agent_poses[i] if initial_agent_poses is not None else None,
+                        build_separate=build_separate,
+                    )
+                )
+        self.agent = agents[0] if agents else None
+
+    def _load_scene(self, options: dict):
+        pass
+
+    def _load_lighting(self, options: dict):
+        pass
+
+    def _setup_sensors(self, options: dict):
+        """cameras degrade to "none" in this build"""
+        self._sensors = dict()
+        self._sensor_configs = dict()
+
+    def _after_reconfigure(self, options):
+        pass
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def sim_freq(self) -> int:
+        return self._sim_freq
+
+    @property
+    def control_freq(self):
+        return self._control_freq
+
+    @property
+    def sim_timestep(self):
+        return 1.0 / self._sim_freq
+
+    @property
+    def control_timestep(self):
+        return 1.0 / self._control_freq
+
+    @property
+    def control_mode(self) -> str:
+        return self.agent.control_mode
+
+    @property
+    def elapsed_steps(self) -> torch.Tensor:
+        return self._elapsed_steps
+
+    @property
+    def obs_mode(self) -> str:
+        return self._obs_mode
+
+    @property
+    def reward_mode(self):
+        return self._reward_mode
+
+    @property
+    def robot_link_names(self):
+        return self.agent.robot_link_names
+
+    # ------------------------------------------------------------------ observations / reward
+    def get_obs(self, info: Optional[Dict] = None):
+        if info is None:
+            info = self.get_info()
+        if self._obs_mode == "none":
+            return dict()
+        if self._obs_mode == "state":
+            return common.flatten_state_dict(self._get_obs_state_dict(info), use_torch=True, device=self.device)
+        if self._obs_mode == "state_dict":
+            # getters are views of the simulation buffers in this build: hand out copies
+            return common.torch_clone_dict(self._get_obs_state_dict(info))
+        raise NotImplementedError(self._obs_mode)
+
+    def _get_obs_state_dict(self, info: Dict):
+        return dict(agent=self._get_obs_agent(), extra=self._get_obs_extra(info))
+
+    def _get_obs_agent(self):
+        return self.agent.get_proprioception()
+
+    def _get_obs_extra(self, info: Dict):
+        return dict()
+
+    def get_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        if self._reward_mode == "sparse":
+            return self.compute_sparse_reward(obs=obs, action=action, info=info)
+        if self._reward_mode == "dense":
+            return self.compute_dense_reward(obs=obs, action=action, info=info)
+        if self._reward_mode == "normalized_dense":
+            return self.compute_normalized_dense_reward(obs=obs, action=action, info=info)
+        if self._reward_mode == "none":
+            return torch.zeros((self.num_envs,), dtype=torch.float, device=self.device)
+        raise NotImplementedError(self._reward_mode)
+
+    def compute_sparse_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        """+1 on success, -1 on fail, 0 otherwise (sapien_env.py:618-635)"""
+        if "success" in info:
+            if "fail" in info:
+                return info["success"].to(torch.float) - info["fail"].to(torch.float)
+            return info["success"]
+        if "fail" in info:
+            return -info["fail"]
+        return torch.zeros(self.num_envs, dtype=torch.float, device=self.device)
+
+    def compute_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        raise NotImplementedError()
+
+    def compute_normalized_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        raise NotImplementedError()
+
+    # ------------------------------------------------------------------ reconfigure / reset
+    def _reconfigure(self, options=dict()):
+        self._clear()
+        self._setup_scene()
+        self._load_agent(options)
+        self._load_scene(options)
+        self._load_lighting(options)
+        self.scene._setup(enable_gpu=True)
+        self._setup_sensors(options)
+        self._reconfig_counter = self.reconfiguration_freq
+
+    def _setup_scene(self):
+        self.scene = ManiSkillScene(
+            self.num_envs,
+            sim_config=self.sim_config,
+            device=self.device,
+            backend_name=self.backend.sim_backend,
+            parallel_in_single_scene=self._parallel_in_single_scene,
+        )
+        self.scene.px.timestep = 1.0 / self._sim_freq
+
+    def _clear(self):
+        if self.scene is not None:
+            self.scene.px.close()
+        self.agent = None
+        self._sensors = dict()
+        self.scene = None
+        self._hidden_objects = []
+        gc.collect()
+
+    def close(self):
+        self._clear()
+
+    def reset(self, seed: Union[None, int, List[int]] = None, options: Union[None, dict] = None):
+        if options is None:
+            options = dict()
+        reconfigure = options.get("reconfigure", False)
+        reconfigure = reconfigure or (self._reconfig_counter == 0 and self.reconfiguration_freq != 0)
+        partial = "env_idx" in options
+        if partial:
+            env_idx = common.to_tensor(options["env_idx"], device=self.device).long()
+            if len(env_idx) != self.num_envs and reconfigure:
+                raise RuntimeError("Cannot do a partial reset and reconfigure the environment. You must do one or the other.")
+        else:
+            env_idx = torch.arange(0, self.num_envs, device=self.device)
+
+        self._set_main_rng(seed)
+        if reconfigure:
+            self._set_episode_rng(seed if seed is not None else self._batched_main_rng.randint(2**31), env_idx)
+            with torch.random.fork_rng():
+                torch.manual_seed(seed=int(self._episode_seed[0]))
+                self._reconfigure(options)
+                self._after_reconfigure(options)
+            self._set_episode_rng(self._episode_seed, env_idx)
+        else:
+            self._set_episode_rng(seed, env_idx)
+
+        self.scene._set_reset_idx(env_idx if partial else None)
+        self._elapsed_steps[env_idx] = 0
+        self._clear_sim_state()
+        if self.reconfiguration_freq != 0:
+            self._reconfig_counter -= 1
+        if self.agent is not None:
+            self.agent.reset()
+        if seed is not None or self._enhanced_determinism:
+            with torch.random.fork_rng():
+                torch.manual_seed(int(self._episode_seed[0]))
+                self._initialize_episode(env_idx, options)
+        else:
+            self._initialize_episode(env_idx, options)
+        controller_mask = (self.scene._reset_mask, self.scene._reset_mask_all)
+        self.scene._set_reset_idx(None)
+        self.scene._gpu_apply_all()
+        self.scene.px.gpu_update_articulation_kinematics()
+        self.scene._gpu_fetch_all()
+
+        if self.agent is not None:
+            # the reference resets controllers under the all-ones mask (sapien_env.py:857-871)
+            self.agent.controller.reset()
+
+        info = self.get_info()
+        obs = self.get_obs(info)
+        info["reconfigure"] = reconfigure
+        return obs, info
+
+    def _set_main_rng(self, seed):
+        if seed is None:
+            if self._main_seed is not None:
+                return
+            seed = np.random.RandomState().randint(2**31, size=(self.num_envs,))
+        if not np.iterable(seed):
+            seed = [seed]
+        self._main_seed = list(seed)
+        self._main_rng = np.random.RandomState(self._main_seed[0])
+        if len(self._main_seed) == 1 and self.num_envs > 1:
+            self._main_seed = self._main_seed + np.random.RandomState(self._main_seed[0]).randint(2**31, size=(self.num_envs - 1,)).tolist()
+        self._batched_main_rng = BatchedRNG.from_seeds(self._main_seed, backend=self._batched_rng_backend)
+
+    def _set_episode_rng(self, seed, env_idx: torch.Tensor):
+        if seed is not None or self._enhanced_determinism:
+            env_idx = common.to_numpy(env_idx)
+            if seed is None:
+                self._episode_seed[env_idx] = self._batched_main_rng[env_idx].randint(2**31)
+            else:
+                if not np.iterable(seed):
+                    seed = [seed]
+                self._episode_seed = common.to_numpy(seed, dtype=np.int64)
+                if len(self._episode_seed) == 1 and self.num_envs > 1:
+                    self._episode_seed = np.concatenate(
+                        (self._episode_seed, np.random.RandomState(self._episode_seed[0]).randint(2**31, size=(self.num_envs - 1,)))
+                    )
+            if seed is not None or self._batched_episode_rng is None:
+                self._batched_episode_rng = BatchedRNG.from_seeds(self._episode_seed, backend=self._batched_rng_backend)
+            else:
+                self._batched_episode_rng[env_idx] = BatchedRNG.from_seeds(self._episode_seed[env_idx], backend=self._batched_rng_backend)
+            self._episode_rng = self._batched_episode_rng[0]
+
+    def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
+        pass
+
+    def _clear_sim_state(self):
+        """zero velocities of the envs being reset (sapien_env.py:924-937)"""
+        for actor in self.scene.actors.values():
+            if actor.px_body_type == "dynamic":
+                actor.set_linear_velocity(torch.zeros(3, device=self.device))
+                actor.set_angular_velocity(torch.zeros(3, device=self.device))
+        for art in self.scene.articulations.values():
+            art.set_qvel(torch.zeros(art.max_dof, device=self.device))
+            art.set_root_linear_velocity(torch.zeros(3, device=self.device))
+            art.set_root_angular_velocity(torch.zeros(3, device=self.device))
+        self.scene._gpu_apply_all()
+        self.scene._gpu_fetch_all()
+
+    # ------------------------------------------------------------------ step
+    def step(self, action: Union[None, np.ndarray, torch.Tensor, Dict]):
+        action = self._step_action(action)
+        self._elapsed_steps += 1
+        info = self.get_info()
+        obs = self.get_obs(info)
+        reward = self.get_reward(obs=obs, action=action, info=info)
+        if "success" in info:
+            terminated = torch.logical_or(info["success"], info["fail"]) if "fail" in info else info["success"].clone()
+        elif "fail" in info:
+            terminated = info["fail"].clone()
+        else:
+            terminated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        return obs, reward, terminated, torch.zeros(self.num_envs, dtype=torch.bool, device=self.device), info
+
+    def _substep_hooks_overridden(self) -> bool:
+        cls = type(self)
+        return cls._before_simulation_step is not BaseEnv._before_simulation_step or cls._after_simulation_step is not BaseEnv._after_simulation_step
+
+    def _step_action(self, action):
+        set_action = False
+        unbatched = False
+        if action is None:
+            pass
+        elif isinstance(action, (np.ndarray, torch.Tensor)):
+            action = common.to_tensor(action, device=self.device)
+            if action.shape == self._orig_single_action_space.shape:
+                unbatched = True
+            set_action = True
+        elif isinstance(action, dict):
+            if "control_mode" in action:
+                if action["control_mode"] != self.agent.control_mode:
+                    self.agent.set_control_mode(action["control_mode"])
+                    self.agent.controller.reset()
+                action = common.to_tensor(action["action"], device=self.device)
+                if action.shape == self._orig_single_action_space.shape:
+                    unbatched = True
+            else:
+                raise NotImplementedError("dict actions are for multi-agent tasks, which this build does not include")
+            set_action = True
+        else:
+            raise TypeError(type(action))
+
+        if set_action:
+            if self.num_envs == 1 and unbatched:
+                action = common.batch(action)
+            self.agent.set_action(action)
+            self.scene.px.gpu_apply_articulation_target_position()
+            self.scene.px.gpu_apply_articulation_target_velocity()
+        self._before_control_step()
+        per_substep = self._substep_hooks_overridden() or (
+            self.agent is not None and getattr(self.agent.controller, "needs_per_substep_update", False)
+        )
+        if per_substep:
+            for _ in range(self._sim_steps_per_control):
+                if self.agent is not None:
+                    self.agent.before_simulation_step()
+                self._before_simulation_step()
+                self.scene.step()
+                self._after_simulation_step()
+        else:
+            # fused substep loop (sapien_env.py:1016-1021 issues these one px.step() at a time)
+            self.scene.step(self._sim_steps_per_control)
+        self._after_control_step()
+        self.scene._gpu_fetch_all()
+        return action
+
+    def evaluate(self) -> dict:
+        return dict()
+
+    def get_info(self) -> dict:
+        info = dict(elapsed_steps=self._elapsed_steps.clone())
+        info.update(self.evaluate())
+        return info
+
+    def _before_control_step(self):
+        pass
+
+    def _after_control_step(self):
+        pass
+
+    def _before_simulation_step(self):
+        pass
+
+    def _after_simulation_step(self):
+        pass
+
+    # ------------------------------------------------------------------ state (sapien_env.py:1153-1199)
+    def add_to_state_dict_registry(self, obj):
+        self.scene.add_to_state_dict_registry(obj)
+
+    def remove_from_state_dict_registry(self, obj):
+        self.scene.remove_from_state_dict_registry(obj)
+
+    def get_state_dict(self):
+        return self.scene.get_sim_state()
+
+    def get_state(self):
+        return common.flatten_state_dict(self.get_state_dict(), use_torch=True)
+
+    def set_state_dict(self, state: Dict, env_idx: torch.Tensor = None):
+        self.scene.set_sim_state(state, env_idx)
+        self.scene._gpu_apply_all()
+        self.scene.px.gpu_update_articulation_kinematics()
+        self.scene._gpu_fetch_all()
+
+    def set_state(self, state, env_idx: torch.Tensor = None):
+        state = common.to_tensor(state, device=self.device)
+        sd = dict(actors=dict(), articulations=dict())
+        start = 0
+        for actor_id in self._init_raw_state.get("actors", {}).keys():
+            sd["actors"][actor_id] = state[:, start : start + 13]
+            start += 13
+        for art_id, art_state in self._init_raw_state.get("articulations", {}).items():
+            size = art_state.shape[-1]
+            sd["articulations"][art_id] = state[:, start : start + size]
+            start += size
+        self.set_state_dict(sd, env_idx)
+
+    # ------------------------------------------------------------------ misc
+    def render(self):
+        raise NotImplementedError("rendering is out of scope of this build (state observations only)")
+
+    def print_sim_details(self):
+        print("# -------------------------------------------------------------------------- #")
+        print(f"Task ID: {getattr(self.spec, 'id', type(self).__name__)}, {self.num_envs} parallel environments, sim_backend={self.backend.sim_backend}")
+        print(f"obs_mode={self.obs_mode}, control_mode={self.control_mode}")
+        print(f"sim_freq={self.sim_freq}, control_freq={self.control_freq}")
+        print(f"observation space: {self.observation_space}")
+        print(f"(single) action space: {self.single_action_space}")
+        print("# -------------------------------------------------------------------------- #")

@@ -1,0 +1,274 @@
+"""ManiSkillScene: owns the `px` system, the actor / articulation registry and the partial-reset mask.
+
+Counterpart of mani_skill/envs/scene.py (step :374-375, contact queries :736-796, state registry
+:819-892, _setup :897-939, _gpu_apply_all :941-957, _gpu_fetch_all :959-977). Rendering, cameras,
+lights and the viewer are out of scope (state observations only): the light / camera calls are
+accepted and ignored. There are no sub-scenes: every env shares one compiled model and has its own
+coordinate frame, so no spacing offsets exist.
+"""
+import contextlib
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from maniskill_amd.model.compile import SceneModelBuilder
+from maniskill_amd.physx.system import MssimSystem
+from maniskill_amd.utils import common
+from maniskill_amd.utils.building.actor_builder import ActorBuilder, PhysxMaterial
+from maniskill_amd.utils.building.urdf_loader import URDFLoader
+from maniskill_amd.utils.structs.actor import Actor, Link
+from maniskill_amd.utils.structs.articulation import Articulation
+from maniskill_amd.utils.structs.types import SimConfig
+
+
+class ManiSkillScene:
+    def __init__(self, num_envs: int, sim_config: SimConfig = None, device="cuda", backend_name: str = "physx_cuda", parallel_in_single_scene: bool = False):
+        self.num_envs = int(num_envs)
+        self.sim_config = sim_config if sim_config is not None else SimConfig()
+        self.device = torch.device(device)
+        self.parallel_in_single_scene = parallel_in_single_scene
+        self.px = MssimSystem(device=self.device, backend=backend_name)
+        self.actors: Dict[str, Actor] = {}
+        self.articulations: Dict[str, Articulation] = {}
+        self.state_dict_registry = _Registry()
+        self.sensors = {}
+        self.human_render_cameras = {}
+        self._builder = SceneModelBuilder()
+        self._gpu_sim_initialized = False
+        self._needs_fetch = False
+        self._all_env_idx = torch.arange(self.num_envs, device=self.device)
+        self._reset_mask_t = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
+        self._reset_mask_all = True
+        m = self.sim_config.default_materials_config
+        self.default_material = PhysxMaterial(m.static_friction, m.dynamic_friction, m.restitution)
+        self._pair_queries = {}
+        self._body_queries = {}
+        self.sub_scenes = [None] * self.num_envs  # API placeholder: there are no per-env scene objects
+
+    # ------------------------------------------------------------------ reset mask
+    @property
+    def _reset_mask(self) -> torch.Tensor:
+        return self._reset_mask_t
+
+    @_reset_mask.setter
+    def _reset_mask(self, mask: torch.Tensor):
+        """external assignment (reference style); costs one host sync to learn whether it is all-true"""
+        self._reset_mask_t = mask.to(self.device).bool()
+        self._reset_mask_all = bool(self._reset_mask_t.all())
+
+    def _set_reset_idx(self, env_idx: Optional[torch.Tensor]):
+        """sync-free form used by BaseEnv: None = all envs"""
+        if env_idx is None or len(env_idx) == self.num_envs:
+            self._reset_mask_t = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
+            self._reset_mask_all = True
+        else:
+            m = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+            m[env_idx] = True
+            self._reset_mask_t = m
+            self._reset_mask_all = False
+
+    @contextlib.contextmanager
+    def _narrow_reset_mask(self, env_idx):
+        """actor.py:142-160 / articulation.py:281-303: set_state(env_idx) temporarily narrows the mask"""
+        if env_idx is None:
+            yield
+            return
+        prev, prev_all = self._reset_mask_t, self._reset_mask_all
+        self._set_reset_idx(common.to_tensor(env_idx, device=self.device).long())
+        try:
+            yield
+        finally:
+            self._reset_mask_t, self._reset_mask_all = prev, prev_all
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def gpu_sim_enabled(self) -> bool:
+        return True
+
+    @property
+    def timestep(self) -> float:
+        return self.px.timestep
+
+    @timestep.setter
+    def timestep(self, dt):
+        self.px.timestep = dt
+
+    # ------------------------------------------------------------------ builders
+    def create_actor_builder(self) -> ActorBuilder:
+        return ActorBuilder(self)
+
+    def create_urdf_loader(self) -> URDFLoader:
+        return URDFLoader(self)
+
+    def create_articulation_builder(self):
+        raise NotImplementedError("programmatic articulation building is not available; load a URDF with create_urdf_loader()")
+
+    def create_mjcf_loader(self):
+        raise NotImplementedError("MJCF import is out of scope of this build (SURVEY.md 2, row 5b)")
+
+    def _register_actor(self, actor: Actor, record):
+        assert not self._gpu_sim_initialized, "actors must be built before the simulation is initialised"
+        self._builder.add_actor(record)
+        self.actors[actor.name] = actor
+        self.add_to_state_dict_registry(actor)
+
+    def _register_articulation(self, art: Articulation, record):
+        assert not self._gpu_sim_initialized, "articulations must be built before the simulation is initialised"
+        self._builder.set_articulation(record)
+        self.articulations[art.name] = art
+        self.add_to_state_dict_registry(art)
+
+    def _set_collision_group_bit(self, actor_name, group, bit_idx, bit):
+        assert not self._gpu_sim_initialized, "collision groups must be set before the simulation is initialised"
+        for rec in self._builder.actors:
+            if rec.name == actor_name:
+                for s in rec.shapes:
+                    g = list(s.collision_groups)
+                    g[group] = (g[group] & ~(1 << bit_idx)) | (int(bool(bit)) << bit_idx)
+                    s.collision_groups = tuple(g)
+
+    def _set_collision_group(self, actor_name, group, value):
+        assert not self._gpu_sim_initialized, "collision groups must be set before the simulation is initialised"
+        for rec in self._builder.actors:
+            if rec.name == actor_name:
+                for s in rec.shapes:
+                    g = list(s.collision_groups)
+                    g[group] = int(value)
+                    s.collision_groups = tuple(g)
+
+    # ------------------------------------------------------------------ setup / stepping
+    def _setup(self, enable_gpu: bool = True):
+        """px.gpu_init + initial apply/fetch (scene.py:897-939)"""
+        sc = self.sim_config.scene_config
+        model = self._builder.compile(
+            timestep=self.px.timestep,
+            gravity=tuple(float(g) for g in np.asarray(sc.gravity)),
+            contact_offset=sc.contact_offset,
+            rest_offset=sc.rest_offset,
+            bounce_threshold=sc.bounce_threshold,
+            position_iterations=sc.solver_position_iterations,
+            velocity_iterations=sc.solver_velocity_iterations,
+            sleep_threshold=sc.sleep_threshold,
+        )
+        self.px.gpu_init(model, self.num_envs)
+        self.model = model
+        for name, actor in self.actors.items():
+            row = model.row_of(name)
+            actor._body_row = row if row >= 0 else None
+        for art in self.articulations.values():
+            assert [l.name for l in art.links] == model.link_names
+        self._gpu_sim_initialized = True
+        # per-env initial poses given at build time
+        for actor in self.actors.values():
+            if actor._body_row is not None and len(actor.initial_pose) == self.num_envs and self.num_envs > 1:
+                actor._rows()[:, :7] = actor.initial_pose.raw_pose.to(self.device)
+        for art in self.articulations.values():
+            if len(art.initial_pose) == self.num_envs and self.num_envs > 1:
+                art.root._rows()[:, :7] = art.initial_pose.raw_pose.to(self.device)
+        self.px.gpu_apply_all()
+        self.px.gpu_update_articulation_kinematics()
+        self._gpu_fetch_all()
+
+    def step(self, n_substeps: int = 1):
+        self.px.step(n_substeps)
+        self._needs_fetch = True
+
+    def _gpu_apply_all(self):
+        """scene.py:941-957 (8 apply kinds; here one fused native call)"""
+        assert not self._needs_fetch, "Once _gpu_apply_all is called, you must call _gpu_fetch_all before calling _gpu_apply_all again"
+        self.px.gpu_apply_all()
+
+    def _gpu_fetch_all(self):
+        """scene.py:959-977"""
+        self.px.gpu_fetch_all()
+        self._needs_fetch = False
+
+    # ------------------------------------------------------------------ contacts
+    def _row_of(self, obj: Union[Actor, Link]) -> int:
+        return -1 if obj._body_row is None else obj._body_row
+
+    def _pair_query(self, row_a: int, row_b: int):
+        key = (row_a, row_b)
+        if key not in self._pair_queries:
+            self._pair_queries[key] = self.px.gpu_create_contact_pair_impulse_query([key])
+        return self._pair_queries[key]
+
+    def _body_query(self, rows):
+        key = rows if isinstance(rows, tuple) else (rows,)
+        if key not in self._body_queries:
+            self._body_queries[key] = self.px.gpu_create_contact_body_impulse_query(list(key))
+        return self._body_queries[key]
+
+    def get_pairwise_contact_impulses(self, obj1: Union[Actor, Link], obj2: Union[Actor, Link]) -> torch.Tensor:
+        """[N,3] impulse on obj1 from obj2 during the last substep (scene.py:736-782)"""
+        q = self._pair_query(self._row_of(obj1), self._row_of(obj2))
+        self.px.gpu_query_contact_pair_impulses(q)
+        return q.cuda_impulses.torch().clone()
+
+    def get_pairwise_contact_forces(self, obj1, obj2) -> torch.Tensor:
+        return self.get_pairwise_contact_impulses(obj1, obj2) / self.px.timestep
+
+    # ------------------------------------------------------------------ state registry (scene.py:819-892)
+    def add_to_state_dict_registry(self, obj: Union[Actor, Articulation]):
+        self.state_dict_registry.add(obj)
+
+    def remove_from_state_dict_registry(self, obj: Union[Actor, Articulation]):
+        self.state_dict_registry.remove(obj)
+
+    def get_sim_state(self) -> dict:
+        state = dict(actors=dict(), articulations=dict())
+        for actor in self.state_dict_registry.actors.values():
+            if actor.px_body_type == "static":
+                continue
+            state["actors"][actor.name] = actor.get_state().clone()
+        for art in self.state_dict_registry.articulations.values():
+            state["articulations"][art.name] = art.get_state().clone()
+        if len(state["actors"]) == 0:
+            del state["actors"]
+        if len(state["articulations"]) == 0:
+            del state["articulations"]
+        return state
+
+    def set_sim_state(self, state: dict, env_idx: torch.Tensor = None):
+        with self._narrow_reset_mask(env_idx):
+            for name, s in state.get("actors", {}).items():
+                if name in self.actors:
+                    self.actors[name].set_state(s)
+            for name, s in state.get("articulations", {}).items():
+                if name in self.articulations:
+                    self.articulations[name].set_state(s)
+
+    # ------------------------------------------------------------------ render-side no-ops
+    def set_ambient_light(self, *a, **kw):
+        pass
+
+    def add_directional_light(self, *a, **kw):
+        pass
+
+    def add_point_light(self, *a, **kw):
+        pass
+
+    def update_render(self, *a, **kw):
+        pass
+
+    def get_sensor_images(self, *a, **kw):
+        return {}
+
+    def get_all_actors(self):
+        return list(self.actors.values())
+
+    def get_all_articulations(self):
+        return list(self.articulations.values())
+
+
+class _Registry:
+    def __init__(self):
+        self.actors: Dict[str, Actor] = {}
+        self.articulations: Dict[str, Articulation] = {}
+
+    def add(self, obj):
+        (self.actors if isinstance(obj, Actor) else self.articulations)[obj.name] = obj
+
+    def remove(self, obj):
+        (self.actors if isinstance(obj, Actor) else self.articulations).pop(obj.name, None)

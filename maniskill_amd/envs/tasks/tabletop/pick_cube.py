@@ -1,0 +1,106 @@
+"""PickCube-v1 (task definition restated from mani_skill/envs/tasks/tabletop/pick_cube.py:18-158):
+grasp a 4 cm cube and bring it to a goal position; success = cube within 2.5 cm of the goal and the
+robot static. Same scene content, randomisation, observation keys, reward shaping and limits."""
+from typing import Any, Dict
+
+import numpy as np
+import sapien
+import torch
+
+import maniskill_amd.envs.utils.randomization as randomization
+from maniskill_amd.envs.sapien_env import BaseEnv
+from maniskill_amd.sensors.camera import CameraConfig
+from maniskill_amd.utils import sapien_utils
+from maniskill_amd.utils.building import actors
+from maniskill_amd.utils.registration import register_env
+from maniskill_amd.utils.scene_builder.table import TableSceneBuilder
+from maniskill_amd.utils.structs.pose import Pose
+
+
+@register_env("PickCube-v1", max_episode_steps=50)
+class PickCubeEnv(BaseEnv):
+    SUPPORTED_ROBOTS = ["panda", "fetch", "xarm6_robotiq"]
+    cube_half_size = 0.02
+    goal_thresh = 0.025
+
+    def __init__(self, *args, robot_uids="panda", robot_init_qpos_noise=0.02, **kwargs):
+        self.robot_init_qpos_noise = robot_init_qpos_noise
+        super().__init__(*args, robot_uids=robot_uids, **kwargs)
+
+    @property
+    def _default_sensor_configs(self):
+        pose = sapien_utils.look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
+        return [CameraConfig("base_camera", pose, 128, 128, np.pi / 2, 0.01, 100)]
+
+    @property
+    def _default_human_render_camera_configs(self):
+        pose = sapien_utils.look_at([0.6, 0.7, 0.6], [0.0, 0.0, 0.35])
+        return CameraConfig("render_camera", pose, 512, 512, 1, 0.01, 100)
+
+    def _load_agent(self, options: dict):
+        super()._load_agent(options, sapien.Pose(p=[-0.615, 0, 0]))
+
+    def _load_scene(self, options: dict):
+        self.table_scene = TableSceneBuilder(self, robot_init_qpos_noise=self.robot_init_qpos_noise)
+        self.table_scene.build()
+        self.cube = actors.build_cube(
+            self.scene, half_size=self.cube_half_size, color=[1, 0, 0, 1], name="cube", initial_pose=sapien.Pose(p=[0, 0, self.cube_half_size])
+        )
+        self.goal_site = actors.build_sphere(
+            self.scene, radius=self.goal_thresh, color=[0, 1, 0, 1], name="goal_site", body_type="kinematic", add_collision=False,
+            initial_pose=sapien.Pose(),
+        )
+        self._hidden_objects.append(self.goal_site)
+
+    def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
+        with torch.device(self.device):
+            b = len(env_idx)
+            self.table_scene.initialize(env_idx)
+            xyz = torch.zeros((b, 3))
+            xyz[:, :2] = torch.rand((b, 2)) * 0.2 - 0.1
+            xyz[:, 2] = self.cube_half_size
+            qs = randomization.random_quaternions(b, lock_x=True, lock_y=True)
+            self.cube.set_pose(Pose.create_from_pq(xyz, qs))
+
+            goal_xyz = torch.zeros((b, 3))
+            goal_xyz[:, :2] = torch.rand((b, 2)) * 0.2 - 0.1
+            goal_xyz[:, 2] = torch.rand((b)) * 0.3 + xyz[:, 2]
+            self.goal_site.set_pose(Pose.create_from_pq(goal_xyz))
+
+    def _get_obs_extra(self, info: Dict):
+        obs = dict(is_grasped=info["is_grasped"], tcp_pose=self.agent.tcp.pose.raw_pose, goal_pos=self.goal_site.pose.p)
+        if "state" in self.obs_mode:
+            obs.update(
+                obj_pose=self.cube.pose.raw_pose,
+                tcp_to_obj_pos=self.cube.pose.p - self.agent.tcp.pose.p,
+                obj_to_goal_pos=self.goal_site.pose.p - self.cube.pose.p,
+            )
+        return obs
+
+    def evaluate(self):
+        is_obj_placed = torch.linalg.norm(self.goal_site.pose.p - self.cube.pose.p, axis=1) <= self.goal_thresh
+        is_grasped = self.agent.is_grasping(self.cube)
+        is_robot_static = self.agent.is_static(0.2)
+        return {
+            "success": is_obj_placed & is_robot_static,
+            "is_obj_placed": is_obj_placed,
+            "is_robot_static": is_robot_static,
+            "is_grasped": is_grasped,
+        }
+
+    def compute_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        tcp_to_obj_dist = torch.linalg.norm(self.cube.pose.p - self.agent.tcp.pose.p, axis=1)
+        reward = 1 - torch.tanh(5 * tcp_to_obj_dist)
+        is_grasped = info["is_grasped"]
+        reward += is_grasped
+        obj_to_goal_dist = torch.linalg.norm(self.goal_site.pose.p - self.cube.pose.p, axis=1)
+        reward += (1 - torch.tanh(5 * obj_to_goal_dist)) * is_grasped
+        qvel = self.agent.robot.get_qvel()
+        if self.robot_uids == "panda":
+            qvel = qvel[..., :-2]
+        reward += (1 - torch.tanh(5 * torch.linalg.norm(qvel, axis=1))) * info["is_obj_placed"]
+        reward[info["success"]] = 5
+        return reward
+
+    def compute_normalized_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        return self.compute_dense_reward(obs=obs, action=action, info=info) / 5

@@ -1,0 +1,3 @@
+from .batched_rng import BatchedRNG
+from .pose import random_quaternions
+from .samplers import UniformPlacementSampler

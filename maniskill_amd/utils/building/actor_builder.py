@@ -1,0 +1,190 @@
+"""ActorBuilder: records collision shapes and registers ONE batched actor record with the scene.
+
+Counterpart of mani_skill/utils/building/actor_builder.py:31-260 (which subclasses
+`sapien.ActorBuilder` and builds one entity per sub-scene). Visual shapes are accepted and
+dropped: this build has no renderer (state observations only).
+"""
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from maniskill_amd.model import geom, mesh
+from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+from maniskill_amd.utils import common
+from maniskill_amd.utils.structs.actor import Actor
+from maniskill_amd.utils.structs.pose import Pose, to_sapien_pose
+
+
+class PhysxMaterial:
+    def __init__(self, static_friction=0.3, dynamic_friction=0.3, restitution=0.0):
+        self.static_friction, self.dynamic_friction, self.restitution = float(static_friction), float(dynamic_friction), float(restitution)
+
+
+def _pose7(pose) -> np.ndarray:
+    if pose is None:
+        return geom.pose()
+    if isinstance(pose, Pose):
+        raw = common.to_numpy(pose.raw_pose)
+        assert raw.shape[0] == 1, "shape poses must be unbatched"
+        return geom.pose(raw[0, :3], raw[0, 3:])
+    return geom.pose(np.asarray(pose.p, dtype=np.float64), np.asarray(pose.q, dtype=np.float64))
+
+
+class ActorBuilder:
+    def __init__(self, scene=None):
+        self.scene = scene
+        self.name: Optional[str] = None
+        self.initial_pose = None
+        self.physx_body_type = "dynamic"
+        self.collision_groups = [1, 1, 0, 0]
+        self.shapes: List[ShapeRecord] = []
+        self.scene_idxs = None
+        self._mass = None
+        self._cmass_local_pose = None
+        self._inertia = None
+        self.linear_damping = 0.0
+        self.angular_damping = 0.0
+
+    # -- configuration ------------------------------------------------------------
+    def set_scene(self, scene):
+        self.scene = scene
+        return self
+
+    def set_name(self, name: str):
+        self.name = name
+        return self
+
+    def set_initial_pose(self, pose):
+        self.initial_pose = pose
+        return self
+
+    def set_physx_body_type(self, t: str):
+        assert t in ("dynamic", "kinematic", "static")
+        self.physx_body_type = t
+        return self
+
+    def set_scene_idxs(self, scene_idxs=None):
+        if scene_idxs is not None and len(scene_idxs) != self.scene.num_envs:
+            raise NotImplementedError(
+                "per-env distinct object sets (scene_idxs subsets / Actor.merge) are not supported by this core yet "
+                "(SURVEY.md 8f rank 4)"
+            )
+        self.scene_idxs = scene_idxs
+        return self
+
+    def set_collision_groups(self, groups):
+        self.collision_groups = list(groups)
+        return self
+
+    def set_mass_and_inertia(self, mass, cmass_local_pose, inertia):
+        self._mass, self._cmass_local_pose, self._inertia = float(mass), cmass_local_pose, np.asarray(inertia, dtype=np.float64)
+        return self
+
+    def _material(self, material):
+        m = material if material is not None else self.scene.default_material
+        return float(m.static_friction), float(m.dynamic_friction), float(m.restitution)
+
+    def _add(self, type_, pose, material, density, patch_radius, min_patch_radius, **kw):
+        sf, df, rest = self._material(material)
+        self.shapes.append(
+            ShapeRecord(
+                type_,
+                _pose7(pose),
+                static_friction=sf,
+                dynamic_friction=df,
+                restitution=rest,
+                patch_radius=patch_radius,
+                min_patch_radius=min_patch_radius,
+                density=density,
+                **kw,
+            )
+        )
+        return self
+
+    # -- collision shapes (sapien.ActorBuilder names) ------------------------------------
+    def add_plane_collision(self, pose=None, material=None, patch_radius=0, min_patch_radius=0):
+        return self._add("plane", pose, material, 0.0, patch_radius, min_patch_radius)
+
+    def add_box_collision(self, pose=None, half_size=(1, 1, 1), material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        return self._add("box", pose, material, density, patch_radius, min_patch_radius, half_size=np.asarray(half_size, dtype=np.float64))
+
+    def add_sphere_collision(self, pose=None, radius=1, material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        return self._add("sphere", pose, material, density, patch_radius, min_patch_radius, radius=float(radius))
+
+    def add_capsule_collision(self, pose=None, radius=1, half_length=1, material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        return self._add("capsule", pose, material, density, patch_radius, min_patch_radius, radius=float(radius), half_length=float(half_length))
+
+    def add_cylinder_collision(self, pose=None, radius=1, half_length=1, material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        return self._add("cylinder", pose, material, density, patch_radius, min_patch_radius, radius=float(radius), half_length=float(half_length))
+
+    def add_convex_collision_from_file(self, filename, pose=None, scale=(1, 1, 1), material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        verts = mesh.cook_convex_mesh(str(filename), tuple(scale))
+        return self._add("convex", pose, material, density, patch_radius, min_patch_radius, vertices=verts)
+
+    def add_multiple_convex_collisions_from_file(self, *a, **kw):
+        raise NotImplementedError("convex decomposition is not available in this build (SURVEY.md 8f rank 4)")
+
+    def add_nonconvex_collision_from_file(self, *a, **kw):
+        raise NotImplementedError("triangle-mesh collision is not available in this build (SURVEY.md 8f rank 4)")
+
+    # -- visuals: accepted, ignored -------------------------------------------------------
+    def add_box_visual(self, *a, **kw):
+        return self
+
+    def add_sphere_visual(self, *a, **kw):
+        return self
+
+    def add_capsule_visual(self, *a, **kw):
+        return self
+
+    def add_cylinder_visual(self, *a, **kw):
+        return self
+
+    def add_visual_from_file(self, *a, **kw):
+        return self
+
+    # -- build ---------------------------------------------------------------------------
+    def build(self, name=None) -> Actor:
+        if name is not None:
+            self.set_name(name)
+        assert self.name is not None and self.name != "" and self.name not in self.scene.actors, (
+            "built actors in ManiSkill must have unique names and cannot be None or empty strings"
+        )
+        for s in self.shapes:
+            s.collision_groups = tuple(self.collision_groups)
+        init = Pose.create(self.initial_pose if self.initial_pose is not None else Pose.create_from_pq(), device=self.scene.device)
+        raw = common.to_numpy(init.raw_pose)
+        if raw.shape[0] != 1:
+            # per-env initial poses: the model keeps env 0's pose; the rest are written after gpu_init
+            pass
+        rec = ActorRecord(
+            self.name,
+            self.physx_body_type,
+            list(self.shapes),
+            initial_pose=geom.pose(raw[0, :3], raw[0, 3:]),
+            linear_damping=self.linear_damping,
+            angular_damping=self.angular_damping,
+        )
+        if self._mass is not None:
+            rec.mass = self._mass
+            rec.com = None if self._cmass_local_pose is None else np.asarray(self._cmass_local_pose.p, dtype=np.float64)
+            rec.inertia = np.diag(self._inertia) if self._inertia is not None and np.ndim(self._inertia) == 1 else self._inertia
+        mass = 0.0
+        if self.physx_body_type == "dynamic":
+            mass = rec.mass if rec.mass is not None else sum(s.mass_properties()[0] for s in self.shapes)
+        actor = Actor(self.scene, self.name, self.physx_body_type, init, has_collision_shapes=len(self.shapes) > 0, mass=mass)
+        self.scene._register_actor(actor, rec)
+        return actor
+
+    def build_kinematic(self, name=None) -> Actor:
+        self.set_physx_body_type("kinematic")
+        return self.build(name)
+
+    def build_static(self, name=None) -> Actor:
+        self.set_physx_body_type("static")
+        return self.build(name)
+
+    def build_dynamic(self, name=None) -> Actor:
+        self.set_physx_body_type("dynamic")
+        return self.build(name)

@@ -1,0 +1,287 @@
+"""Batched rigid actors and articulation links as views over `px.cuda_rigid_body_data`.
+
+API counterpart of mani_skill/utils/structs/{base,actor,link}.py. The reference keeps one
+`sapien.Entity` per sub-scene and gathers rows by `_body_data_index`; here one record describes
+the body in all envs and its rows are one contiguous slice (body-major rows), so getters are
+zero-copy views. Setters keep the reference's partial-reset contract: only rows selected by
+`scene._reset_mask` are written (actor.py:378-380, link.py:255-257, base.py:369-374, 442-447).
+Velocity columns are lin 7:10 / ang 10:13 for all rows (documented deviation).
+"""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from maniskill_amd.utils import common
+from maniskill_amd.utils.structs.pose import Pose, vectorize_pose
+
+
+class _RigidBase:
+    """state shared by Actor and Link"""
+
+    name: str
+    scene = None
+    _body_row: Optional[int] = None
+
+    @property
+    def device(self):
+        return self.scene.device
+
+    @property
+    def px(self):
+        return self.scene.px
+
+    @property
+    def _num_objs(self):
+        return self.scene.num_envs
+
+    @property
+    def _scene_idxs(self):
+        return self.scene._all_env_idx
+
+    @property
+    def _body_data_index(self) -> torch.Tensor:
+        """row indices into `px.cuda_rigid_body_data` (structs/base.py:103-110)"""
+        N = self.scene.num_envs
+        return torch.arange(self._body_row * N, (self._body_row + 1) * N, device=self.device)
+
+    @property
+    def _body_data(self) -> torch.Tensor:
+        return self.px.cuda_rigid_body_data.torch()
+
+    def _rows(self) -> torch.Tensor:
+        N = self.scene.num_envs
+        return self._body_data[self._body_row * N : (self._body_row + 1) * N]
+
+    def _masked_write(self, cols: slice, value):
+        value = common.to_tensor(value, device=self.device)
+        rows = self._rows()
+        mask = self.scene._reset_mask
+        if self.scene._reset_mask_all:
+            rows[:, cols] = value
+        else:
+            rows[mask, cols] = value
+
+    # velocities -------------------------------------------------------------
+    @property
+    def linear_velocity(self) -> torch.Tensor:
+        return self._rows()[:, 7:10]
+
+    @property
+    def angular_velocity(self) -> torch.Tensor:
+        return self._rows()[:, 10:13]
+
+    def get_linear_velocity(self):
+        return self.linear_velocity
+
+    def get_angular_velocity(self):
+        return self.angular_velocity
+
+    def get_pose(self) -> Pose:
+        return self.pose
+
+    # contact forces -----------------------------------------------------------
+    def get_net_contact_impulses(self):
+        q = self.scene._body_query(self._body_row)
+        self.px.gpu_query_contact_body_impulses(q)
+        return q.cuda_impulses.torch().clone()
+
+    def get_net_contact_forces(self):
+        return self.get_net_contact_impulses() / self.scene.timestep
+
+    def __hash__(self):
+        return hash((type(self).__name__, self.name, id(self.scene)))
+
+    def __repr__(self):
+        return f"<{type(self).__name__} {self.name}>"
+
+
+class Actor(_RigidBase):
+    """dynamic / kinematic / static actor built by `ActorBuilder` (actor.py:25-400)"""
+
+    def __init__(self, scene, name: str, body_type: str, initial_pose: Pose, has_collision_shapes: bool, mass: float = 0.0):
+        self.scene = scene
+        self.name = name
+        self.px_body_type = body_type
+        self.initial_pose = initial_pose
+        self.has_collision_shapes = has_collision_shapes
+        self._mass = mass
+        self.hidden = False
+        self.before_hide_pose = None
+        self._body_row = None
+        self.merged = False
+
+    # ---- state dict ----------------------------------------------------------
+    def get_state(self):
+        pose = self.pose
+        if self.px_body_type == "dynamic":
+            return torch.hstack([pose.p, pose.q, self.linear_velocity, self.angular_velocity])
+        z = torch.zeros((len(pose), 6), device=self.device)
+        return torch.hstack([pose.p, pose.q, z])
+
+    def set_state(self, state, env_idx: torch.Tensor = None):
+        state = common.to_tensor(state, device=self.device)
+        with self.scene._narrow_reset_mask(env_idx):
+            self.set_pose(Pose.create(state[:, :7]))
+            if self.px_body_type == "dynamic":
+                self.set_linear_velocity(state[:, 7:10])
+                self.set_angular_velocity(state[:, 10:13])
+
+    # ---- visibility (actor.py:176-218) -----------------------------------------
+    def hide_visual(self):
+        assert not self.has_collision_shapes, "Cannot hide objects with collision shapes in the GPU sim"
+        if self.hidden:
+            return
+        self.before_hide_pose = self._rows()[:, :7].clone()
+        self._rows()[:, :3] = self.before_hide_pose[:, :3] + 99999
+        self.scene._gpu_apply_all()
+        self.scene._gpu_fetch_all()
+        self.hidden = True
+
+    def show_visual(self):
+        assert not self.has_collision_shapes, "Cannot show objects with collision shapes in the GPU sim"
+        if not self.hidden:
+            return
+        self.hidden = False
+        self._rows()[:, :7] = self.before_hide_pose
+        self.scene._gpu_apply_all()
+        self.scene._gpu_fetch_all()
+
+    def is_static(self, lin_thresh=1e-2, ang_thresh=1e-1):
+        return torch.logical_and(
+            torch.linalg.norm(self.linear_velocity, dim=1) <= lin_thresh,
+            torch.linalg.norm(self.angular_velocity, dim=1) <= ang_thresh,
+        )
+
+    def set_collision_group_bit(self, group: int, bit_idx: int, bit):
+        self.scene._set_collision_group_bit(self.name, group, bit_idx, bit)
+
+    def set_collision_group(self, group: int, value):
+        self.scene._set_collision_group(self.name, group, value)
+
+    def apply_force(self, force):
+        """force for the next simulation step only (actor.py:305-316)"""
+        force = common.to_tensor(force, device=self.device)
+        N = self.scene.num_envs
+        buf = self.px.cuda_rigid_body_force.torch()[self._body_row * N : (self._body_row + 1) * N]
+        buf[self.scene._reset_mask, :3] = force
+        self.px.gpu_apply_rigid_dynamic_force()
+
+    @property
+    def mass(self):
+        return torch.full((self.scene.num_envs,), float(self._mass), device=self.device)
+
+    def get_mass(self):
+        return self.mass
+
+    # ---- pose -------------------------------------------------------------------
+    @property
+    def pose(self) -> Pose:
+        if self.px_body_type == "static":
+            return self.initial_pose
+        if self.hidden:
+            return Pose.create(self.before_hide_pose)
+        return Pose.create(self._rows()[:, :7])
+
+    @pose.setter
+    def pose(self, arg1) -> None:
+        if self.px_body_type == "static":
+            if self.scene._gpu_sim_initialized:
+                raise AssertionError("cannot set the pose of a static actor after the simulation is initialised")
+            self.initial_pose = Pose.create(arg1, device=self.device)
+            return
+        raw = vectorize_pose(arg1, device=self.device)
+        if not self.scene._gpu_sim_initialized:
+            self.initial_pose = Pose.create(raw)
+            return
+        if self.hidden:
+            if self.scene._reset_mask_all:
+                self.before_hide_pose[:] = raw
+            else:
+                self.before_hide_pose[self.scene._reset_mask] = raw
+            return
+        self._masked_write(slice(0, 7), raw)
+
+    def set_pose(self, arg1) -> None:
+        self.pose = arg1
+
+    def set_linear_velocity(self, v):
+        self._masked_write(slice(7, 10), v)
+
+    def set_angular_velocity(self, v):
+        self._masked_write(slice(10, 13), v)
+
+    @_RigidBase.linear_velocity.setter
+    def linear_velocity(self, v):
+        self.set_linear_velocity(v)
+
+    @_RigidBase.angular_velocity.setter
+    def angular_velocity(self, v):
+        self.set_angular_velocity(v)
+
+
+class Link(_RigidBase):
+    """articulation link (link.py:27-340)"""
+
+    def __init__(self, scene, articulation, name: str, index: int, joint=None):
+        self.scene = scene
+        self.articulation = articulation
+        self.name = name
+        self.index_int = index
+        self._body_row = index
+        self.joint = joint
+        self.merged = False
+        self.disable_gravity_flag = False
+
+    @property
+    def index(self) -> torch.Tensor:
+        return torch.full((self.scene.num_envs,), self.index_int, dtype=torch.int, device=self.device)
+
+    @property
+    def is_root(self) -> torch.Tensor:
+        return torch.full((self.scene.num_envs,), self.index_int == 0, dtype=torch.bool, device=self.device)
+
+    def get_index(self):
+        return self.index
+
+    def get_joint(self):
+        return self.joint
+
+    def get_articulation(self):
+        return self.articulation
+
+    def get_name(self):
+        return self.name
+
+    @property
+    def disable_gravity(self):
+        return torch.full((self.scene.num_envs,), self.disable_gravity_flag, dtype=torch.bool, device=self.device)
+
+    @disable_gravity.setter
+    def disable_gravity(self, v: bool):
+        if self.scene._gpu_sim_initialized:
+            raise AssertionError("disable_gravity cannot be changed after gpu_init (structs/decorators.py:1-13)")
+        self.disable_gravity_flag = bool(v)
+        self.articulation._record.link_gravity[self.name] = not bool(v)
+
+    def set_collision_group_bit(self, group: int, bit_idx: int, bit):
+        self.articulation._set_link_collision_group_bit(self.name, group, bit_idx, bit)
+
+    def set_collision_group(self, group: int, value):
+        self.articulation._set_link_collision_group(self.name, group, value)
+
+    @property
+    def pose(self) -> Pose:
+        return Pose.create(self._rows()[:, :7])
+
+    @pose.setter
+    def pose(self, arg1) -> None:
+        """only meaningful for the root link (articulation root pose, link.py:239-269)"""
+        raw = vectorize_pose(arg1, device=self.device)
+        if not self.scene._gpu_sim_initialized:
+            self.articulation.initial_pose = Pose.create(raw)
+            return
+        self._masked_write(slice(0, 7), raw)
+
+    def set_pose(self, arg1) -> None:
+        self.pose = arg1

@@ -1,0 +1,34 @@
+"""rotation_conversions restatement vs golden vectors produced by the reference's own file
+(tests/golden/make_rotation_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+from maniskill_amd.utils.geometry import rotation_conversions as rc
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rotation_golden.npz"))
+t = lambda k: torch.from_numpy(G[k])
+
+
+def close(a, k, atol=1e-6):
+    np.testing.assert_allclose(a.numpy(), G[k], atol=atol, rtol=1e-5)
+
+
+def test_quaternion_ops_match_reference():
+    qa, qb, pts = t("qa"), t("qb"), t("pts")
+    close(rc.quaternion_multiply(qa, qb), "quaternion_multiply")
+    close(rc.quaternion_raw_multiply(qa, qb), "quaternion_raw_multiply")
+    close(rc.quaternion_apply(qa, pts), "quaternion_apply")
+    close(rc.quaternion_invert(qa), "quaternion_invert")
+    close(rc.standardize_quaternion(qa), "standardize_quaternion")
+
+
+def test_matrix_conversions_match_reference():
+    qa = t("qa")
+    close(rc.quaternion_to_matrix(qa), "quaternion_to_matrix")
+    close(rc.matrix_to_quaternion(t("quaternion_to_matrix")), "matrix_to_quaternion", atol=1e-5)
+    close(rc.euler_angles_to_matrix(t("eul"), "XYZ"), "euler_XYZ")
+    close(rc.euler_angles_to_matrix(t("eul"), "ZYX"), "euler_ZYX")
+    close(rc.axis_angle_to_quaternion(t("aa")), "axis_angle_to_quaternion")
+    close(rc.quaternion_to_axis_angle(qa), "quaternion_to_axis_angle", atol=1e-5)
