@@ -209,6 +209,12 @@ int MSSIM_FN(read_internal)(mssim_handle h, const char* name, float* out, int32_
 /* capacity overflow must be a reported condition (SURVEY 8b error conventions): number of envs
  * whose solver row capacity was exceeded since the last call (synchronises the stream). */
 int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
+/* Measurement aid (bench.py roofline block): when enabled, every k_solve / k_narrow launch inside
+ * mssim_step is bracketed by HIP events on the SAME stream it is launched on. profile_read
+ * synchronises, returns the accumulated milliseconds and launch counts since the last read
+ * (index 0 = solve kernel, 1 = narrowphase kernel) and clears them. The oracle returns zeros. */
+int MSSIM_FN(profile_enable)(mssim_handle h, int32_t on);
+int MSSIM_FN(profile_read)(mssim_handle h, float* out_ms2, int32_t* out_counts2);
 /* last error message of this handle (or of create when h == NULL) */
 const char* MSSIM_FN(last_error)(mssim_handle h);
 int MSSIM_FN(abi_version)(void);

@@ -889,6 +889,10 @@ struct mssim_sim {
   std::vector<int> query_kind;
   std::string err;
   int row_fields = 0;
+  // profiling (bench roofline block): event pairs recorded on the launch stream
+  bool profiling = false;
+  std::vector<hipEvent_t> ev[2];  // [kernel] start/stop interleaved
+  size_t ev_used[2] = {0, 0};
 };
 
 static std::string g_create_error;
@@ -934,6 +938,8 @@ void mssim_destroy(mssim_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (void* p : h->allocs) (void)hipFree(p);
+  for (int k = 0; k < 2; k++)
+    for (auto& e : h->ev[k]) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -1044,15 +1050,57 @@ int mssim_update_kinematics(mssim_handle h, void* stream) {
   return 0;
 }
 
+static inline void prof_mark(mssim_handle h, int k, hipStream_t st) {
+  if (!h->profiling || h->ev_used[k] >= h->ev[k].size()) return;
+  (void)hipEventRecord(h->ev[k][h->ev_used[k]++], st);
+}
+
 int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
   for (int s = 0; s < n_substeps; s++) {
-    if (h->M.n_pair > 0) hipLaunchKernelGGL(k_narrow, dim3((h->N + 63) / 64, h->M.n_pair), dim3(64), 0, st, h->M, h->S);
+    if (h->M.n_pair > 0) {
+      prof_mark(h, 1, st);
+      hipLaunchKernelGGL(k_narrow, dim3((h->N + 63) / 64, h->M.n_pair), dim3(64), 0, st, h->M, h->S);
+      prof_mark(h, 1, st);
+    }
+    prof_mark(h, 0, st);
     if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
     else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+    prof_mark(h, 0, st);
   }
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_profile_enable(mssim_handle h, int32_t on) {
+  HIPCHK(h, hipSetDevice(h->device));
+  if (on && h->ev[0].empty()) {
+    for (int k = 0; k < 2; k++) {
+      h->ev[k].resize(2 * 4096);
+      for (auto& e : h->ev[k]) HIPCHK(h, hipEventCreate(&e));
+    }
+  }
+  h->profiling = on != 0;
+  h->ev_used[0] = h->ev_used[1] = 0;
+  return 0;
+}
+
+int mssim_profile_read(mssim_handle h, float* out_ms, int32_t* out_counts) {
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  for (int k = 0; k < 2; k++) {
+    float total = 0.f;
+    size_t pairs = h->ev_used[k] / 2;
+    for (size_t i = 0; i < pairs; i++) {
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev[k][2 * i], h->ev[k][2 * i + 1]));
+      total += ms;
+    }
+    out_ms[k] = total;
+    out_counts[k] = (int32_t)pairs;
+    h->ev_used[k] = 0;
+  }
   return 0;
 }
 

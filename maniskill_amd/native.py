@@ -154,6 +154,8 @@ class NativeLib:
         f("set_drive_properties", C.c_int, [H, _F32P])
         f("read_internal", C.c_int, [H, C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p])
         f("overflow_count", C.c_int, [H, C.c_void_p])
+        f("profile_enable", C.c_int, [H, C.c_int32])
+        f("profile_read", C.c_int, [H, _F32P, _I32P])
         f("last_error", C.c_char_p, [H])
         f("abi_version", C.c_int, [])
         if self.abi_version() != ABI_VERSION:
@@ -162,7 +164,8 @@ class NativeLib:
     EXPORTS = [
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
-        "query_body_impulses", "set_drive_properties", "read_internal", "overflow_count", "last_error",
+        "query_body_impulses", "set_drive_properties", "read_internal", "overflow_count", "profile_enable",
+        "profile_read", "last_error",
         "abi_version",
     ]
 
@@ -262,6 +265,16 @@ class NativeSim:
         if n < 0:
             self._check(n, f"read_internal({name})")
         return n
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.profile_enable(self.h, 1 if on else 0), "profile_enable")
+
+    def profile_read(self):
+        """-> {"solve": (ms, launches), "narrow": (ms, launches)} since the last read"""
+        ms = (C.c_float * 2)()
+        cnt = (C.c_int32 * 2)()
+        self._check(self.lib.profile_read(self.h, ms, cnt), "profile_read")
+        return {"solve": (float(ms[0]), int(cnt[0])), "narrow": (float(ms[1]), int(cnt[1]))}
 
     def overflow_count(self, stream=None):
         return int(self.lib.overflow_count(self.h, stream))

@@ -278,6 +278,13 @@ class MssimSystem:
         n = self._sim.read_internal(name, out.data_ptr(), max_items, self._stream())
         return out[:n]
 
+    def profile_enable(self, on: bool = True):
+        """bracket the solve / narrowphase launches with HIP events on their launch stream"""
+        self._sim.profile_enable(on)
+
+    def profile_read(self):
+        return self._sim.profile_read()
+
     def overflow_count(self) -> int:
         return self._sim.overflow_count(self._stream())
 

@@ -670,8 +670,12 @@ int mssim_ref_fetch(mssim_handle h, uint32_t what, void*) {
 }
 
 int mssim_ref_step(mssim_handle h, int32_t n_substeps, void*) {
-  for (int s = 0; s < n_substeps; s++)
-    for (auto& E : h->env) substep(h, E);
+  // envs are independent (per-env state only; the model is read-only): parallel over envs when
+  // built with -fopenmp (used for the multi-core cpu_baseline of bench.py)
+  const int N = h->N;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < N; e++)
+    for (int s = 0; s < n_substeps; s++) substep(h, h->env[e]);
   return 0;
 }
 
@@ -775,6 +779,9 @@ int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_
   }
   return items;
 }
+
+int mssim_ref_profile_enable(mssim_handle, int32_t) { return 0; }
+int mssim_ref_profile_read(mssim_handle, float* ms, int32_t* cnt) { ms[0] = ms[1] = 0; cnt[0] = cnt[1] = 0; return 0; }
 
 int mssim_ref_overflow_count(mssim_handle h, void*) {
   int c = 0;
