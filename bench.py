@@ -20,28 +20,25 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# host threads actually available to this process (the GPU box exposes a CPU share, not all cores)
+def _host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota, when the box limits this job to a share of the host
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 16) if n > 64 else n  # a one-GPU box is a 16-core share of a larger host
+
+
+HOST_CORES = _host_cores()
+os.environ.setdefault("OMP_NUM_THREADS", str(HOST_CORES))
 
 import torch  # noqa: E402
 
 ALG_BYTES_PER_ENV_STEP = 1332  # 192 B read + 1140 B written per env-step (f32)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-
-
-def run_env_loop(env, steps, warmup, gather=None, seed=None, profile=False):
-    base = env.unwrapped
-    dev = base.device
-    N = base.num_envs
-    env.reset(seed=seed)
-    for _ in range(warmup):
-        a = 2 * torch.rand((N, 8), device=dev) - 1
-        out = env.step(a)
-    if seed is not None:
-        env.reset(seed=seed)
-    if profile:
-        base.scene.px.profile_enable(True)
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
-    return base, dev, N
 
 
 def timed_steps(env, steps, gather, barrier):
@@ -72,7 +69,7 @@ def cpu_baseline(seconds_budget=20.0):
 
     ob.register("f32", "cpu_oracle_f32")
     n = 512
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(HOST_CORES)
     env = gym.make("PickCube-v1", num_envs=n, sim_backend="cpu_oracle_f32")
     env.reset(seed=[2022 + i for i in range(n)])
     for _ in range(2):
@@ -86,7 +83,7 @@ def cpu_baseline(seconds_budget=20.0):
             break
     dt = time.perf_counter() - t0
     env.close()
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = int(os.environ.get("OMP_NUM_THREADS", HOST_CORES))
     return dict(
         value=round(k * n / dt, 1),
         unit="env-steps/s",

@@ -51,6 +51,8 @@ struct DevState {
   unsigned* hit_mask;                           // [n_words][N]
   float* rows;                                  // [3*MAXC * RF][N] solver scratch
   int* overflow;                                // [N]
+  int row_slots;                                // LDS slots per lane for packed solver rows
+  int glb_slots;                                // overflow slots per lane in `rows` (wave-contiguous: [block][slot][64])
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -236,18 +238,6 @@ __global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// solver row layout in the scratch buffer (fields of one row, each [N] floats)
-template <int MAXD>
-struct RowF {
-  static constexpr int JA = 0, WA = MAXD, F0 = 2 * MAXD, F1 = 2 * MAXD + 11;  // free side: idx, minv, Jl3, Jw3, Ww3
-  static constexpr int INVD = 2 * MAXD + 22, BPOS = INVD + 1, BVEL = INVD + 2, MU = INVD + 3, LAM = INVD + 4, FLAGS = INVD + 5,
-                       PAIR = INVD + 6, DIR = INVD + 7;
-  static constexpr int COUNT = INVD + 10;
-};
-#define ROW_HAS_ART 1
-#define ROW_FRICTION 2
-#define ROW_VALID 4
-
 // per-lane free-body data kept in LDS as [item][64]: 16 items per body
 #define FB_V 0   // linear velocity (3)
 #define FB_W 3   // angular velocity (3)
@@ -258,8 +248,10 @@ struct RowF {
 
 template <class T>
 __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
-  __shared__ float fb[MSSIM_MAX_FREE * FB_ITEMS * 64];
-  typedef RowF<T::MAXD> RF;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* fb = smem;                                              // [n_free*FB_ITEMS][64]
+  float* rowbuf = smem + (size_t)M.n_free * FB_ITEMS * 64 + threadIdx.x;  // [row_slots][64], this lane's column
+  const int row_slots = S.row_slots;
   const int N = S.N;
   const int lane = threadIdx.x;
   int e = blockIdx.x * 64 + lane;
@@ -421,7 +413,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
   }
   // LDL^T, solve, force-limit active set, explicit inverse
   float L[T::MAXD][T::MAXD], v[T::MAXD], Ainv[T::MAXD][T::MAXD];
-  auto factor = [&]() {
+  auto factor = [&]() __attribute__((always_inline)) {
 #pragma unroll T::UNROLL
     for (int j = 0; j < T::MAXD; j++) {
       if (j >= n) break;
@@ -448,7 +440,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
       }
     }
   };
-  auto solve = [&](float* b) {
+  auto solve = [&](float* b) __attribute__((always_inline)) {
 #pragma unroll T::UNROLL
     for (int i = 0; i < T::MAXD; i++) {
       if (i >= n) break;
@@ -550,10 +542,15 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
     lim_lam[j] = 0.f;
   }
 
-  // ---- 4b. contact rows -> scratch
-  int nrows = 0;
+  // ---- 4b. contact rows: packed variable-length records, first in LDS (per-lane column,
+  //      [slot][64 lanes] => conflict-free), overflow in the global scratch with the same layout.
+  //      record = header | inv_diag | bias | mu | lambda | [Ja(n) Wa(n)] | [Jl Jw Ww](9) x free sides
+  //      header bits: 0 has_art, 1 friction, 2 valid, 3 sep>=0, 4-7 free0+1, 8-11 free1+1, 12-27 pair, 28-29 dir
+  int nrows_lds = 0, nrows_glb = 0;
   {
     int ncontacts = 0;
+    int off_lds = 0, off_glb = 0;
+    bool lds_full = false;
     for (int w = 0; w < M.n_words; w++) {
       unsigned bits = S.hit_mask[(size_t)w * N + e];
       while (bits) {
@@ -570,6 +567,9 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
         f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
         f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
         f3 t2 = cross(nrm, t1);
+        bool hasart = (kinds[0] == MSSIM_BODY_ART && idxs[0] >= 0) || (kinds[1] == MSSIM_BODY_ART && idxs[1] >= 0);
+        int nfree = (kinds[0] == MSSIM_BODY_FREE ? 1 : 0) + (kinds[1] == MSSIM_BODY_FREE ? 1 : 0);
+        const int rlen = 5 + (hasart ? 2 * n : 0) + 9 * nfree;
         for (int k = 0; k < cnt; k++) {
           if (ncontacts >= MAXC) { S.overflow[e] = 1; break; }
           ncontacts++;
@@ -577,20 +577,22 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
           float sep = pd[(size_t)(6 + 4 * k) * N];
           for (int dk = 0; dk < 3; dk++) {
             f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
-            float* row = S.rows + (size_t)nrows * RF::COUNT * N + e;
-#define RW(f) row[(size_t)(f) * N]
+            if (!lds_full && off_lds + rlen > row_slots) lds_full = true;
+            float* row;
+            size_t rs;
+            if (!lds_full) { row = rowbuf + (size_t)off_lds * 64; rs = 64; off_lds += rlen; nrows_lds++; }
+            else { row = S.rows + ((size_t)blockIdx.x * S.glb_slots + off_glb) * 64 + threadIdx.x; rs = 64; off_glb += rlen; nrows_glb++; }
+#define RW(f) row[(size_t)(f) * rs]
             float Ja[T::MAXD];
 #pragma unroll T::UNROLL
             for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; Ja[i] = 0.f; }
-            bool hasart = false;
-            int nfree = 0;
             float diag = 0.f;
-            RW(RF::F0) = __int_as_float(-1);
-            RW(RF::F1) = __int_as_float(-1);
+            int hdr = (hasart ? 1 : 0) | (dk > 0 ? 2 : 0) | (sep >= 0.f ? 8 : 0) | (p << 12) | (dk << 28);
+            int fpos = 5 + (hasart ? 2 * n : 0);
+            int fside = 0;
             for (int s = 0; s < 2; s++) {
               float sign = s == 0 ? 1.f : -1.f;
               if (kinds[s] == MSSIM_BODY_ART && idxs[s] >= 0) {
-                hasart = true;
                 unsigned am = M.dof_anc[idxs[s]] | (1u << idxs[s]);
 #pragma unroll T::UNROLL
                 for (int i = 0; i < T::MAXD; i++) {
@@ -607,13 +609,13 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
                 float minv = FB(b, FB_MINV);
                 f3 Jl = d * sign, Jw = cross(x - com, d) * sign;
                 f3 Ww = smulv(Ii, Jw);
-                int base = nfree == 0 ? RF::F0 : RF::F1;
-                RW(base) = __int_as_float(b); RW(base + 1) = minv;
-                RW(base + 2) = Jl.x; RW(base + 3) = Jl.y; RW(base + 4) = Jl.z;
-                RW(base + 5) = Jw.x; RW(base + 6) = Jw.y; RW(base + 7) = Jw.z;
-                RW(base + 8) = Ww.x; RW(base + 9) = Ww.y; RW(base + 10) = Ww.z;
-                diag += dot(Jl, Jl) * minv + dot(Jw, Ww);
-                nfree++;
+                RW(fpos) = Jl.x; RW(fpos + 1) = Jl.y; RW(fpos + 2) = Jl.z;
+                RW(fpos + 3) = Jw.x; RW(fpos + 4) = Jw.y; RW(fpos + 5) = Jw.z;
+                RW(fpos + 6) = Ww.x; RW(fpos + 7) = Ww.y; RW(fpos + 8) = Ww.z;
+                diag += minv + dot(Jw, Ww);  // |Jl| = 1
+                hdr |= (b + 1) << (4 + 4 * fside);
+                fpos += 9;
+                fside++;
               }
             }
             if (hasart) {
@@ -623,29 +625,165 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
                 float wv = 0.f;
 #pragma unroll T::UNROLL
                 for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; wv += Ainv[i][j] * Ja[j]; }
-                RW(RF::JA + i) = Ja[i];
-                RW(RF::WA + i) = wv;
+                RW(5 + i) = Ja[i];
+                RW(5 + n + i) = wv;
                 diag += Ja[i] * wv;
               }
             }
-            int flags = (hasart ? ROW_HAS_ART : 0) | (dk > 0 ? ROW_FRICTION : 0) | (diag > 1e-12f ? ROW_VALID : 0);
-            RW(RF::INVD) = diag > 1e-12f ? 1.f / diag : 0.f;
-            RW(RF::BPOS) = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
-            RW(RF::BVEL) = dk == 0 ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
-            RW(RF::MU) = mu;
-            RW(RF::LAM) = 0.f;
-            RW(RF::FLAGS) = __int_as_float(flags);
-            RW(RF::PAIR) = __int_as_float(p);
-            RW(RF::DIR) = d.x; RW(RF::DIR + 1) = d.y; RW(RF::DIR + 2) = d.z;
-            nrows++;
+            if (diag > 1e-12f) hdr |= 4;
+            RW(0) = __int_as_float(hdr);
+            RW(1) = diag > 1e-12f ? 1.f / diag : 0.f;
+            RW(2) = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
+            RW(3) = mu;
+            RW(4) = 0.f;
+#undef RW
           }
         }
       }
     }
   }
 
-  // ---- 5. projected Gauss-Seidel
-  auto sweep = [&](bool use_bias) {
+  // ---- 5. projected Gauss-Seidel.
+  // The sweep is one long dependent chain per env (Gauss-Seidel), so per-row latency is what
+  // matters: (a) the twists of the (up to two) free bodies a row touches are cached in VGPRs and
+  // only written back to LDS when a row needs a different body; (b) row records are software
+  // prefetched one row ahead into a second register set so LDS / L2 latency overlaps the
+  // arithmetic of the current row.
+  struct RowRegs {
+    int hdr;
+    float invd, bias, mu, lam;
+    float f0[9], f1[9];
+    float ja[T::MAXD], wa[T::MAXD];
+  };
+  int cb0 = -1, cb1 = -1;  // cached free-body ids per side
+  f3 cv0 = f3{0, 0, 0}, cw0 = cv0, cv1 = cv0, cw1 = cv0;
+  float cm0 = 0.f, cm1 = 0.f;
+  auto wb0 = [&]() __attribute__((always_inline)) {
+    if (cb0 >= 0) {
+      FB(cb0, FB_V) = cv0.x; FB(cb0, FB_V + 1) = cv0.y; FB(cb0, FB_V + 2) = cv0.z;
+      FB(cb0, FB_W) = cw0.x; FB(cb0, FB_W + 1) = cw0.y; FB(cb0, FB_W + 2) = cw0.z;
+    }
+  };
+  auto wb1 = [&]() __attribute__((always_inline)) {
+    if (cb1 >= 0) {
+      FB(cb1, FB_V) = cv1.x; FB(cb1, FB_V + 1) = cv1.y; FB(cb1, FB_V + 2) = cv1.z;
+      FB(cb1, FB_W) = cw1.x; FB(cb1, FB_W + 1) = cw1.y; FB(cb1, FB_W + 2) = cw1.z;
+    }
+  };
+  auto need0 = [&](int b) __attribute__((always_inline)) {
+    if (cb0 == b) return;
+    wb0();
+    if (cb1 == b) { wb1(); cb1 = -1; }
+    cb0 = b;
+    cv0 = f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)};
+    cw0 = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
+    cm0 = FB(b, FB_MINV);
+  };
+  auto need1 = [&](int b) __attribute__((always_inline)) {
+    if (cb1 == b) return;
+    wb1();
+    if (cb0 == b) { wb0(); cb0 = -1; }
+    cb1 = b;
+    cv1 = f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)};
+    cw1 = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
+    cm1 = FB(b, FB_MINV);
+  };
+  auto row_len = [&](int hdr) __attribute__((always_inline)) -> int {
+    return 5 + ((hdr & 1) ? 2 * n : 0) + (((hdr >> 4) & 15) ? 9 : 0) + (((hdr >> 8) & 15) ? 9 : 0);
+  };
+  auto load_row = [&](const float* row, size_t rs, RowRegs& R) __attribute__((always_inline)) {
+    R.hdr = __float_as_int(row[0]);
+    R.invd = row[rs]; R.bias = row[2 * rs]; R.mu = row[3 * rs]; R.lam = row[4 * rs];
+    const bool hasart = R.hdr & 1;
+    const int fbase = 5 + (hasart ? 2 * n : 0);
+    if (hasart) {
+#pragma unroll T::UNROLL
+      for (int i = 0; i < T::MAXD; i++) {
+        if (i >= n) break;
+        R.ja[i] = row[(size_t)(5 + i) * rs];
+        R.wa[i] = row[(size_t)(5 + n + i) * rs];
+      }
+    }
+    if ((R.hdr >> 4) & 15) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) R.f0[k] = row[(size_t)(fbase + k) * rs];
+    }
+    if ((R.hdr >> 8) & 15) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) R.f1[k] = row[(size_t)(fbase + 9 + k) * rs];
+    }
+  };
+  float lam_n = 0.f;
+  auto process_row = [&](const RowRegs& R, float* row, size_t rs, bool use_bias) __attribute__((always_inline)) {
+    const int hdr = R.hdr;
+    const bool hasart = hdr & 1, fric = hdr & 2;
+    const int b0 = ((hdr >> 4) & 15) - 1, b1 = ((hdr >> 8) & 15) - 1;
+    if (!fric) lam_n = R.lam;
+    if (!(hdr & 4)) return;
+    float jv = 0.f;
+    if (hasart) {
+#pragma unroll T::UNROLL
+      for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; jv += R.ja[i] * v[i]; }
+    }
+    if (b0 >= 0) {
+      need0(b0);
+      jv += R.f0[0] * cv0.x + R.f0[1] * cv0.y + R.f0[2] * cv0.z + R.f0[3] * cw0.x + R.f0[4] * cw0.y + R.f0[5] * cw0.z;
+    }
+    if (b1 >= 0) {
+      need1(b1);
+      jv += R.f1[0] * cv1.x + R.f1[1] * cv1.y + R.f1[2] * cv1.z + R.f1[3] * cw1.x + R.f1[4] * cw1.y + R.f1[5] * cw1.z;
+    }
+    float lo = 0.f, hi = 1e30f;
+    if (fric) { hi = R.mu * lam_n; lo = -hi; }
+    float b = use_bias ? R.bias : ((hdr & 8) ? R.bias : 0.f);
+    float nl = R.lam - (jv + b) * R.invd;
+    nl = nl < lo ? lo : (nl > hi ? hi : nl);
+    float dl = nl - R.lam;
+    if (!fric) lam_n = nl;
+    if (dl != 0.f) {
+      row[4 * rs] = nl;
+      if (hasart) {
+#pragma unroll T::UNROLL
+        for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += R.wa[i] * dl; }
+      }
+      if (b0 >= 0) {
+        float mdl = cm0 * dl;
+        cv0.x += R.f0[0] * mdl; cv0.y += R.f0[1] * mdl; cv0.z += R.f0[2] * mdl;
+        cw0.x += R.f0[6] * dl; cw0.y += R.f0[7] * dl; cw0.z += R.f0[8] * dl;
+      }
+      if (b1 >= 0) {
+        float mdl = cm1 * dl;
+        cv1.x += R.f1[0] * mdl; cv1.y += R.f1[1] * mdl; cv1.z += R.f1[2] * mdl;
+        cw1.x += R.f1[6] * dl; cw1.y += R.f1[7] * dl; cw1.z += R.f1[8] * dl;
+      }
+    }
+  };
+  float* const glb_rows = S.rows + (size_t)blockIdx.x * S.glb_slots * 64 + threadIdx.x;  // wave-contiguous chunk
+  const int nrows_all = nrows_lds + nrows_glb;
+  float vpos[T::MAXD];
+  const int n_iters = M.pos_iters + M.vel_iters;
+  for (int it = 0; it <= n_iters; it++) {
+    if (it == M.pos_iters) {
+      // end of the position iterations: integrate poses with the biased velocities
+      wb0(); wb1();
+#pragma unroll T::UNROLL
+      for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; vpos[j] = v[j]; }
+      for (int b = 0; b < M.n_free; b++) {
+        const float* in = M.free_inertial + 10 * b;
+        f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)} + f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)} * dt;
+        f3 w = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
+        q4 qq = q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)};
+        qq = qnormalized(qq);
+        q4 dq = qmul(q4{0.f, w.x, w.y, w.z}, qq);
+        qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
+        f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
+        SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
+        SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
+      }
+    }
+    if (it == n_iters) break;
+    const bool use_bias = it < M.pos_iters;
+    // joint-limit rows (registers)
 #pragma unroll T::UNROLL
     for (int j = 0; j < T::MAXD; j++) {
       if (j >= n) break;
@@ -662,90 +800,52 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
         }
       }
     }
-    float lam_n = 0.f;
-    for (int r = 0; r < nrows; r++) {
-      float* row = S.rows + (size_t)r * RF::COUNT * N + e;
-      int flags = __float_as_int(RW(RF::FLAGS));
-      float lam = RW(RF::LAM);
-      if (!(flags & ROW_FRICTION)) lam_n = lam;
-      if (!(flags & ROW_VALID)) continue;
-      float jv = 0.f;
-      float Wa[T::MAXD];
-      if (flags & ROW_HAS_ART) {
-#pragma unroll T::UNROLL
-        for (int i = 0; i < T::MAXD; i++) {
-          if (i >= n) break;
-          jv += RW(RF::JA + i) * v[i];
-          Wa[i] = RW(RF::WA + i);
-        }
-      }
-      int b0 = __float_as_int(RW(RF::F0)), b1 = __float_as_int(RW(RF::F1));
-      f3 Jl0, Jw0, Jl1, Jw1;
-      if (b0 >= 0) {
-        Jl0 = f3{RW(RF::F0 + 2), RW(RF::F0 + 3), RW(RF::F0 + 4)};
-        Jw0 = f3{RW(RF::F0 + 5), RW(RF::F0 + 6), RW(RF::F0 + 7)};
-        jv += dot(Jl0, f3{FB(b0, FB_V), FB(b0, FB_V + 1), FB(b0, FB_V + 2)}) + dot(Jw0, f3{FB(b0, FB_W), FB(b0, FB_W + 1), FB(b0, FB_W + 2)});
-      }
-      if (b1 >= 0) {
-        Jl1 = f3{RW(RF::F1 + 2), RW(RF::F1 + 3), RW(RF::F1 + 4)};
-        Jw1 = f3{RW(RF::F1 + 5), RW(RF::F1 + 6), RW(RF::F1 + 7)};
-        jv += dot(Jl1, f3{FB(b1, FB_V), FB(b1, FB_V + 1), FB(b1, FB_V + 2)}) + dot(Jw1, f3{FB(b1, FB_W), FB(b1, FB_W + 1), FB(b1, FB_W + 2)});
-      }
-      float lo = 0.f, hi = 1e30f;
-      if (flags & ROW_FRICTION) { hi = RW(RF::MU) * lam_n; lo = -hi; }
-      float b = use_bias ? RW(RF::BPOS) : RW(RF::BVEL);
-      float nl = lam - (jv + b) * RW(RF::INVD);
-      nl = nl < lo ? lo : (nl > hi ? hi : nl);
-      float dl = nl - lam;
-      if (!(flags & ROW_FRICTION)) lam_n = nl;
-      if (dl != 0.f) {
-        RW(RF::LAM) = nl;
-        if (flags & ROW_HAS_ART) {
-#pragma unroll T::UNROLL
-          for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += Wa[i] * dl; }
-        }
-        if (b0 >= 0) {
-          float minv = RW(RF::F0 + 1);
-          f3 Ww = f3{RW(RF::F0 + 8), RW(RF::F0 + 9), RW(RF::F0 + 10)};
-          FB(b0, FB_V) += Jl0.x * minv * dl; FB(b0, FB_V + 1) += Jl0.y * minv * dl; FB(b0, FB_V + 2) += Jl0.z * minv * dl;
-          FB(b0, FB_W) += Ww.x * dl; FB(b0, FB_W + 1) += Ww.y * dl; FB(b0, FB_W + 2) += Ww.z * dl;
-        }
-        if (b1 >= 0) {
-          float minv = RW(RF::F1 + 1);
-          f3 Ww = f3{RW(RF::F1 + 8), RW(RF::F1 + 9), RW(RF::F1 + 10)};
-          FB(b1, FB_V) += Jl1.x * minv * dl; FB(b1, FB_V + 1) += Jl1.y * minv * dl; FB(b1, FB_V + 2) += Jl1.z * minv * dl;
-          FB(b1, FB_W) += Ww.x * dl; FB(b1, FB_W + 1) += Ww.y * dl; FB(b1, FB_W + 2) += Ww.z * dl;
-        }
+    // contact rows: LDS records first, then the global overflow records (both stride 64)
+    lam_n = 0.f;
+    if (nrows_all > 0) {
+      RowRegs A, B;
+      float* pa = nrows_lds > 0 ? rowbuf : glb_rows;
+      load_row(pa, 64, A);
+      int r = 0;
+      while (r < nrows_all) {
+        float* pb = (r + 1 == nrows_lds) ? glb_rows : pa + (size_t)row_len(A.hdr) * 64;
+        if (r + 1 < nrows_all) load_row(pb, 64, B);
+        process_row(A, pa, 64, use_bias);
+        r++;
+        if (r >= nrows_all) break;
+        pa = (r + 1 == nrows_lds) ? glb_rows : pb + (size_t)row_len(B.hdr) * 64;
+        if (r + 1 < nrows_all) load_row(pa, 64, A);
+        process_row(B, pb, 64, use_bias);
+        r++;
       }
     }
-  };
-  for (int it = 0; it < M.pos_iters; it++) sweep(true);
-  float vpos[T::MAXD];
-#pragma unroll T::UNROLL
-  for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; vpos[j] = v[j]; }
-  // free-body position-iteration velocities: integrate poses now, velocities after the velocity sweep
-  for (int b = 0; b < M.n_free; b++) {
-    const float* in = M.free_inertial + 10 * b;
-    f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)} + f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)} * dt;
-    f3 w = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
-    q4 qq = q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)};
-    qq = qnormalized(qq);
-    q4 dq = qmul(q4{0.f, w.x, w.y, w.z}, qq);
-    qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
-    f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
-    SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
-    SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
   }
-  for (int it = 0; it < M.vel_iters; it++) sweep(false);
+  wb0(); wb1();
 
-  // ---- contact impulses per pair
-  for (int r = 0; r < nrows; r++) {
-    float* row = S.rows + (size_t)r * RF::COUNT * N + e;
-    float lam = RW(RF::LAM);
-    int p = __float_as_int(RW(RF::PAIR));
-    SOA(S.pair_imp, 3 * p) += RW(RF::DIR) * lam;
-    SOA(S.pair_imp, 3 * p + 1) += RW(RF::DIR + 1) * lam;
-    SOA(S.pair_imp, 3 * p + 2) += RW(RF::DIR + 2) * lam;
+  // ---- contact impulses per pair: lambda * direction, direction rebuilt from the pair normal
+  auto accumulate = [&](float* row, size_t rs) __attribute__((always_inline)) -> int {
+    const int hdr = __float_as_int(row[0]);
+    const int b0 = ((hdr >> 4) & 15) - 1, b1 = ((hdr >> 8) & 15) - 1;
+    const int rlen = 5 + ((hdr & 1) ? 2 * n : 0) + (b0 >= 0 ? 9 : 0) + (b1 >= 0 ? 9 : 0);
+    const int p = (hdr >> 12) & 0xFFFF, dk = (hdr >> 28) & 3;
+    const float lam = row[4 * rs];
+    const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
+    f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
+    f3 d = nrm;
+    if (dk > 0) {
+      f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
+      d = dk == 1 ? t1 : cross(nrm, t1);
+    }
+    SOA(S.pair_imp, 3 * p) += d.x * lam;
+    SOA(S.pair_imp, 3 * p + 1) += d.y * lam;
+    SOA(S.pair_imp, 3 * p + 2) += d.z * lam;
+    return rlen;
+  };
+  {
+    int off = 0;
+    for (int r = 0; r < nrows_lds; r++) off += accumulate(rowbuf + (size_t)off * 64, 64);
+    off = 0;
+    for (int r = 0; r < nrows_glb; r++) off += accumulate(S.rows + ((size_t)blockIdx.x * S.glb_slots + off) * 64 + threadIdx.x, 64);
   }
 
   // ---- 6. integrate + FK at the new state
@@ -765,7 +865,6 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
   fk_bodies(topo, M, root, q, bp, aw, anchor);
   write_kinematics(topo, M, S, e, root, v, bp, aw, anchor);
   for (int w = 0; w < M.n_words; w++) S.hit_mask[(size_t)w * N + e] = 0u;
-#undef RW
 #undef FB
 }
 
@@ -890,6 +989,7 @@ struct mssim_sim {
   std::string err;
   int row_fields = 0;
   // profiling (bench roofline block): event pairs recorded on the launch stream
+  unsigned solve_lds_bytes = 0;
   bool profiling = false;
   std::vector<hipEvent_t> ev[2];  // [kernel] start/stop interleaved
   size_t ev_used[2] = {0, 0};
@@ -984,7 +1084,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   S->panda = (n == 9);
   for (int j = 0; j < n && S->panda; j++)
     if (d->dof_parent[j] != kPandaParent[j] || d->dof_type[j] != kPandaType[j]) S->panda = false;
-  S->row_fields = S->panda ? RowF<TopoPanda::MAXD>::COUNT : RowF<TopoDyn::MAXD>::COUNT;
+  S->row_fields = 5 + 2 * (n > 0 ? n : 0) + 18;  // longest packed row
   DevState& D = S->S;
   D.N = num_envs;
   const size_t N = (size_t)num_envs;
@@ -993,8 +1093,23 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin)
   AL(bodypose, 7 * n) AL(bodyvel, 6 * n)
   AL(pair_cnt, d->n_pair) AL(pair_data, 19 * d->n_pair) AL(pair_imp, 3 * d->n_pair) AL(hit_mask, M.n_words)
-  AL(rows, 3 * MAXC * S->row_fields) AL(overflow, 1)
+  D.glb_slots = 3 * MAXC * S->row_fields;
+  if ((rc = dalloc(S, (size_t)D.glb_slots * 64 * (((size_t)num_envs + 63) / 64), &D.rows))) { mssim_destroy(S); return rc; }
+  AL(overflow, 1)
 #undef AL
+  // LDS budget of the solve kernel: one 64-lane block per CU when the grid is small enough to give
+  // every block its own CU (N <= 256*64 envs), otherwise 64 KB so two blocks share a CU
+  {
+    size_t fb_bytes = (size_t)d->n_free * FB_ITEMS * 64 * sizeof(float);
+    size_t budget = ((size_t)num_envs + 63) / 64 <= 256 ? 144 * 1024 : 64 * 1024;
+    size_t slots = budget > fb_bytes ? (budget - fb_bytes) / (64 * sizeof(float)) : 0;
+    D.row_slots = (int)slots;
+    S->solve_lds_bytes = (unsigned)(fb_bytes + slots * 64 * sizeof(float));
+    if (S->solve_lds_bytes > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)k_solve<TopoPanda>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->solve_lds_bytes);
+      (void)hipFuncSetAttribute((const void*)k_solve<TopoDyn>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->solve_lds_bytes);
+    }
+  }
   // identity quaternions
   std::vector<float> ones(N, 1.0f);
   hipMemcpy(D.root + 3 * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
@@ -1065,8 +1180,8 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
       prof_mark(h, 1, st);
     }
     prof_mark(h, 0, st);
-    if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
-    else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+    if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
+    else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);
   }
   HIPCHK(h, hipGetLastError());

@@ -48,9 +48,19 @@ def test_env_rollout_matches_oracle_backend():
     g = torch.Generator().manual_seed(0)
     acts = [2 * torch.rand(N, 8, generator=g) - 1 for _ in range(5)]
     outs = []
-    for backend in (BACKEND, "oracle_f64_env"):
+    ref_state = None
+    for backend in ("oracle_f64_env", BACKEND):
         env = gym.make("PickCube-v1", num_envs=N, sim_backend=backend)
         obs, _ = env.reset(seed=11)
+        # torch.rand differs between the CPU and the GPU generator (as in the reference, whose CPU
+        # and GPU sims also place objects differently), so start both from the oracle env's state
+        if ref_state is None:
+            ref_state = {k: {n: v.clone() for n, v in d.items()} for k, d in env.unwrapped.get_state_dict().items()}
+        else:
+            dev = env.unwrapped.device
+            env.unwrapped.set_state_dict({k: {n: v.to(dev) for n, v in d.items()} for k, d in ref_state.items()})
+            env.unwrapped.agent.controller.reset()
+        obs = env.unwrapped.get_obs()
         traj = [obs.cpu().clone()]
         for a in acts:
             obs, rew, *_ = env.step(a.to(env.unwrapped.device))
