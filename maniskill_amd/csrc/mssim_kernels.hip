@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct DevState {
   float *root, *q, *qd, *qt, *qdt, *qf, *qacc;  // [7][N], [n_dof][N] ...
   float *free_s, *free_force, *kin;             // [n_free*13][N], [n_free*3][N], [n_kin*7][N]
   float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
+  float* bodyaux;                               // [n_dof*6][N] world joint axis (3) + joint anchor (3)
   int* pair_cnt;                                // [n_pair][N]
   float* pair_data;                             // [n_pair*19][N]: n(3), 4 x (x(3), sep)
   float* pair_imp;                              // [n_pair*3][N]
@@ -151,6 +153,9 @@ MS_DEV void write_kinematics(const T& topo, const DevModel& M, const DevState& S
     float* o = S.bodyvel + (size_t)(6 * j) * N + e;
     o[0] = V[j].w.x; o[(size_t)N] = V[j].w.y; o[2 * (size_t)N] = V[j].w.z;
     o[3 * (size_t)N] = V[j].v.x; o[4 * (size_t)N] = V[j].v.y; o[5 * (size_t)N] = V[j].v.z;
+    float* a = S.bodyaux + (size_t)(6 * j) * N + e;
+    a[0] = aw[j].x; a[(size_t)N] = aw[j].y; a[2 * (size_t)N] = aw[j].z;
+    a[3 * (size_t)N] = anchor[j].x; a[4 * (size_t)N] = anchor[j].y; a[5 * (size_t)N] = anchor[j].z;
   }
 }
 
@@ -868,6 +873,8 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
 #undef FB
 }
 
+#include "mssim_solve16.h"
+
 // ------------------------------------------------------------------------------------------------
 // apply / fetch: transposes between the user-visible AoS buffers and the SoA state
 __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) {
@@ -990,6 +997,7 @@ struct mssim_sim {
   int row_fields = 0;
   // profiling (bench roofline block): event pairs recorded on the launch stream
   unsigned solve_lds_bytes = 0;
+  bool coop = false;  // use k_solve16
   bool profiling = false;
   std::vector<hipEvent_t> ev[2];  // [kernel] start/stop interleaved
   size_t ev_used[2] = {0, 0};
@@ -1091,10 +1099,19 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
 #define AL(field, count) if ((rc = dalloc(S, (size_t)(count) * N, &D.field))) { mssim_destroy(S); return rc; }
   AL(root, 7) AL(q, n) AL(qd, n) AL(qt, n) AL(qdt, n) AL(qf, n) AL(qacc, n)
   AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin)
-  AL(bodypose, 7 * n) AL(bodyvel, 6 * n)
+  AL(bodypose, 7 * n) AL(bodyvel, 6 * n) AL(bodyaux, 6 * n)
   AL(pair_cnt, d->n_pair) AL(pair_data, 19 * d->n_pair) AL(pair_imp, 3 * d->n_pair) AL(hit_mask, M.n_words)
   D.glb_slots = 3 * MAXC * S->row_fields;
-  if ((rc = dalloc(S, (size_t)D.glb_slots * 64 * (((size_t)num_envs + 63) / 64), &D.rows))) { mssim_destroy(S); return rc; }
+  {
+    size_t v1_floats = (size_t)D.glb_slots * 64 * (((size_t)num_envs + 63) / 64);
+    size_t v2_floats = (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN;
+    if ((rc = dalloc(S, v1_floats > v2_floats ? v1_floats : v2_floats, &D.rows))) { mssim_destroy(S); return rc; }
+  }
+  // cooperative 16-lanes-per-env kernel when every velocity component fits one DPP row
+  S->coop = (n + 6 * d->n_free <= S16_LANES);
+  if (const char* ev = getenv("MSSIM_SOLVER")) {
+    if (!strcmp(ev, "lane")) S->coop = false;
+  }
   AL(overflow, 1)
 #undef AL
   // LDS budget of the solve kernel: one 64-lane block per CU when the grid is small enough to give
@@ -1180,7 +1197,8 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
       prof_mark(h, 1, st);
     }
     prof_mark(h, 0, st);
-    if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
+    if (h->coop) hipLaunchKernelGGL(k_solve16, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(64), 0, st, h->M, h->S);
+    else if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);
   }

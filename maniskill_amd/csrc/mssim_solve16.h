@@ -1,0 +1,604 @@
+// mssim_solve16.h -- the cooperative solve kernel: 16 lanes per env, 4 envs per wave.
+//
+// Why: with one env per lane N = 4096 envs are 64 wavefronts on a chip with 1024 SIMDs and the
+// kernel is instruction-issue bound at one wave per SIMD. Here every env is
+// spread over a 16-lane DPP row: lane c owns velocity component c (joint c, or one linear /
+// angular component of a free body), so N = 4096 is 1024 waves and the long serial chains become
+//   * tree recursions  -> sums over ancestor / descendant bit sets of per-body quantities staged
+//                         in LDS (no sequential pass except FK),
+//   * dense 9x9 algebra-> Gauss-Jordan with one matrix row per lane, pivot row broadcast via LDS,
+//   * Gauss-Seidel row -> one multiply, a 4-step DPP row-rotate all-reduce, a clamp, one FMA.
+// Solver rows (J[16], W[16], 8 scalars) live in LDS, overflow rows in a per-env global scratch.
+//
+// Same math and the same row order as k_solve / the oracle (limits, then contacts in pair order,
+// normal + 2 friction rows each), so the parity tests cover it unchanged.
+// Requires n_dof + 6 * n_free <= 16.
+#pragma once
+
+#define S16_LANES 16
+#define S16_ENVS_PER_BLOCK 4
+// per-env LDS layout (floats)
+#define S16_COM 0      // [8][3] free-body centres of mass
+#define S16_VEC 32     // 4 x [16] scratch vectors
+#define S16_BP 96      // [16][7] body poses (FK staging)
+#define S16_U 208      // union: dynamics staging | solver rows
+#define S16_S (S16_U)          // [16][6]
+#define S16_V (S16_U + 96)     // [16][6]
+#define S16_T (S16_U + 192)    // [16][6]
+#define S16_F (S16_U + 288)    // [16][6]
+#define S16_IC (S16_U + 384)   // [16][10]
+#define S16_MAT (S16_U + 544)  // [16][16]
+#define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
+#define S16_ROWLEN 40          // J[16] W[16] | invd bpos bvel mu lam pair dk pad
+#define S16_ROWS_LDS 58
+#define S16_ENV_FLOATS (S16_U + S16_ROWLEN * S16_ROWS_LDS)  // 3248 floats = 12992 B per env
+#define S16_ROWS_GLB (16 + 3 * MAXC - S16_ROWS_LDS)
+
+template <int CTRL>
+MS_DEV float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+// all-reduce (sum) inside each 16-lane DPP row: rotations by 8, 4, 2, 1
+MS_DEV float gsum16(float x) {
+  x += dpp_f<0x128>(x);
+  x += dpp_f<0x124>(x);
+  x += dpp_f<0x122>(x);
+  x += dpp_f<0x121>(x);
+  return x;
+}
+MS_DEV float gbc(float x, int j) { return __shfl(x, j, 16); }
+MS_DEV int gbci(int x, int j) { return __shfl(x, j, 16); }
+
+MS_DEV void ld16(const float* p, float* out) {  // 16 consecutive floats (16-B aligned)
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float4 t = q[i];
+    out[4 * i] = t.x; out[4 * i + 1] = t.y; out[4 * i + 2] = t.z; out[4 * i + 3] = t.w;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
+  __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
+  const int N = S.N;
+  const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int e_raw = blockIdx.x * S16_ENVS_PER_BLOCK + g;
+  const bool live = e_raw < N;
+  const int e = live ? e_raw : N - 1;  // dead groups shadow the last env and never store
+  float* L = sm + g * S16_ENV_FLOATS;
+  const int n = M.n_dof, nf = M.n_free;
+  const float dt = M.dt;
+  const f3 g3 = f3{M.gx, M.gy, M.gz};
+  const bool art = c < n;
+  // lane role among the free-body components
+  const int fc = c - n;
+  const bool freel = fc >= 0 && fc < 6 * nf;
+  const int fb_id = freel ? fc / 6 : 0;
+  const int fk = freel ? fc % 6 : 0;  // 0..2 linear xyz, 3..5 angular xyz
+  const int fbase = n + 6 * fb_id;
+
+  // ---------------------------------------------------------------- state
+  const pose_t root = pose_soa(S.root, 0, N, e);
+  const f3 O = root.p;
+  float q_c = 0.f, qd_c = 0.f, qt_c = 0.f, qdt_c = 0.f, qf_c = 0.f;
+  pose_t bp_c = root;
+  f3 aw_c = f3{0, 0, 0}, an_c = f3{0, 0, 0};
+  bool rev_c = false;
+  unsigned anc_c = 0u;
+  float kp = 0.f, kd = 0.f, fmax = 3e38f, arm = 0.f, lo_c = -3e38f, hi_c = 3e38f;
+  float inert[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool grav_c = false, accel_mode = false;
+  if (art) {
+    q_c = SOA(S.q, c); qd_c = SOA(S.qd, c); qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
+    bp_c = pose_soa(S.bodypose, 7 * c, N, e);
+    aw_c = f3{SOA(S.bodyaux, 6 * c), SOA(S.bodyaux, 6 * c + 1), SOA(S.bodyaux, 6 * c + 2)};
+    an_c = f3{SOA(S.bodyaux, 6 * c + 3), SOA(S.bodyaux, 6 * c + 4), SOA(S.bodyaux, 6 * c + 5)};
+    rev_c = M.dof_type[c] == MSSIM_JOINT_REVOLUTE;
+    anc_c = M.dof_anc[c];
+    kp = M.dof_drive[4 * c]; kd = M.dof_drive[4 * c + 1]; fmax = M.dof_drive[4 * c + 2];
+    accel_mode = (int)M.dof_drive[4 * c + 3] == MSSIM_DRIVE_ACCELERATION;
+    arm = M.dof_armature[c];
+    lo_c = M.dof_limit[2 * c]; hi_c = M.dof_limit[2 * c + 1];
+#pragma unroll
+    for (int k = 0; k < 10; k++) inert[k] = M.body_inertial[10 * c + k];
+    grav_c = M.body_gravity[c] != 0;
+  }
+  const unsigned self_c = art ? (1u << c) : 0u;
+
+  // ---------------------------------------------------------------- dynamics: RNEA bias + CRBA
+  sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+  if (art) S_c = rev_c ? sv6{aw_c, cross(an_c - O, aw_c)} : sv6{f3{0, 0, 0}, aw_c};
+  {
+    float* p = L + S16_S + 6 * c;
+    p[0] = S_c.w.x; p[1] = S_c.w.y; p[2] = S_c.w.z; p[3] = S_c.v.x; p[4] = S_c.v.y; p[5] = S_c.v.z;
+    L[S16_VEC + c] = qd_c;
+  }
+  __syncthreads();
+  // V_c = sum over (ancestors + self) of S_i qd_i
+  sv6 V = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+  for (int i = 0; i < n; i++) {
+    float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;
+    const float* p = L + S16_S + 6 * i;
+    V.w += f3{p[0], p[1], p[2]} * m;
+    V.v += f3{p[3], p[4], p[5]} * m;
+  }
+  {
+    sv6 T = crossm(V, S_c);
+    float* p = L + S16_T + 6 * c;
+    p[0] = T.w.x * qd_c; p[1] = T.w.y * qd_c; p[2] = T.w.z * qd_c; p[3] = T.v.x * qd_c; p[4] = T.v.y * qd_c; p[5] = T.v.z * qd_c;
+  }
+  __syncthreads();
+  sv6 Ab = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+  for (int i = 0; i < n; i++) {
+    float m = (((anc_c | self_c) >> i) & 1u) ? 1.f : 0.f;
+    const float* p = L + S16_T + 6 * i;
+    Ab.w += f3{p[0], p[1], p[2]} * m;
+    Ab.v += f3{p[3], p[4], p[5]} * m;
+  }
+  si10 I_c = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
+  sf6 F_c = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
+  if (art) {
+    m3 R = qmat(bp_c.q);
+    s3 Iw = srotate(R, s3{inert[4], inert[5], inert[6], inert[7], inert[8], inert[9]});
+    f3 cm = bp_c.p + mmulv(R, f3{inert[1], inert[2], inert[3]}) - O;
+    float m = inert[0], cc = dot(cm, cm);
+    Iw.xx += m * (cc - cm.x * cm.x); Iw.yy += m * (cc - cm.y * cm.y); Iw.zz += m * (cc - cm.z * cm.z);
+    Iw.xy -= m * cm.x * cm.y; Iw.xz -= m * cm.x * cm.z; Iw.yz -= m * cm.y * cm.z;
+    I_c = si10{m, cm * m, Iw};
+    sf6 f1 = imul(I_c, Ab);
+    sf6 f2 = crossf(V, imul(I_c, V));
+    F_c = sf6{f1.n + f2.n, f1.f + f2.f};
+    if (grav_c) { F_c.f -= g3 * m; F_c.n -= cross(I_c.h, g3); }
+  }
+  {
+    float* p = L + S16_F + 6 * c;
+    p[0] = F_c.n.x; p[1] = F_c.n.y; p[2] = F_c.n.z; p[3] = F_c.f.x; p[4] = F_c.f.y; p[5] = F_c.f.z;
+    float* qI = L + S16_IC + 10 * c;
+    qI[0] = I_c.m; qI[1] = I_c.h.x; qI[2] = I_c.h.y; qI[3] = I_c.h.z;
+    qI[4] = I_c.I.xx; qI[5] = I_c.I.yy; qI[6] = I_c.I.zz; qI[7] = I_c.I.xy; qI[8] = I_c.I.xz; qI[9] = I_c.I.yz;
+#pragma unroll
+    for (int k = 0; k < 16; k++) L[S16_MAT + 16 * c + k] = 0.f;
+  }
+  __syncthreads();
+  // composite force / inertia: sum over (descendants + self)
+  sf6 Fc = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
+  si10 Icc = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
+  for (int k = 0; k < n; k++) {
+    unsigned ak = M.dof_anc[k] | (1u << k);
+    float m = (art && ((ak >> c) & 1u)) ? 1.f : 0.f;
+    const float* p = L + S16_F + 6 * k;
+    Fc.n += f3{p[0], p[1], p[2]} * m;
+    Fc.f += f3{p[3], p[4], p[5]} * m;
+    const float* qI = L + S16_IC + 10 * k;
+    Icc.m += qI[0] * m;
+    Icc.h += f3{qI[1], qI[2], qI[3]} * m;
+    Icc.I.xx += qI[4] * m; Icc.I.yy += qI[5] * m; Icc.I.zz += qI[6] * m;
+    Icc.I.xy += qI[7] * m; Icc.I.xz += qI[8] * m; Icc.I.yz += qI[9] * m;
+  }
+  const float bias_c = sdot(S_c, Fc);
+  {
+    sf6 Fcol = imul(Icc, S_c);
+    for (int i = 0; i < n; i++) {
+      if (art && (((anc_c | self_c) >> i) & 1u)) {
+        const float* p = L + S16_S + 6 * i;
+        float v = dot(f3{p[0], p[1], p[2]}, Fcol.n) + dot(f3{p[3], p[4], p[5]}, Fcol.f);
+        L[S16_MAT + 16 * c + i] = v;
+        L[S16_MAT + 16 * i + c] = v;
+      }
+    }
+  }
+  __syncthreads();
+  float Mrow[16], qdv[16];
+  ld16(L + S16_MAT + 16 * c, Mrow);
+  ld16(L + S16_VEC, qdv);
+  const float Mdiag = L[S16_MAT + 16 * c + c];
+  if (accel_mode) { kp *= Mdiag; kd *= Mdiag; }
+  const float tau0 = kp * (qt_c - q_c) + kd * qdt_c;
+  float Dj = dt * kd + dt * dt * kp;
+  float mv = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) mv += Mrow[k] * qdv[k];
+  // tendons: torque into rhs, implicit stiffness into the matrix row
+  float tau_t = 0.f;
+  float Trow[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) Trow[k] = 0.f;
+  for (int t = 0; t < M.n_tendon; t++) {
+    const int a = M.tendon_dof[2 * t], b = M.tendon_dof[2 * t + 1];
+    const float* tp = M.tendon_param + 5 * t;
+    const float ca = tp[0], cb = tp[1];
+    const float cval = ca * gbc(q_c, a) + cb * gbc(q_c, b) - tp[2];
+    const float w = dt * dt * tp[3] + dt * tp[4];
+    const float cj = c == a ? ca : (c == b ? cb : 0.f);
+    tau_t -= tp[3] * cval * cj;
+#pragma unroll
+    for (int k = 0; k < 16; k++) Trow[k] += w * cj * (k == a ? ca : (k == b ? cb : 0.f));
+  }
+  float rhs_c = art ? mv + dt * (tau0 + tau_t - bias_c + qf_c) : 0.f;
+
+  // ---------------------------------------------------------------- A^-1 by Gauss-Jordan (row per lane)
+  float Irow[16];
+  float vstar = 0.f;
+  for (int pass = 0; pass < 2; pass++) {
+    float Arow[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      Arow[k] = art ? (Mrow[k] + Trow[k] + (k == c ? Dj + arm : 0.f)) : (k == c ? 1.f : 0.f);
+      Irow[k] = k == c ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k >= n) break;
+      __syncthreads();
+      if (c == k) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + 16 + j] = Irow[j]; }
+      }
+      __syncthreads();
+      float PA[16], PI[16];
+      ld16(L + S16_PIV, PA);
+      ld16(L + S16_PIV + 16, PI);
+      const float inv = 1.f / PA[k];
+      const float fac = Arow[k] * inv;
+      const bool piv = c == k;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        Arow[j] = piv ? PA[j] * inv : Arow[j] - fac * PA[j];
+        Irow[j] = piv ? PI[j] * inv : Irow[j] - fac * PI[j];
+      }
+    }
+    __syncthreads();
+    L[S16_VEC + 16 + c] = rhs_c;
+    __syncthreads();
+    float rv[16];
+    ld16(L + S16_VEC + 16, rv);
+    vstar = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) vstar += Irow[k] * rv[k];
+    if (pass == 1) break;
+    // drive force limit: saturated joints get the constant limit torque, lose their implicit terms
+    const float td = kp * (qt_c - q_c - dt * vstar) + kd * (qdt_c - vstar);
+    const bool sat = art && fmax < 1e30f && fabsf(td) > fmax;
+    if (!__any(sat)) break;
+    if (sat) {
+      rhs_c += dt * ((td > 0.f ? fmax : -fmax) - tau0);
+      Dj = 0.f;
+    }
+  }
+  if (!art) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) Irow[k] = 0.f;
+  }
+
+  // ---------------------------------------------------------------- free bodies
+  float v_c = art ? vstar : 0.f;
+  f3 mycom = f3{0, 0, 0};
+  for (int b = 0; b < nf; b++) {
+    const float* in = M.free_inertial + 10 * b;
+    pose_t P = pose_soa(S.free_s, 13 * b, N, e);
+    m3 R = qmat(P.q);
+    s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
+    s3 Ii = sinverse(Iw);
+    const float minv = 1.f / in[0];
+    f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
+    f3 v0 = f3{SOA(S.free_s, 13 * b + 7), SOA(S.free_s, 13 * b + 8), SOA(S.free_s, 13 * b + 9)};
+    f3 w0 = f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)};
+    f3 acc = f3{SOA(S.free_force, 3 * b), SOA(S.free_force, 3 * b + 1), SOA(S.free_force, 3 * b + 2)} * minv;
+    if (M.free_gravity[b]) acc += g3;
+    f3 vv = v0 + acc * dt;
+    f3 ww = w0 - smulv(Ii, cross(w0, smulv(Iw, w0))) * dt;
+    const float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
+    vv = vv * (ld > 0.f ? ld : 0.f);
+    ww = ww * (ad > 0.f ? ad : 0.f);
+    if (c == 0) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
+    if (freel && fb_id == b) {
+      mycom = com;
+      v_c = fk < 3 ? comp(vv, fk) : comp(ww, fk - 3);
+      const f3 irow = fk == 3 ? f3{Ii.xx, Ii.xy, Ii.xz} : (fk == 4 ? f3{Ii.xy, Ii.yy, Ii.yz} : f3{Ii.xz, Ii.yz, Ii.zz});
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        float val = 0.f;
+        if (fk < 3) val = k == c ? minv : 0.f;
+        else val = k == fbase + 3 ? irow.x : (k == fbase + 4 ? irow.y : (k == fbase + 5 ? irow.z : 0.f));
+        Irow[k] = val;
+      }
+    }
+  }
+  __syncthreads();  // the dynamics staging area is dead from here on: rows overlay it
+
+  // ---------------------------------------------------------------- rows
+  float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
+  // joint limits: row j for joint j
+  {
+    const bool has = art && (lo_c > -1e30f || hi_c < 1e30f);
+    const float dlo = q_c - lo_c, dhi = hi_c - q_c;
+    const float C = dlo <= dhi ? dlo : dhi;
+    const float side = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
+    float dself = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      if (j >= n) break;
+      const float sj = gbc(side, j);
+      float* row = L + S16_U + S16_ROWLEN * j;
+      row[c] = c == j ? sj : 0.f;
+      row[16 + c] = sj * Irow[j];
+      if (c == j) dself = Irow[j];
+    }
+    if (art) {
+      float* row = L + S16_U + S16_ROWLEN * c;
+      row[32] = (has && dself > 1e-12f) ? 1.f / dself : 0.f;
+      row[33] = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
+      row[34] = C >= 0.f ? C / dt : 0.f;
+      row[35] = -1.f;  // mu < 0: unilateral row with bounds [0, inf)
+      row[36] = 0.f;
+      row[37] = __int_as_float(-1);
+      row[38] = 0.f; row[39] = 0.f;
+    }
+  }
+  int nrow = n;
+  {
+    int ncontact = 0;
+    for (int w = 0; w < M.n_words; w++) {
+      unsigned bits = S.hit_mask[(size_t)w * N + e];
+      while (__any(bits != 0u)) {
+        const bool act = bits != 0u;
+        const int bit = act ? (__ffs(bits) - 1) : 0;
+        bits = act ? (bits & (bits - 1u)) : 0u;
+        const int p = act ? (w * 32 + bit) : 0;
+        const int cnt = act ? S.pair_cnt[(size_t)p * N + e] : 0;
+        const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
+        if (act && live && c < 3) SOA(S.pair_imp, 3 * p + c) = 0.f;
+        const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+        const int ka = M.shape_kind[sa], kb = M.shape_kind[sb], ia = M.shape_index[sa], ib = M.shape_index[sb];
+        const float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
+        const f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
+        const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
+        const f3 t2 = cross(nrm, t1);
+        // does this lane's component move with side A / side B of the pair?
+        float sgn_art = 0.f;  // for articulation lanes: +1 (A), -1 (B), 0, or both cancel
+        bool mineA = false, mineB = false;
+        if (art) {
+          if (ka == MSSIM_BODY_ART && ia >= 0 && (((M.dof_anc[ia] | (1u << ia)) >> c) & 1u)) mineA = true;
+          if (kb == MSSIM_BODY_ART && ib >= 0 && (((M.dof_anc[ib] | (1u << ib)) >> c) & 1u)) mineB = true;
+          sgn_art = (mineA ? 1.f : 0.f) - (mineB ? 1.f : 0.f);
+        } else if (freel) {
+          mineA = ka == MSSIM_BODY_FREE && ia == fb_id;
+          mineB = kb == MSSIM_BODY_FREE && ib == fb_id;
+        }
+        const float sgn_free = (mineA ? 1.f : 0.f) - (mineB ? 1.f : 0.f);
+        for (int k = 0; k < 4; k++) {
+          const bool ck = act && k < cnt && ncontact < MAXC;
+          if (act && k < cnt && ncontact >= MAXC && live && c == 0) S.overflow[e] = 1;
+          if (!__any(ck)) break;
+          const int kk = ck ? k : 0;
+          const f3 x = f3{pd[(size_t)(3 + 4 * kk) * N], pd[(size_t)(4 + 4 * kk) * N], pd[(size_t)(5 + 4 * kk) * N]};
+          const float sep = pd[(size_t)(6 + 4 * kk) * N];
+          // per-lane geometric factor of this contact point
+          f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
+          if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
+          const f3 r = x - mycom;
+#pragma unroll
+          for (int dk = 0; dk < 3; dk++) {
+            const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
+            float J = 0.f;
+            if (art) J = sgn_art * dot(d, col);
+            else if (freel) J = sgn_free * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
+            __syncthreads();
+            L[S16_VEC + 32 + c] = J;
+            __syncthreads();
+            float Jv[16];
+            ld16(L + S16_VEC + 32, Jv);
+            float W = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) W += Irow[j] * Jv[j];
+            const float diag = gsum16(J * W);
+            const int r_idx = nrow + dk;
+            if (ck) {
+              float* row = r_idx < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * r_idx) : (grow + (size_t)S16_ROWLEN * (r_idx - S16_ROWS_LDS));
+              if (r_idx < S16_ROWS_LDS || live) {
+                row[c] = J;
+                row[16 + c] = W;
+                if (c == 0) {
+                  row[32] = diag > 1e-12f ? 1.f / diag : 0.f;
+                  row[33] = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
+                  row[34] = dk == 0 ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
+                  row[35] = dk == 0 ? -1.f : mu;
+                  row[36] = 0.f;
+                  row[37] = __int_as_float(p);
+                  row[38] = __int_as_float(dk);
+                  row[39] = 0.f;
+                }
+              }
+            }
+          }
+          if (ck) { nrow += 3; ncontact++; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- projected Gauss-Seidel
+  const int nr_lds = nrow < S16_ROWS_LDS ? nrow : S16_ROWS_LDS;
+  const int nr_glb = nrow - nr_lds;
+  int max_lds = nr_lds, max_glb = nr_glb;
+#pragma unroll
+  for (int o = 32; o >= 16; o >>= 1) {
+    max_lds = max(max_lds, __shfl_xor(max_lds, o));
+    max_glb = max(max_glb, __shfl_xor(max_glb, o));
+  }
+  float vpos_c = v_c;
+  float lam_n = 0.f;
+  // one Gauss-Seidel row: the record of the NEXT row is loaded before the dependent chain of the
+  // current one starts (LDS ops are in order per wave, so the lambda store below cannot pass them)
+  struct RowRec {
+    float J, W, lam;
+    float4 s;  // invd, bpos, bvel, mu
+  };
+  auto row_load = [&](const float* row, RowRec& R) __attribute__((always_inline)) {
+    R.J = row[c];
+    R.W = row[16 + c];
+    R.s = *reinterpret_cast<const float4*>(row + 32);
+    R.lam = row[36];
+  };
+  auto row_apply = [&](const RowRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
+    const float jv = gsum16(R.J * v_c);
+    const bool unilateral = R.s.w < 0.f;
+    const float hi = unilateral ? 1e30f : R.s.w * lam_n;
+    const float lo = unilateral ? 0.f : -hi;
+    const float b = use_bias ? R.s.y : R.s.z;
+    float nl = R.lam - (jv + b) * R.s.x;
+    nl = fminf(fmaxf(nl, lo), hi);
+    // inactive slots (another env of this wave has more rows) hold garbage: never touch v with them
+    const bool upd = active && R.s.x > 0.f;
+    nl = upd ? nl : R.lam;
+    lam_n = (unilateral && active) ? nl : lam_n;
+    v_c = upd ? fmaf(R.W, nl - R.lam, v_c) : v_c;
+    if (c == 0 && active) row[36] = nl;
+  };
+  const int n_iters = M.pos_iters + M.vel_iters;
+  for (int it = 0; it <= n_iters; it++) {
+    if (it == M.pos_iters) {
+      vpos_c = v_c;
+      q_c += dt * v_c;
+      for (int b = 0; b < nf; b++) {
+        const float* in = M.free_inertial + 10 * b;
+        const int base = n + 6 * b;
+        f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
+        f3 ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
+        f3 com = f3{L[S16_COM + 3 * b], L[S16_COM + 3 * b + 1], L[S16_COM + 3 * b + 2]} + vv * dt;
+        q4 qq = qnormalized(q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)});
+        q4 dq = qmul(q4{0.f, ww.x, ww.y, ww.z}, qq);
+        qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
+        f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
+        if (c == 0 && live) {
+          SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
+          SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
+        }
+      }
+    }
+    if (it == n_iters) break;
+    const bool use_bias = it < M.pos_iters;
+    lam_n = 0.f;
+    // joint-limit rows: skip the sequential pass when no row of the whole wave would change
+    int r0 = n;
+    {
+      const float* row = L + S16_U + S16_ROWLEN * (art ? c : 0);
+      const float invd = row[32], b = use_bias ? row[33] : row[34], lam = row[36];
+      float nl = lam - (row[c] * v_c + b) * invd;  // J of row c is +-1 at lane c
+      nl = nl < 0.f ? 0.f : nl;
+      const bool changed = art && invd > 0.f && nl != lam;
+      if (__any(changed)) r0 = 0;
+    }
+    if (r0 < max_lds) {
+      RowRec A, B;
+      float* base = L + S16_U;
+      row_load(base + S16_ROWLEN * r0, A);
+      int r = r0;
+      while (true) {
+        if (r + 1 < max_lds) row_load(base + S16_ROWLEN * (r + 1), B);
+        row_apply(A, base + S16_ROWLEN * r, r < nr_lds, use_bias);
+        if (++r >= max_lds) break;
+        if (r + 1 < max_lds) row_load(base + S16_ROWLEN * (r + 1), A);
+        row_apply(B, base + S16_ROWLEN * r, r < nr_lds, use_bias);
+        if (++r >= max_lds) break;
+      }
+    }
+    for (int r = 0; r < max_glb; r++) {
+      const bool active = r < nr_glb;
+      float* row = grow + (size_t)S16_ROWLEN * (active ? r : 0);
+      RowRec A;
+      row_load(row, A);
+      row_apply(A, row, active && live, use_bias);
+    }
+  }
+
+  // ---------------------------------------------------------------- contact impulses per pair
+  {
+    int prev_p = -1;
+    f3 acc = f3{0, 0, 0};
+    const int ncon = (nrow - n) / 3;
+    for (int i = 0; i < ncon; i++) {
+      const int r = n + 3 * i;
+      const float* row = r < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * r) : (grow + (size_t)S16_ROWLEN * (r - S16_ROWS_LDS));
+      // rows of one contact are consecutive and never straddle the LDS / global boundary? they can:
+      const float* row1 = (r + 1) < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * (r + 1)) : (grow + (size_t)S16_ROWLEN * (r + 1 - S16_ROWS_LDS));
+      const float* row2 = (r + 2) < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * (r + 2)) : (grow + (size_t)S16_ROWLEN * (r + 2 - S16_ROWS_LDS));
+      const int p = __float_as_int(row[37]);
+      const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
+      const f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
+      const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
+      const f3 t2 = cross(nrm, t1);
+      const f3 imp = nrm * row[36] + t1 * row1[36] + t2 * row2[36];
+      if (p != prev_p) {
+        if (prev_p >= 0 && c == 0 && live) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
+        acc = f3{0, 0, 0};
+        prev_p = p;
+      }
+      acc += imp;
+    }
+    if (prev_p >= 0 && c == 0 && live) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
+  }
+
+  // ---------------------------------------------------------------- write back + FK at the new state
+  if (art && live) {
+    SOA(S.qacc, c) = (v_c - qd_c) / dt;
+    SOA(S.q, c) = q_c;
+    SOA(S.qd, c) = v_c;
+  }
+  if (freel && live) {
+    SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
+    if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
+  }
+  __syncthreads();
+  // sequential FK (a product chain); every lane runs it, lane j keeps body j
+  pose_t nb = root;
+  f3 naw = f3{0, 0, 0}, nan = f3{0, 0, 0};
+  for (int j = 0; j < n; j++) {
+    const int pj = M.dof_parent[j];
+    pose_t P = root;
+    if (pj >= 0) {
+      const float* b = L + S16_BP + 7 * pj;
+      P = pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}};
+    }
+    pose_t Jp = pmul(P, pose_from(M.dof_frame + 7 * j));
+    const f3 al = f3{M.dof_axis[3 * j], M.dof_axis[3 * j + 1], M.dof_axis[3 * j + 2]};
+    const f3 a = qrot(Jp.q, al);
+    const float qj = gbc(q_c, j);
+    pose_t B = Jp;
+    if (M.dof_type[j] == MSSIM_JOINT_REVOLUTE) B.q = qnormalized(qmul(Jp.q, qaxis_angle(al, qj)));
+    else B.p = Jp.p + a * qj;
+    if (c == 0) {
+      float* b = L + S16_BP + 7 * j;
+      b[0] = B.p.x; b[1] = B.p.y; b[2] = B.p.z; b[3] = B.q.w; b[4] = B.q.x; b[5] = B.q.y; b[6] = B.q.z;
+    }
+    if (c == j) { nb = B; naw = a; nan = Jp.p; }
+    __syncthreads();
+  }
+  // body velocities about O with the new subspaces
+  sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+  if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
+  {
+    float* p = L + S16_S + 6 * c;
+    p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
+    L[S16_VEC + c] = art ? v_c : 0.f;
+  }
+  __syncthreads();
+  sv6 nV = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+  for (int i = 0; i < n; i++) {
+    float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;
+    const float* p = L + S16_S + 6 * i;
+    nV.w += f3{p[0], p[1], p[2]} * m;
+    nV.v += f3{p[3], p[4], p[5]} * m;
+  }
+  if (art && live) {
+    pose_store_soa(S.bodypose, 7 * c, N, e, nb);
+    float* o = S.bodyvel + (size_t)(6 * c) * N + e;
+    o[0] = nV.w.x; o[(size_t)N] = nV.w.y; o[2 * (size_t)N] = nV.w.z;
+    o[3 * (size_t)N] = nV.v.x; o[4 * (size_t)N] = nV.v.y; o[5 * (size_t)N] = nV.v.z;
+    float* a = S.bodyaux + (size_t)(6 * c) * N + e;
+    a[0] = naw.x; a[(size_t)N] = naw.y; a[2 * (size_t)N] = naw.z;
+    a[3 * (size_t)N] = nan.x; a[4 * (size_t)N] = nan.y; a[5 * (size_t)N] = nan.z;
+  }
+  if (live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
+}

@@ -27,8 +27,9 @@ rest_dn = torch.tensor([0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, np.pi
 rec = panda_record(); rec.link_shapes = {}
 b = SceneModelBuilder(); b.set_articulation(rec)
 run("robot only (no shapes)", b.compile(), rest_up)
-b = SceneModelBuilder(); b.add_actor(table_record()); b.add_actor(ground_record()); b.add_actor(cube_record())
-run("cube on table only", b.compile())
+for iters in (15, 7, 1):
+    b = SceneModelBuilder(); b.add_actor(table_record()); b.add_actor(ground_record()); b.add_actor(cube_record())
+    run(f"cube on table, {iters} pos iters", b.compile(position_iterations=iters))
 run("full scene, arm up", panda_tabletop_model(), rest_up)
 run("full scene, arm near table", panda_tabletop_model(), rest_dn)
 q = rest_dn.clone(); q[1] = 0.62  # fingers pressed onto the table
