@@ -209,6 +209,34 @@ int MSSIM_FN(read_internal)(mssim_handle h, const char* name, float* out, int32_
 /* capacity overflow must be a reported condition (SURVEY 8b error conventions): number of envs
  * whose solver row capacity was exceeded since the last call (synchronises the stream). */
 int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
+/* ---- fused callers of the step: what the reference does with ~10 + ~100 tiny
+ * torch kernels per control step around px.step(), as one launch each. Results are identical to
+ * the torch restatements in maniskill_amd/agents/controllers and envs/tasks (parity-tested). ----
+ *
+ * Affine action -> joint drive targets, for every PD joint-position style controller
+ * (agents/controllers/pd_joint_pos.py:73-90, base_controller.py:120-133, utils/gym_utils.py:102-105):
+ *   a = action[env][column[j]];  if (flags[j] & 2) a = low[j] + 0.5*(clip(a,-1,1)+1)*(high[j]-low[j]);
+ *   target[j] = (flags[j] & 1 ? qpos[j] : 0) + a        (column[j] < 0: joint left untouched)
+ * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host. */
+int MSSIM_FN(set_action_map)(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags);
+int MSSIM_FN(apply_action)(mssim_handle h, const float* action /* device [N][action_dim] */, int32_t action_dim, void* stream);
+
+/* PickCube-style evaluate + state observation + dense reward in one launch
+ * (envs/tasks/tabletop/pick_cube.py:99-158, agents/robots/panda/panda.py:236-298). Reads the
+ * user-visible buffers (after fetch) and the last substep's contact impulses. */
+typedef struct mssim_pick_task {
+  int32_t tcp_row, obj_row, goal_row, finger1_row, finger2_row; /* rigid_body_data body rows */
+  int32_t n_static_dofs;      /* qvel[:n] used by is_static and the static reward (7 for the Panda) */
+  float goal_thresh;          /* 0.025 */
+  float static_thresh;        /* 0.2   */
+  float min_force;            /* 0.5 N */
+  float max_angle_deg;        /* 85    */
+  float reward_scale;         /* 1 (dense) or 1/5 (normalized_dense) */
+} mssim_pick_task;
+/* obs [N][2*n_dof+24] f32 (qpos, qvel, is_grasped, tcp_pose7, goal_pos3, obj_pose7, tcp_to_obj3,
+ * obj_to_goal3), reward [N] f32, flags [N][4] u8 = success, is_obj_placed, is_robot_static, is_grasped */
+int MSSIM_FN(task_pick_outputs)(mssim_handle h, const mssim_pick_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
+
 /* Measurement aid (bench.py roofline block): when enabled, every k_solve / k_narrow launch inside
  * mssim_step is bracketed by HIP events on the SAME stream it is launched on. profile_read
  * synchronises, returns the accumulated milliseconds and launch counts since the last read

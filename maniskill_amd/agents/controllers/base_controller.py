@@ -187,6 +187,20 @@ class CombinedController(DictController):
             s, e = self.action_mapping[uid]
             c.set_action(action[:, s:e])
 
+    def fused_action_spec(self):
+        """per-dof (column, low, high, flags) arrays for `px.set_action_map`, or None if any
+        sub-controller cannot be expressed as an affine action -> target map"""
+        n = self.articulation.max_dof
+        col, lo, hi, fl = [-1] * n, [0.0] * n, [0.0] * n, [0] * n
+        for uid, c in self.controllers.items():
+            spec = getattr(c, "fused_action_spec", lambda: None)()
+            if spec is None:
+                return None
+            start, _ = self.action_mapping[uid]
+            for dof, lcol, l, h, f in spec:
+                col[dof], lo[dof], hi[dof], fl[dof] = start + lcol, l, h, f
+        return col, lo, hi, fl
+
     def to_action_dict(self, action):
         return {uid: action[s:e] for uid, (s, e) in self.action_mapping.items()}
 

@@ -75,6 +75,21 @@ class PDJointPosController(BaseController):
             self.set_drive_targets(self._start_qpos + self._step_size * self._step)
             self.articulation.px.gpu_apply_articulation_target_position()
 
+    def fused_action_spec(self):
+        """[(dof, local action column, low, high, flags)] for the fused native action kernel, or None
+        when this controller keeps state across steps (use_target) or updates targets per substep"""
+        if self.config.use_target or self.config.interpolate:
+            return None
+        nact = self.single_action_space.shape[0]
+        out = []
+        for i, dof in enumerate(self.active_joint_indices.tolist()):
+            col = i if nact == len(self.joints) else 0  # mimic controllers broadcast one column
+            lo = float(self.action_space_low[col]) if self._normalize_action else 0.0
+            hi = float(self.action_space_high[col]) if self._normalize_action else 0.0
+            flags = (1 if self.config.use_delta else 0) | (2 if self._normalize_action else 0)
+            out.append((dof, col, lo, hi, flags))
+        return out
+
     def get_state(self) -> dict:
         return {"target_qpos": self._target_qpos} if self.config.use_target else {}
 

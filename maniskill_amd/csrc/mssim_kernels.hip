@@ -972,6 +972,98 @@ __global__ void k_query(DevModel M, DevState S, const int* q, int nq, int body_q
   o[0] = s.x; o[1] = s.y; o[2] = s.z;
 }
 
+// affine action -> drive targets (user-visible buffer + simulation state)
+__global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const float* __restrict__ action, int adim,
+                               const int* __restrict__ col, const float* __restrict__ lo, const float* __restrict__ hi,
+                               const int* __restrict__ flags) {
+  const int N = S.N;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  for (int j = 0; j < n; j++) {
+    const int cj = col[j];
+    if (cj < 0) continue;
+    float a = action[(size_t)e * adim + cj];
+    if (flags[j] & 2) {
+      a = fminf(fmaxf(a, -1.f), 1.f);
+      a = 0.5f * (hi[j] + lo[j]) + 0.5f * (hi[j] - lo[j]) * a;
+    }
+    const float qj = B.art_qpos ? B.art_qpos[(size_t)e * n + j] : SOA(S.q, j);  // what `controller.qpos` reads
+    const float t = ((flags[j] & 1) ? qj : 0.f) + a;
+    SOA(S.qt, j) = t;
+    if (B.art_target_qpos) B.art_target_qpos[(size_t)e * n + j] = t;
+  }
+}
+
+// PickCube-style evaluate / obs / reward
+__global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_task T, float* __restrict__ obs, float* __restrict__ reward,
+                            uint8_t* __restrict__ flags) {
+  const int N = S.N;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  const int D = 2 * n + 24;
+  float* o = obs + (size_t)e * D;
+  auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
+  float qv_max = 0.f, qv_sq = 0.f;
+  for (int j = 0; j < n; j++) {
+    const float q = B.art_qpos[(size_t)e * n + j], v = B.art_qvel[(size_t)e * n + j];
+    o[j] = q;
+    o[n + j] = v;
+    if (j < T.n_static_dofs) { qv_max = fmaxf(qv_max, fabsf(v)); qv_sq += v * v; }
+  }
+  const float* tcp = rowp(T.tcp_row);
+  const float* ob = rowp(T.obj_row);
+  const float* gl = rowp(T.goal_row);
+  const f3 ptcp = f3{tcp[0], tcp[1], tcp[2]}, pobj = f3{ob[0], ob[1], ob[2]}, pgoal = f3{gl[0], gl[1], gl[2]};
+  // pairwise contact impulses finger <-> object during the last substep (scene.py:736-796)
+  f3 lf = f3{0, 0, 0}, rf = f3{0, 0, 0};
+  for (int p = 0; p < M.n_pair; p++) {
+    const int ra = M.shape_row[M.pair_shape[2 * p]], rb = M.shape_row[M.pair_shape[2 * p + 1]];
+    const bool a_obj = ra == T.obj_row, b_obj = rb == T.obj_row;
+    if (!(a_obj || b_obj)) continue;
+    const int other = a_obj ? rb : ra;
+    if (other != T.finger1_row && other != T.finger2_row) continue;
+    if (S.pair_cnt[(size_t)p * N + e] <= 0) continue;
+    // impulse on the finger from the object: +imp if the finger is shape A, -imp otherwise
+    f3 imp = f3{SOA(S.pair_imp, 3 * p), SOA(S.pair_imp, 3 * p + 1), SOA(S.pair_imp, 3 * p + 2)} * (a_obj ? -1.f : 1.f);
+    if (other == T.finger1_row) lf += imp; else rf += imp;
+  }
+  const float inv_dt = 1.f / M.dt;
+  lf = lf * inv_dt; rf = rf * inv_dt;
+  auto yaxis = [&](const float* r) { return mcol(qmat(qnormalized(q4{r[3], r[4], r[5], r[6]})), 1); };
+  auto angle_deg = [&](f3 a, f3 b) {
+    const float na = norm(a), nb = norm(b);
+    a = a * (1.f / (na < 1e-6f ? 1.f : na));
+    b = b * (1.f / (nb < 1e-6f ? 1.f : nb));
+    return acosf(fminf(fmaxf(dot(a, b), -1.f), 1.f)) * 57.29577951308232f;
+  };
+  const f3 ldir = yaxis(rowp(T.finger1_row)), rdir = -yaxis(rowp(T.finger2_row));
+  const bool lflag = norm(lf) >= T.min_force && angle_deg(ldir, lf) <= T.max_angle_deg;
+  const bool rflag = norm(rf) >= T.min_force && angle_deg(rdir, rf) <= T.max_angle_deg;
+  const bool grasped = lflag && rflag;
+  const float d_goal = norm(pgoal - pobj);
+  const bool placed = d_goal <= T.goal_thresh;
+  const bool is_static = qv_max <= T.static_thresh;
+  const bool success = placed && is_static;
+  // observation
+  int k = 2 * n;
+  o[k++] = grasped ? 1.f : 0.f;
+  for (int i = 0; i < 7; i++) o[k++] = tcp[i];
+  o[k++] = pgoal.x; o[k++] = pgoal.y; o[k++] = pgoal.z;
+  for (int i = 0; i < 7; i++) o[k++] = ob[i];
+  o[k++] = pobj.x - ptcp.x; o[k++] = pobj.y - ptcp.y; o[k++] = pobj.z - ptcp.z;
+  o[k++] = pgoal.x - pobj.x; o[k++] = pgoal.y - pobj.y; o[k++] = pgoal.z - pobj.z;
+  // dense reward (pick_cube.py:128-158)
+  float r = 1.f - tanhf(5.f * norm(pobj - ptcp));
+  if (grasped) r += 1.f + (1.f - tanhf(5.f * d_goal));
+  if (placed) r += 1.f - tanhf(5.f * sqrtf(qv_sq));
+  if (success) r = 5.f;
+  reward[e] = r * T.reward_scale;
+  uint8_t* f = flags + 4 * (size_t)e;
+  f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
+}
+
 __global__ void k_i2f(const int* src, float* dst, size_t count) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < count) dst[i] = (float)src[i];
@@ -996,6 +1088,7 @@ struct mssim_sim {
   std::string err;
   int row_fields = 0;
   // profiling (bench roofline block): event pairs recorded on the launch stream
+  int* d_act_col = nullptr; float* d_act_lo = nullptr; float* d_act_hi = nullptr; int* d_act_flags = nullptr;
   unsigned solve_lds_bytes = 0;
   bool coop = false;  // use k_solve16
   bool profiling = false;
@@ -1234,6 +1327,39 @@ int mssim_profile_read(mssim_handle h, float* out_ms, int32_t* out_counts) {
     out_counts[k] = (int32_t)pairs;
     h->ev_used[k] = 0;
   }
+  return 0;
+}
+
+int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags) {
+  HIPCHK(h, hipSetDevice(h->device));
+  const int n = h->M.n_dof > 0 ? h->M.n_dof : 1;
+  if (!h->d_act_col) {
+    int rc;
+    if ((rc = dalloc(h, n, &h->d_act_col)) || (rc = dalloc(h, n, &h->d_act_lo)) || (rc = dalloc(h, n, &h->d_act_hi)) || (rc = dalloc(h, n, &h->d_act_flags))) return rc;
+  }
+  HIPCHK(h, hipMemcpy(h->d_act_col, column, sizeof(int) * h->M.n_dof, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_act_lo, low, sizeof(float) * h->M.n_dof, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_act_hi, high, sizeof(float) * h->M.n_dof, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_act_flags, flags, sizeof(int) * h->M.n_dof, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mssim_apply_action(mssim_handle h, const float* action, int32_t action_dim, void* stream) {
+  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, action, action_dim,
+                     h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_task_pick_outputs(mssim_handle h, const mssim_pick_task* task, float* obs, float* reward, uint8_t* flags, void* stream) {
+  const int R = h->M.n_link + h->M.n_free + h->M.n_kin;
+  const int rows[5] = {task->tcp_row, task->obj_row, task->goal_row, task->finger1_row, task->finger2_row};
+  for (int r : rows)
+    if (r < 0 || r >= R) { h->err = "task_pick_outputs: body row out of range"; return 1; }
+  if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
+  hipLaunchKernelGGL(k_task_pick, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, obs, reward, flags);
+  HIPCHK(h, hipGetLastError());
   return 0;
 }
 

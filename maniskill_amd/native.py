@@ -118,6 +118,14 @@ def make_model_desc(model: CompiledModel):
     return d, keep
 
 
+class PickTask(C.Structure):
+    _fields_ = [
+        ("tcp_row", C.c_int32), ("obj_row", C.c_int32), ("goal_row", C.c_int32), ("finger1_row", C.c_int32), ("finger2_row", C.c_int32),
+        ("n_static_dofs", C.c_int32), ("goal_thresh", C.c_float), ("static_thresh", C.c_float), ("min_force", C.c_float),
+        ("max_angle_deg", C.c_float), ("reward_scale", C.c_float),
+    ]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -154,6 +162,9 @@ class NativeLib:
         f("set_drive_properties", C.c_int, [H, _F32P])
         f("read_internal", C.c_int, [H, C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p])
         f("overflow_count", C.c_int, [H, C.c_void_p])
+        f("set_action_map", C.c_int, [H, _I32P, _F32P, _F32P, _I32P])
+        f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
+        f("task_pick_outputs", C.c_int, [H, C.POINTER(PickTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("profile_enable", C.c_int, [H, C.c_int32])
         f("profile_read", C.c_int, [H, _F32P, _I32P])
         f("last_error", C.c_char_p, [H])
@@ -164,7 +175,8 @@ class NativeLib:
     EXPORTS = [
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
-        "query_body_impulses", "set_drive_properties", "read_internal", "overflow_count", "profile_enable",
+        "query_body_impulses", "set_drive_properties", "read_internal", "overflow_count", "set_action_map",
+        "apply_action", "task_pick_outputs", "profile_enable",
         "profile_read", "last_error",
         "abi_version",
     ]
@@ -265,6 +277,20 @@ class NativeSim:
         if n < 0:
             self._check(n, f"read_internal({name})")
         return n
+
+    def set_action_map(self, column, low, high, flags):
+        col = np.ascontiguousarray(column, dtype=np.int32)
+        lo = np.ascontiguousarray(low, dtype=np.float32)
+        hi = np.ascontiguousarray(high, dtype=np.float32)
+        fl = np.ascontiguousarray(flags, dtype=np.int32)
+        assert len(col) == len(lo) == len(hi) == len(fl) == self.model.n_dof
+        self._check(self.lib.set_action_map(self.h, col.ctypes.data_as(_I32P), lo.ctypes.data_as(_F32P), hi.ctypes.data_as(_F32P), fl.ctypes.data_as(_I32P)), "set_action_map")
+
+    def apply_action(self, action_ptr, action_dim, stream=None):
+        self._check(self.lib.apply_action(self.h, action_ptr, action_dim, stream), "apply_action")
+
+    def task_pick_outputs(self, task: "PickTask", obs_ptr, reward_ptr, flags_ptr, stream=None):
+        self._check(self.lib.task_pick_outputs(self.h, C.byref(task), obs_ptr, reward_ptr, flags_ptr, stream), "task_pick_outputs")
 
     def profile_enable(self, on=True):
         self._check(self.lib.profile_enable(self.h, 1 if on else 0), "profile_enable")

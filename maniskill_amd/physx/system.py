@@ -278,6 +278,22 @@ class MssimSystem:
         n = self._sim.read_internal(name, out.data_ptr(), max_items, self._stream())
         return out[:n]
 
+    # ------------------------------------------------------------------ fused callers (HIP only)
+    @property
+    def supports_fused_callers(self) -> bool:
+        return self.backend == "physx_cuda"
+
+    def set_action_map(self, column, low, high, flags):
+        self._sim.set_action_map(column, low, high, flags)
+
+    def apply_action(self, action: torch.Tensor):
+        """affine action -> drive targets in one launch (include/mssim.h `apply_action`)"""
+        assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs
+        self._sim.apply_action(action.data_ptr(), action.shape[1], self._stream())
+
+    def task_pick_outputs(self, task, obs: torch.Tensor, reward: torch.Tensor, flags: torch.Tensor):
+        self._sim.task_pick_outputs(task, obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), self._stream())
+
     def profile_enable(self, on: bool = True):
         """bracket the solve / narrowphase launches with HIP events on their launch stream"""
         self._sim.profile_enable(on)

@@ -780,6 +780,10 @@ int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_
   return items;
 }
 
+// fused callers are an optimisation of the HIP product; the oracle keeps the plain (torch) path
+int mssim_ref_set_action_map(mssim_handle h, const int32_t*, const float*, const float*, const int32_t*) { h->err = "not available in the oracle"; return 1; }
+int mssim_ref_apply_action(mssim_handle h, const float*, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
+int mssim_ref_task_pick_outputs(mssim_handle h, const mssim_pick_task*, float*, float*, uint8_t*, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_profile_enable(mssim_handle, int32_t) { return 0; }
 int mssim_ref_profile_read(mssim_handle, float* ms, int32_t* cnt) { ms[0] = ms[1] = 0; cnt[0] = cnt[1] = 0; return 0; }
 

@@ -70,3 +70,31 @@ def test_env_rollout_matches_oracle_backend():
         env.close()
     for a, b in zip(*outs):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
+
+
+def test_fused_callers_match_torch_path(monkeypatch):
+    """the fused native action map + PickCube epilogue give the same step outputs as the torch path"""
+    import gymnasium as gym
+
+    N = 256
+    g = torch.Generator().manual_seed(3)
+    acts = [2 * torch.rand(N, 8, generator=g) - 1 for _ in range(12)]
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MS_FUSED", fused)
+        env = gym.make("PickCube-v1", num_envs=N, sim_backend="physx_cuda")
+        assert env.unwrapped._use_fused_callers == (fused == "1")
+        obs, _ = env.reset(seed=5)
+        traj = []
+        for a in acts:
+            obs, rew, term, trunc, info = env.step(a.cuda())
+            traj.append((obs.cpu().clone(), rew.cpu().clone(), term.cpu().clone(), {k: v.cpu().clone() for k, v in info.items()}))
+        outs.append(traj)
+        env.close()
+    for (o1, r1, t1, i1), (o2, r2, t2, i2) in zip(*outs):
+        assert torch.allclose(o1, o2, atol=1e-5), (o1 - o2).abs().max()
+        assert torch.allclose(r1, r2, atol=1e-5)
+        assert torch.equal(t1, t2)
+        assert i1.keys() == i2.keys()
+        for k in i1:
+            assert torch.equal(i1[k], i2[k]), k
