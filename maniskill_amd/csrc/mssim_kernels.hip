@@ -1290,7 +1290,7 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
       prof_mark(h, 1, st);
     }
     prof_mark(h, 0, st);
-    if (h->coop) hipLaunchKernelGGL(k_solve16, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(64), 0, st, h->M, h->S);
+    if (h->coop) hipLaunchKernelGGL(k_solve16, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S);
     else if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);

@@ -16,7 +16,9 @@
 #pragma once
 
 #define S16_LANES 16
+#ifndef S16_ENVS_PER_BLOCK
 #define S16_ENVS_PER_BLOCK 4
+#endif
 // per-env LDS layout (floats)
 #define S16_COM 0      // [8][3] free-body centres of mass
 #define S16_VEC 32     // 4 x [16] scratch vectors
@@ -58,7 +60,7 @@ MS_DEV void ld16(const float* p, float* out) {  // 16 consecutive floats (16-B a
   }
 }
 
-__global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
+__global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S) {
   __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   const int N = S.N;
   const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -336,6 +338,8 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
     }
   }
   int nrow = n;
+  // contact rows come in blocks of 3 (normal, t1, t2): keep whole blocks on one side of the LDS boundary
+  const int lds_limit = n + 3 * ((S16_ROWS_LDS - n) / 3);
   {
     int ncontact = 0;
     for (int w = 0; w < M.n_words; w++) {
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
           f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
           if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
           const f3 r = x - mycom;
+          float Wprev0 = 0.f, Wprev1 = 0.f;
 #pragma unroll
           for (int dk = 0; dk < 3; dk++) {
             const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
@@ -392,10 +397,16 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
 #pragma unroll
             for (int j = 0; j < 16; j++) W += Irow[j] * Jv[j];
             const float diag = gsum16(J * W);
+            // Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
+            float ga = 0.f, gb = 0.f;
+            if (dk == 1) ga = gsum16(J * Wprev0);
+            if (dk == 2) { ga = gsum16(J * Wprev0); gb = gsum16(J * Wprev1); }
+            if (dk == 0) Wprev0 = W;
+            if (dk == 1) Wprev1 = W;
             const int r_idx = nrow + dk;
             if (ck) {
-              float* row = r_idx < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * r_idx) : (grow + (size_t)S16_ROWLEN * (r_idx - S16_ROWS_LDS));
-              if (r_idx < S16_ROWS_LDS || live) {
+              float* row = r_idx < lds_limit ? (L + S16_U + S16_ROWLEN * r_idx) : (grow + (size_t)S16_ROWLEN * (r_idx - lds_limit));
+              if (r_idx < lds_limit || live) {
                 row[c] = J;
                 row[16 + c] = W;
                 if (c == 0) {
@@ -405,8 +416,8 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
                   row[35] = dk == 0 ? -1.f : mu;
                   row[36] = 0.f;
                   row[37] = __int_as_float(p);
-                  row[38] = __int_as_float(dk);
-                  row[39] = 0.f;
+                  row[38] = ga;
+                  row[39] = gb;
                 }
               }
             }
@@ -419,44 +430,67 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
   __syncthreads();
 
   // ---------------------------------------------------------------- projected Gauss-Seidel
-  const int nr_lds = nrow < S16_ROWS_LDS ? nrow : S16_ROWS_LDS;
-  const int nr_glb = nrow - nr_lds;
-  int max_lds = nr_lds, max_glb = nr_glb;
+  const int nr_lds = nrow < lds_limit ? nrow : lds_limit;  // rows held in LDS (limits + whole contact blocks)
+  const int nc_lds = (nr_lds - n) / 3, nc_glb = (nrow - nr_lds) / 3;
+  int max_clds = nc_lds, max_cglb = nc_glb;
 #pragma unroll
-  for (int o = 32; o >= 16; o >>= 1) {
-    max_lds = max(max_lds, __shfl_xor(max_lds, o));
-    max_glb = max(max_glb, __shfl_xor(max_glb, o));
+  for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) {
+    max_clds = max(max_clds, __shfl_xor(max_clds, o));
+    max_cglb = max(max_cglb, __shfl_xor(max_cglb, o));
   }
   float vpos_c = v_c;
-  float lam_n = 0.f;
-  // one Gauss-Seidel row: the record of the NEXT row is loaded before the dependent chain of the
-  // current one starts (LDS ops are in order per wave, so the lambda store below cannot pass them)
-  struct RowRec {
-    float J, W, lam;
-    float4 s;  // invd, bpos, bvel, mu
+  // single (joint-limit) row
+  auto limit_row = [&](float* row, bool use_bias) __attribute__((always_inline)) {
+    const float J = row[c], W = row[16 + c];
+    const float4 s = *reinterpret_cast<const float4*>(row + 32);
+    const float lam = row[36];
+    const float jv = gsum16(J * v_c);
+    float nl = fmaxf(lam - (jv + (use_bias ? s.y : s.z)) * s.x, 0.f);
+    nl = s.x > 0.f ? nl : lam;
+    v_c = fmaf(W, nl - lam, v_c);
+    if (c == 0) row[36] = nl;
   };
-  auto row_load = [&](const float* row, RowRec& R) __attribute__((always_inline)) {
-    R.J = row[c];
-    R.W = row[16 + c];
-    R.s = *reinterpret_cast<const float4*>(row + 32);
-    R.lam = row[36];
+  // one contact = block of 3 rows. The three J.v reductions are independent (issued back to back);
+  // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
+  // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
+  // the dependent reduction chains.
+  struct ConRec {
+    float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, g10, g20, g21;
+    float4 s0, s1, s2;
   };
-  auto row_apply = [&](const RowRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
-    const float jv = gsum16(R.J * v_c);
-    const bool unilateral = R.s.w < 0.f;
-    const float hi = unilateral ? 1e30f : R.s.w * lam_n;
-    const float lo = unilateral ? 0.f : -hi;
-    const float b = use_bias ? R.s.y : R.s.z;
-    float nl = R.lam - (jv + b) * R.s.x;
-    nl = fminf(fmaxf(nl, lo), hi);
-    // inactive slots (another env of this wave has more rows) hold garbage: never touch v with them
-    const bool upd = active && R.s.x > 0.f;
-    nl = upd ? nl : R.lam;
-    lam_n = (unilateral && active) ? nl : lam_n;
-    v_c = upd ? fmaf(R.W, nl - R.lam, v_c) : v_c;
-    if (c == 0 && active) row[36] = nl;
+  auto con_load = [&](const float* row, ConRec& R) __attribute__((always_inline)) {
+    R.J0 = row[c]; R.W0 = row[16 + c];
+    R.J1 = row[S16_ROWLEN + c]; R.W1 = row[S16_ROWLEN + 16 + c];
+    R.J2 = row[2 * S16_ROWLEN + c]; R.W2 = row[2 * S16_ROWLEN + 16 + c];
+    R.s0 = *reinterpret_cast<const float4*>(row + 32);
+    R.s1 = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
+    R.s2 = *reinterpret_cast<const float4*>(row + 2 * S16_ROWLEN + 32);
+    R.lam0 = row[36]; R.lam1 = row[S16_ROWLEN + 36]; R.lam2 = row[2 * S16_ROWLEN + 36];
+    R.g10 = row[S16_ROWLEN + 38];
+    R.g20 = row[2 * S16_ROWLEN + 38]; R.g21 = row[2 * S16_ROWLEN + 39];
+  };
+  auto con_apply = [&](const ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
+    const float jv0 = gsum16(R.J0 * v_c);
+    const float jv1 = gsum16(R.J1 * v_c);
+    const float jv2 = gsum16(R.J2 * v_c);
+    float nl0 = fmaxf(R.lam0 - (jv0 + (use_bias ? R.s0.y : R.s0.z)) * R.s0.x, 0.f);
+    nl0 = (active && R.s0.x > 0.f) ? nl0 : R.lam0;
+    const float dl0 = nl0 - R.lam0;
+    const float h1 = R.s1.w * nl0;
+    float nl1 = fminf(fmaxf(R.lam1 - (jv1 + R.g10 * dl0) * R.s1.x, -h1), h1);
+    nl1 = (active && R.s1.x > 0.f) ? nl1 : R.lam1;
+    const float dl1 = nl1 - R.lam1;
+    const float h2 = R.s2.w * nl0;
+    float nl2 = fminf(fmaxf(R.lam2 - (jv2 + R.g20 * dl0 + R.g21 * dl1) * R.s2.x, -h2), h2);
+    nl2 = (active && R.s2.x > 0.f) ? nl2 : R.lam2;
+    const float dl2 = nl2 - R.lam2;
+    if (active) {
+      v_c = fmaf(R.W0, dl0, fmaf(R.W1, dl1, fmaf(R.W2, dl2, v_c)));
+      if (c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
+    }
   };
   const int n_iters = M.pos_iters + M.vel_iters;
+  float* const crow = L + S16_U + S16_ROWLEN * n;  // first contact row in LDS
   for (int it = 0; it <= n_iters; it++) {
     if (it == M.pos_iters) {
       vpos_c = v_c;
@@ -479,37 +513,36 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
     }
     if (it == n_iters) break;
     const bool use_bias = it < M.pos_iters;
-    lam_n = 0.f;
     // joint-limit rows: skip the sequential pass when no row of the whole wave would change
-    int r0 = n;
     {
       const float* row = L + S16_U + S16_ROWLEN * (art ? c : 0);
       const float invd = row[32], b = use_bias ? row[33] : row[34], lam = row[36];
       float nl = lam - (row[c] * v_c + b) * invd;  // J of row c is +-1 at lane c
       nl = nl < 0.f ? 0.f : nl;
       const bool changed = art && invd > 0.f && nl != lam;
-      if (__any(changed)) r0 = 0;
+      if (__any(changed))
+        for (int r = 0; r < n; r++) limit_row(L + S16_U + S16_ROWLEN * r, use_bias);
     }
-    if (r0 < max_lds) {
-      RowRec A, B;
-      float* base = L + S16_U;
-      row_load(base + S16_ROWLEN * r0, A);
-      int r = r0;
+    if (max_clds > 0) {
+      ConRec A, B;
+      con_load(crow, A);
+      int k = 0;
       while (true) {
-        if (r + 1 < max_lds) row_load(base + S16_ROWLEN * (r + 1), B);
-        row_apply(A, base + S16_ROWLEN * r, r < nr_lds, use_bias);
-        if (++r >= max_lds) break;
-        if (r + 1 < max_lds) row_load(base + S16_ROWLEN * (r + 1), A);
-        row_apply(B, base + S16_ROWLEN * r, r < nr_lds, use_bias);
-        if (++r >= max_lds) break;
+        // next block is loaded before the dependent chain of the current one (index clamped: in range)
+        con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), B);
+        con_apply(A, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
+        if (++k >= max_clds) break;
+        con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), A);
+        con_apply(B, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
+        if (++k >= max_clds) break;
       }
     }
-    for (int r = 0; r < max_glb; r++) {
-      const bool active = r < nr_glb;
-      float* row = grow + (size_t)S16_ROWLEN * (active ? r : 0);
-      RowRec A;
-      row_load(row, A);
-      row_apply(A, row, active && live, use_bias);
+    for (int k = 0; k < max_cglb; k++) {
+      const bool active = k < nc_glb;
+      float* row = grow + (size_t)(3 * S16_ROWLEN) * (active ? k : 0);
+      ConRec A;
+      con_load(row, A);
+      con_apply(A, row, active && live, use_bias);
     }
   }
 
@@ -520,10 +553,10 @@ __global__ __launch_bounds__(64) void k_solve16(DevModel M, DevState S) {
     const int ncon = (nrow - n) / 3;
     for (int i = 0; i < ncon; i++) {
       const int r = n + 3 * i;
-      const float* row = r < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * r) : (grow + (size_t)S16_ROWLEN * (r - S16_ROWS_LDS));
-      // rows of one contact are consecutive and never straddle the LDS / global boundary? they can:
-      const float* row1 = (r + 1) < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * (r + 1)) : (grow + (size_t)S16_ROWLEN * (r + 1 - S16_ROWS_LDS));
-      const float* row2 = (r + 2) < S16_ROWS_LDS ? (L + S16_U + S16_ROWLEN * (r + 2)) : (grow + (size_t)S16_ROWLEN * (r + 2 - S16_ROWS_LDS));
+      // a contact's three rows never straddle the LDS / global boundary (lds_limit is block aligned)
+      const float* row = r < lds_limit ? (L + S16_U + S16_ROWLEN * r) : (grow + (size_t)S16_ROWLEN * (r - lds_limit));
+      const float* row1 = row + S16_ROWLEN;
+      const float* row2 = row + 2 * S16_ROWLEN;
       const int p = __float_as_int(row[37]);
       const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
       const f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
