@@ -181,7 +181,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_solve",
+                "kernel": "k_solve16 (cooperative solve, 16 lanes/env)" if getattr(px._sim, "model", None) is not None and (px.model.n_dof + 6 * px.model.n_free) <= 16 and os.environ.get("MSSIM_SOLVER") != "lane" else "k_solve",
                 "achieved": round(achieved, 4),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

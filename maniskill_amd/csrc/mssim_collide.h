@@ -122,13 +122,14 @@ MS_DEV void collide_plane(const shape_t& pl, const shape_t& b, float offset, man
 }
 
 // ------------------------------------------------------------------------------------------
-// box-box.  LDS scratch: 2 polygon buffers of 16 points (x,y,z) -> 96 slots, [slot][64 lanes]
-#define CLIP_SLOTS 96
+// box-box.  LDS scratch: 2 polygon buffers of 8 points (x,y,z) + 8 separations -> 56 slots,
+// [slot][64 lanes] (a quad clipped by 4 planes has at most 8 vertices)
+#define CLIP_SLOTS 56
 struct lds_poly {
   float* base;  // already offset by lane
   int buf;
-  MS_DEV f3 get(int i) const { float* p = base + (size_t)(buf * 48 + 3 * i) * 64; return f3{p[0], p[64], p[128]}; }
-  MS_DEV void put(int i, f3 v) { float* p = base + (size_t)(buf * 48 + 3 * i) * 64; p[0] = v.x; p[64] = v.y; p[128] = v.z; }
+  MS_DEV f3 get(int i) const { float* p = base + (size_t)(buf * 24 + 3 * i) * 64; return f3{p[0], p[64], p[128]}; }
+  MS_DEV void put(int i, f3 v) { float* p = base + (size_t)(buf * 24 + 3 * i) * 64; p[0] = v.x; p[64] = v.y; p[128] = v.z; }
 };
 
 MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
@@ -138,8 +139,8 @@ MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
     f3 a = in.get(i);
     f3 b = in.get(i + 1 < n ? i + 1 : 0);
     float da = dot(pn, a) - pd, db = dot(pn, b) - pd;
-    if (da <= 0.f) out.put(m++, a);
-    if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+    if (da <= 0.f && m < 8) out.put(m++, a);
+    if (((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) && m < 8) {
       float t = da / (da - db);
       out.put(m++, a + (b - a) * t);
     }
@@ -264,7 +265,7 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   // result polygon is in buffer 0; compact the points within the offset into buffer 1 (x,y,z) and
   // their separations into the tail slots of buffer 1
   lds_poly Q{lds, 0}, Rb{lds, 1};
-  float* seps = lds + (size_t)(48 + 32) * 64;  // slots 80..95 of the scratch
+  float* seps = lds + (size_t)48 * 64;  // slots 48..55 of the scratch
   int n = 0;
   for (int i = 0; i < np; i++) {
     f3 p = Q.get(i);

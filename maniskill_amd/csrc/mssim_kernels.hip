@@ -37,6 +37,7 @@ struct DevModel {
   const float *free_inertial, *free_damping;
   const int *shape_type, *shape_kind, *shape_index, *shape_row, *shape_hull, *pair_shape;
   const float *shape_frame, *shape_param, *shape_material, *shape_bound, *hull_verts;
+  const float* shape_center;  // [n_shape][3] bounding-sphere centre in the BODY frame (shape_frame applied)
   float gx, gy, gz, dt, contact_offset, rest_offset, erp, max_depen;
   int pos_iters, vel_iters;
 };
@@ -202,6 +203,12 @@ MS_DEV shape_t make_shape(const DevModel& M, const DevState& S, int s, int e) {
   return sh;
 }
 
+MS_DEV float point_box_dist2(const shape_t& box, f3 pt) {
+  f3 d = mtmulv(box.rot, pt - box.c);
+  f3 q = f3{fmaxf(fabsf(d.x) - box.p0, 0.f), fmaxf(fabsf(d.y) - box.p1, 0.f), fmaxf(fabsf(d.z) - box.p2, 0.f)};
+  return dot(q, q);
+}
+
 __global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
   __shared__ float lds[CLIP_SLOTS * 64];
   const int N = S.N;
@@ -209,17 +216,31 @@ __global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
   int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= N) return;
   const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
-  shape_t A = make_shape(M, S, sa, e), B = make_shape(M, S, sb, e);
-  float ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
-  f3 cb = B.c + mmulv(B.rot, f3{M.shape_bound[4 * sb], M.shape_bound[4 * sb + 1], M.shape_bound[4 * sb + 2]});
+  const int ta = M.shape_type[sa], tb = M.shape_type[sb];
+  // cheap cull first: bounding-sphere centres straight from the body poses (centre offsets are
+  // precomputed in the body frame); the full shape frames are only built for survivors
+  const pose_t PA = body_pose_of(M, S, M.shape_kind[sa], M.shape_index[sa], e);
+  const pose_t PB = body_pose_of(M, S, M.shape_kind[sb], M.shape_index[sb], e);
+  const float ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
+  const f3 cb = PB.p + qrot(PB.q, f3{M.shape_center[3 * sb], M.shape_center[3 * sb + 1], M.shape_center[3 * sb + 2]});
+  f3 ca = f3{0, 0, 0};
   bool cull;
-  if (A.type == SH_PLANE) {
+  shape_t A, B;
+  if (ta == SH_PLANE) {
+    A = make_shape(M, S, sa, e);
     cull = dot(mcol(A.rot, 0), cb - A.c) > rb + M.contact_offset;
   } else {
-    f3 ca = A.c + mmulv(A.rot, f3{M.shape_bound[4 * sa], M.shape_bound[4 * sa + 1], M.shape_bound[4 * sa + 2]});
+    ca = PA.p + qrot(PA.q, f3{M.shape_center[3 * sa], M.shape_center[3 * sa + 1], M.shape_center[3 * sa + 2]});
     f3 d = cb - ca;
     float rr = ra + rb + M.contact_offset;
     cull = dot(d, d) > rr * rr;
+  }
+  if (!cull) {
+    if (ta != SH_PLANE) A = make_shape(M, S, sa, e);
+    B = make_shape(M, S, sb, e);
+    // tighter, still conservative: the other shape's bounding sphere against an oriented box
+    if (ta == SH_BOX) { float rr = rb + M.contact_offset; cull = point_box_dist2(A, cb) > rr * rr; }
+    if (!cull && tb == SH_BOX && ta != SH_PLANE) { float rr = ra + M.contact_offset; cull = point_box_dist2(B, ca) > rr * rr; }
   }
   manifold_t m;
   m.count = 0;
@@ -1178,6 +1199,21 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   if ((rc = upload(S, d->shape_body_kind, (size_t)ns, &M.shape_kind))) { mssim_destroy(S); return rc; }
   if ((rc = upload(S, d->shape_body_index, (size_t)ns, &M.shape_index))) { mssim_destroy(S); return rc; }
   if ((rc = upload(S, anc.data(), (size_t)n, &M.dof_anc))) { mssim_destroy(S); return rc; }
+  {
+    std::vector<float> ctr(3 * (ns > 0 ? ns : 1), 0.f);
+    for (int s2 = 0; s2 < ns; s2++) {
+      const float* f = d->shape_frame + 7 * s2;
+      const float* b = d->shape_bound + 4 * s2;
+      const float w = f[3], x = f[4], y = f[5], z = f[6];
+      const float nq = std::sqrt(w * w + x * x + y * y + z * z);
+      const float qw = w / nq, qx = x / nq, qy = y / nq, qz = z / nq;
+      const float R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)},
+                             {2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)},
+                             {2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
+      for (int i = 0; i < 3; i++) ctr[3 * s2 + i] = f[i] + R[i][0] * b[0] + R[i][1] * b[1] + R[i][2] * b[2];
+    }
+    if ((rc = upload(S, ctr.data(), (size_t)3 * ns, &M.shape_center))) { mssim_destroy(S); return rc; }
+  }
   S->d_drive = const_cast<float*>(M.dof_drive);
   M.gx = d->gravity[0]; M.gy = d->gravity[1]; M.gz = d->gravity[2];
   M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
