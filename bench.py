@@ -39,6 +39,18 @@ import torch  # noqa: E402
 
 ALG_BYTES_PER_ENV_STEP = 1332  # 192 B read + 1140 B written per env-step (f32)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "pmc_summary.json")  # separate --pmc passes, see scripts/summarize_pmc.py
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
+    same command (counters cannot be collected from inside the process); None if not collected"""
+    try:
+        with open(PMC_SUMMARY) as f:
+            return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch_raw"]
+    except Exception:
+        return None
+
 
 
 def timed_steps(env, steps, gather, barrier):
@@ -186,7 +198,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_solve16"),
                 "avg_kernel_ms": round(avg_solve_s * 1e3, 4),
                 "launches": solve_n,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
