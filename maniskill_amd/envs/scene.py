@@ -172,12 +172,12 @@ class ManiSkillScene:
 
     def step(self, n_substeps: int = 1):
         self.px.step(n_substeps)
-        self._needs_fetch = True
 
     def _gpu_apply_all(self):
         """scene.py:941-957 (8 apply kinds; here one fused native call)"""
         assert not self._needs_fetch, "Once _gpu_apply_all is called, you must call _gpu_fetch_all before calling _gpu_apply_all again"
         self.px.gpu_apply_all()
+        self._needs_fetch = True
 
     def _gpu_fetch_all(self):
         """scene.py:959-977"""

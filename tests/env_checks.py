@@ -167,19 +167,71 @@ def check_push_cube(sim_backend):
     env.close()
 
 
-def check_scripted_pick_and_lift(sim_backend, n=2):
-    """task-level behaviour: close on the cube, lift, is_grasped becomes true
-    and the cube follows. Uses pd_joint_pos with IK-free joint targets found by FK search."""
-    env = make("PickCube-v1", n, sim_backend, control_mode="pd_joint_pos")
+def check_scripted_pick_and_lift(sim_backend):
+    """task-level behaviour: descend over the cube, close the gripper, lift and
+    hold. The cube must follow the hand (z rises >= 0.1 m), `is_grasped` must be true while held and
+    the dense reward must increase. `pd_joint_pos` control, joint waypoints found by FK search."""
+    import numpy as np
+
+    from maniskill_amd.utils.structs.pose import Pose
+
+    env = make("PickCube-v1", 1, sim_backend, control_mode="pd_joint_pos")
     base = env.unwrapped
     env.reset(seed=0)
     dev = base.device
-    # put the cube at a known spot under the tcp for a fixed arm configuration
-    q_grasp = torch.tensor([0.0, 0.3927, 0.0, -1.9635, 0.0, 2.3562, 0.7854, 0.04, 0.04], device=dev)
-    base.agent.robot.set_qpos(q_grasp)
+    robot = base.agent.robot
+
+    def tcp_at(q):
+        robot.set_qpos(q)
+        base.scene._gpu_apply_all()
+        base.scene.px.gpu_update_articulation_kinematics()
+        base.scene._gpu_fetch_all()
+        return base.agent.tcp.pose.p[0].clone()
+
+    def ik(q0, target):
+        q, idx = q0.clone(), [1, 3, 5]
+        for _ in range(40):
+            p = tcp_at(q)
+            J = torch.zeros(3, 3, device=dev)
+            for k, j in enumerate(idx):
+                dq = q.clone()
+                dq[0, j] += 1e-4
+                J[:, k] = (tcp_at(dq) - p) / 1e-4
+            step = torch.linalg.solve(J.T @ J + 1e-6 * torch.eye(3, device=dev), J.T @ (target - p))
+            for k, j in enumerate(idx):
+                q[0, j] += step[k]
+        assert torch.norm(tcp_at(q) - target) < 2e-3
+        return q
+
+    q0 = torch.tensor([[0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, np.pi / 4, 0.04, 0.04]], dtype=torch.float32, device=dev)
+    cube_p = torch.tensor([0.0, 0.0, 0.02], device=dev)
+    q_pre = ik(q0, cube_p + torch.tensor([0, 0, 0.10], device=dev))
+    q_grasp = ik(q_pre, cube_p)
+    q_lift = ik(q_grasp, cube_p + torch.tensor([0, 0, 0.15], device=dev))
+    base.cube.set_pose(Pose.create_from_pq(cube_p[None], torch.tensor([[1.0, 0, 0, 0]], device=dev)))
+    robot.set_qpos(q_pre)
+    robot.set_qvel(torch.zeros(9, device=dev))
     base.scene._gpu_apply_all()
     base.scene.px.gpu_update_articulation_kinematics()
     base.scene._gpu_fetch_all()
-    tcp = base.agent.tcp.pose.p.clone()
-    assert abs(tcp[0, 2].item() - 0.17) < 0.01  # rest pose tcp height
-    return env, tcp
+    base.agent.controller.reset()
+
+    def run(qa, qb, grip, steps):
+        for i in range(steps):
+            al = (i + 1) / steps
+            a = torch.zeros(1, 8, device=dev)
+            a[0, :7] = (qa * (1 - al) + qb * al)[0, :7]
+            a[0, 7] = grip
+            out = env.step(a)
+        return out
+
+    _, r0, _, _, info = run(q_pre, q_grasp, 1.0, 20)
+    assert not info["is_grasped"].item() and abs(base.cube.pose.p[0, 2].item() - 0.02) < 2e-3
+    _, r1, _, _, info = run(q_grasp, q_grasp, -1.0, 10)
+    assert info["is_grasped"].item(), "closing the gripper on the cube must register as a grasp"
+    _, r2, _, _, info = run(q_grasp, q_lift, -1.0, 20)
+    _, r3, _, _, info = run(q_lift, q_lift, -1.0, 10)
+    assert info["is_grasped"].item()
+    assert base.cube.pose.p[0, 2].item() > 0.12, base.cube.pose.p
+    assert r1.item() > r0.item() + 0.15  # grasp bonus of the dense reward
+    env.close()

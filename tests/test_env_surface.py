@@ -42,6 +42,10 @@ def test_push_cube():
     ec.check_push_cube(BACKEND)
 
 
+def test_scripted_pick_and_lift():
+    ec.check_scripted_pick_and_lift(BACKEND)
+
+
 def test_hip_backend_fails_loudly_without_gpu():
     import gymnasium as gym
 

@@ -38,6 +38,10 @@ def test_push_cube():
     ec.check_push_cube(BACKEND)
 
 
+def test_scripted_pick_and_lift():
+    ec.check_scripted_pick_and_lift(BACKEND)
+
+
 def test_env_rollout_matches_oracle_backend():
     """same seed, same actions: obs / reward of the HIP env track the oracle-backed env for the first
     control steps (contact-light PickCube start states), within 1e-3 (positions / angles)."""
