@@ -929,41 +929,44 @@ __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) 
     }
 }
 
-__global__ void k_fetch(DevModel M, DevState S, mssim_buffers B, unsigned what) {
+// fetch: grid (N/64, n_rows + 1). blockIdx.y < n_rows: one (body row, env) per lane -> consecutive
+// lanes write consecutive 52-byte records (coalesced); blockIdx.y == n_rows: the articulation arrays
+__global__ __launch_bounds__(64) void k_fetch(DevModel M, DevState S, mssim_buffers B, unsigned what) {
   const int N = S.N;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= N) return;
   const int n = M.n_dof;
-  if (B.rigid_body_data) {
-    if (what & MSSIM_RIGID_DATA) {
-      for (int b = 0; b < M.n_free; b++) {
-        float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
-        for (int c = 0; c < 13; c++) r[c] = SOA(S.free_s, 13 * b + c);
+  const int R = M.n_link + M.n_free + M.n_kin;
+  const int row = blockIdx.y;
+  if (row < R) {
+    if (!B.rigid_body_data) return;
+    float* r = B.rigid_body_data + 13 * ((size_t)row * N + e);
+    if (row < M.n_link) {
+      if (!(what & (MSSIM_LINK_POSE | MSSIM_LINK_VEL))) return;
+      const pose_t root = pose_soa(S.root, 0, N, e);
+      const int b = M.link_body[row];
+      const pose_t P = pmul(b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e), pose_from(M.link_frame + 7 * row));
+      if (what & MSSIM_LINK_POSE) { r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z; }
+      if (what & MSSIM_LINK_VEL) {
+        f3 w = f3{0, 0, 0}, vv = f3{0, 0, 0};
+        if (b >= 0) {
+          w = f3{SOA(S.bodyvel, 6 * b), SOA(S.bodyvel, 6 * b + 1), SOA(S.bodyvel, 6 * b + 2)};
+          vv = f3{SOA(S.bodyvel, 6 * b + 3), SOA(S.bodyvel, 6 * b + 4), SOA(S.bodyvel, 6 * b + 5)} + cross(w, P.p - root.p);
+        }
+        r[7] = vv.x; r[8] = vv.y; r[9] = vv.z; r[10] = w.x; r[11] = w.y; r[12] = w.z;
       }
-      for (int k = 0; k < M.n_kin; k++) {
-        float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
-        pose_t P = pose_soa(S.kin, 7 * k, N, e);
+    } else if (what & MSSIM_RIGID_DATA) {
+      if (row < M.n_link + M.n_free) {
+        const int b = row - M.n_link;
+        for (int c = 0; c < 13; c++) r[c] = SOA(S.free_s, 13 * b + c);
+      } else {
+        const int k = row - M.n_link - M.n_free;
+        const pose_t P = pose_soa(S.kin, 7 * k, N, e);
         r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z;
         for (int c = 7; c < 13; c++) r[c] = 0.f;
       }
     }
-    if (what & (MSSIM_LINK_POSE | MSSIM_LINK_VEL)) {
-      pose_t root = pose_soa(S.root, 0, N, e);
-      for (int l = 0; l < M.n_link; l++) {
-        float* r = B.rigid_body_data + 13 * ((size_t)l * N + e);
-        int b = M.link_body[l];
-        pose_t P = pmul(b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e), pose_from(M.link_frame + 7 * l));
-        if (what & MSSIM_LINK_POSE) { r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z; }
-        if (what & MSSIM_LINK_VEL) {
-          f3 w = f3{0, 0, 0}, vv = f3{0, 0, 0};
-          if (b >= 0) {
-            w = f3{SOA(S.bodyvel, 6 * b), SOA(S.bodyvel, 6 * b + 1), SOA(S.bodyvel, 6 * b + 2)};
-            vv = f3{SOA(S.bodyvel, 6 * b + 3), SOA(S.bodyvel, 6 * b + 4), SOA(S.bodyvel, 6 * b + 5)} + cross(w, P.p - root.p);
-          }
-          r[7] = vv.x; r[8] = vv.y; r[9] = vv.z; r[10] = w.x; r[11] = w.y; r[12] = w.z;
-        }
-      }
-    }
+    return;
   }
   if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) B.art_qpos[(size_t)e * n + j] = SOA(S.q, j);
   if ((what & MSSIM_ART_QVEL) && B.art_qvel) for (int j = 0; j < n; j++) B.art_qvel[(size_t)e * n + j] = SOA(S.qd, j);
@@ -1294,7 +1297,7 @@ int mssim_apply(mssim_handle h, uint32_t what, void* stream) {
 }
 
 int mssim_fetch(mssim_handle h, uint32_t what, void* stream) {
-  hipLaunchKernelGGL(k_fetch, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
+  hipLaunchKernelGGL(k_fetch, dim3((h->N + 63) / 64, h->M.n_link + h->M.n_free + h->M.n_kin + 1), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -310,32 +310,25 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 
   // ---------------------------------------------------------------- rows
   float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
-  // joint limits: row j for joint j
+  // joint limits: row j for joint j. J = side_j e_j, W = side_j * column j of A^-1 (kept in LDS
+  // row j); the scalars and the multiplier stay in lane j's registers.
+  float lim_inv = 0.f, lim_bpos = 0.f, lim_bvel = 0.f, lim_side = 0.f, lim_lam = 0.f;
   {
     const bool has = art && (lo_c > -1e30f || hi_c < 1e30f);
     const float dlo = q_c - lo_c, dhi = hi_c - q_c;
     const float C = dlo <= dhi ? dlo : dhi;
-    const float side = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
+    lim_side = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
     float dself = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       if (j >= n) break;
-      const float sj = gbc(side, j);
-      float* row = L + S16_U + S16_ROWLEN * j;
-      row[c] = c == j ? sj : 0.f;
-      row[16 + c] = sj * Irow[j];
+      const float sj = gbc(lim_side, j);
+      L[S16_U + S16_ROWLEN * j + 16 + c] = sj * Irow[j];
       if (c == j) dself = Irow[j];
     }
-    if (art) {
-      float* row = L + S16_U + S16_ROWLEN * c;
-      row[32] = (has && dself > 1e-12f) ? 1.f / dself : 0.f;
-      row[33] = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
-      row[34] = C >= 0.f ? C / dt : 0.f;
-      row[35] = -1.f;  // mu < 0: unilateral row with bounds [0, inf)
-      row[36] = 0.f;
-      row[37] = __int_as_float(-1);
-      row[38] = 0.f; row[39] = 0.f;
-    }
+    lim_inv = (has && dself > 1e-12f) ? 1.f / dself : 0.f;
+    lim_bpos = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
+    lim_bvel = C >= 0.f ? C / dt : 0.f;
   }
   int nrow = n;
   // contact rows come in blocks of 3 (normal, t1, t2): keep whole blocks on one side of the LDS boundary
@@ -439,17 +432,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     max_cglb = max(max_cglb, __shfl_xor(max_cglb, o));
   }
   float vpos_c = v_c;
-  // single (joint-limit) row
-  auto limit_row = [&](float* row, bool use_bias) __attribute__((always_inline)) {
-    const float J = row[c], W = row[16 + c];
-    const float4 s = *reinterpret_cast<const float4*>(row + 32);
-    const float lam = row[36];
-    const float jv = gsum16(J * v_c);
-    float nl = fmaxf(lam - (jv + (use_bias ? s.y : s.z)) * s.x, 0.f);
-    nl = s.x > 0.f ? nl : lam;
-    v_c = fmaf(W, nl - lam, v_c);
-    if (c == 0) row[36] = nl;
-  };
   // one contact = block of 3 rows. The three J.v reductions are independent (issued back to back);
   // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
   // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
@@ -513,15 +495,26 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     }
     if (it == n_iters) break;
     const bool use_bias = it < M.pos_iters;
-    // joint-limit rows: skip the sequential pass when no row of the whole wave would change
+    // joint-limit rows, exact sequential Gauss-Seidel semantics, but only rows that change are
+    // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
+    // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
     {
-      const float* row = L + S16_U + S16_ROWLEN * (art ? c : 0);
-      const float invd = row[32], b = use_bias ? row[33] : row[34], lam = row[36];
-      float nl = lam - (row[c] * v_c + b) * invd;  // J of row c is +-1 at lane c
-      nl = nl < 0.f ? 0.f : nl;
-      const bool changed = art && invd > 0.f && nl != lam;
-      if (__any(changed))
-        for (int r = 0; r < n; r++) limit_row(L + S16_U + S16_ROWLEN * r, use_bias);
+      int cursor = 0;
+      const float bl = use_bias ? lim_bpos : lim_bvel;
+      while (true) {
+        const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
+        const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
+        const unsigned long long bal = __ballot(cand);
+        if (bal == 0ull) break;
+        const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
+        const bool act = m16 != 0u;
+        const int j = act ? (__ffs(m16) - 1) : 0;
+        float dl = gbc(nl - lim_lam, j);
+        dl = act ? dl : 0.f;
+        if (act && c == j) lim_lam = nl;
+        v_c = fmaf(L[S16_U + S16_ROWLEN * j + 16 + c], dl, v_c);
+        cursor = act ? j + 1 : 16;
+      }
     }
     if (max_clds > 0) {
       ConRec A, B;
