@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MSSIM_ABI_VERSION 1
+#define MSSIM_ABI_VERSION 2
 #define MSSIM_MAX_DOF 16        /* max articulation degrees of freedom per env            */
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
@@ -129,6 +129,20 @@ typedef struct mssim_model_desc {
   float erp;                     /* fraction of penetration removed per substep by the bias       */
   float max_depenetration_velocity;
   float sleep_threshold;         /* reserved (0.005)                                              */
+
+  /* ---- per-env geometry overrides (ABI v2): same shape types in every env, different sizes /
+   *      local poses / inertias -- the reference builds such actors per sub-scene and merges them
+   *      (Actor.merge, utils/structs/actor.py:99-126; PegInsertionSide peg_insertion_side.py:114-181).
+   *      Arrays are [items][num_envs], env fastest; num_envs must equal mssim_create's. ---- */
+  int32_t num_envs;              /* N the env arrays were built for (0 = no env arrays)           */
+  int32_t n_env_shape;
+  const int32_t* shape_env_slot; /* [n_shape] slot into the env_shape_* arrays, -1 = shared       */
+  const float* env_shape_frame;  /* [n_env_shape*7][N]                                            */
+  const float* env_shape_param;  /* [n_env_shape*4][N]                                            */
+  const float* env_shape_bound;  /* [n_env_shape*4][N] bounding-sphere centre in the BODY frame, radius */
+  int32_t n_env_free;
+  const int32_t* free_env_slot;  /* [n_free] slot into env_free_inertial, -1 = shared             */
+  const float* env_free_inertial;/* [n_env_free*10][N]                                            */
 } mssim_model_desc;
 
 /* User-visible buffers (device pointers owned by the caller, e.g. torch tensors); mirrors

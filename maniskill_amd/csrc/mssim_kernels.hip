@@ -38,6 +38,9 @@ struct DevModel {
   const int *shape_type, *shape_kind, *shape_index, *shape_row, *shape_hull, *pair_shape;
   const float *shape_frame, *shape_param, *shape_material, *shape_bound, *hull_verts;
   const float* shape_center;  // [n_shape][3] bounding-sphere centre in the BODY frame (shape_frame applied)
+  // per-env overrides ([items][N], env fastest); slot < 0 = shared value
+  const int *shape_env_slot, *free_env_slot;
+  const float *env_shape_frame, *env_shape_param, *env_shape_bound, *env_free_inertial;
   float gx, gy, gz, dt, contact_offset, rest_offset, erp, max_depen;
   int pos_iters, vel_iters;
 };
@@ -191,13 +194,29 @@ MS_DEV pose_t body_pose_of(const DevModel& M, const DevState& S, int kind, int i
   return pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
 }
 
+// the 10 inertial parameters of free body b in env e (per-env override or shared table)
+MS_DEV void free_inertial_of(const DevModel& M, int N, int b, int e, float* out) {
+  const int slot = M.free_env_slot[b];
+#pragma unroll
+  for (int k = 0; k < 10; k++) out[k] = slot < 0 ? M.free_inertial[10 * b + k] : M.env_free_inertial[(size_t)(10 * slot + k) * N + e];
+}
+
 MS_DEV shape_t make_shape(const DevModel& M, const DevState& S, int s, int e) {
   shape_t sh;
-  pose_t W = pmul(body_pose_of(M, S, M.shape_kind[s], M.shape_index[s], e), pose_from(M.shape_frame + 7 * s));
+  const int slot = M.shape_env_slot[s];
+  pose_t F;
+  if (slot < 0) {
+    F = pose_from(M.shape_frame + 7 * s);
+    sh.p0 = M.shape_param[4 * s]; sh.p1 = M.shape_param[4 * s + 1]; sh.p2 = M.shape_param[4 * s + 2];
+  } else {
+    F = pose_soa(M.env_shape_frame, 7 * slot, S.N, e);
+    const float* pp = M.env_shape_param + (size_t)(4 * slot) * S.N + e;
+    sh.p0 = pp[0]; sh.p1 = pp[(size_t)S.N]; sh.p2 = pp[2 * (size_t)S.N];
+  }
+  pose_t W = pmul(body_pose_of(M, S, M.shape_kind[s], M.shape_index[s], e), F);
   sh.type = M.shape_type[s];
   sh.c = W.p;
   sh.rot = qmat(W.q);
-  sh.p0 = M.shape_param[4 * s]; sh.p1 = M.shape_param[4 * s + 1]; sh.p2 = M.shape_param[4 * s + 2];
   sh.verts = M.hull_verts + 3 * M.shape_hull[2 * s];
   sh.nverts = M.shape_hull[2 * s + 1];
   return sh;
@@ -221,8 +240,15 @@ __global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
   // precomputed in the body frame); the full shape frames are only built for survivors
   const pose_t PA = body_pose_of(M, S, M.shape_kind[sa], M.shape_index[sa], e);
   const pose_t PB = body_pose_of(M, S, M.shape_kind[sb], M.shape_index[sb], e);
-  const float ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
-  const f3 cb = PB.p + qrot(PB.q, f3{M.shape_center[3 * sb], M.shape_center[3 * sb + 1], M.shape_center[3 * sb + 2]});
+  float ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
+  f3 cla = f3{M.shape_center[3 * sa], M.shape_center[3 * sa + 1], M.shape_center[3 * sa + 2]};
+  f3 clb = f3{M.shape_center[3 * sb], M.shape_center[3 * sb + 1], M.shape_center[3 * sb + 2]};
+  {
+    const int la = M.shape_env_slot[sa], lb = M.shape_env_slot[sb];
+    if (la >= 0) { const float* b = M.env_shape_bound + (size_t)(4 * la) * N + e; cla = f3{b[0], b[(size_t)N], b[2 * (size_t)N]}; ra = b[3 * (size_t)N]; }
+    if (lb >= 0) { const float* b = M.env_shape_bound + (size_t)(4 * lb) * N + e; clb = f3{b[0], b[(size_t)N], b[2 * (size_t)N]}; rb = b[3 * (size_t)N]; }
+  }
+  const f3 cb = PB.p + qrot(PB.q, clb);
   f3 ca = f3{0, 0, 0};
   bool cull;
   shape_t A, B;
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
     A = make_shape(M, S, sa, e);
     cull = dot(mcol(A.rot, 0), cb - A.c) > rb + M.contact_offset;
   } else {
-    ca = PA.p + qrot(PA.q, f3{M.shape_center[3 * sa], M.shape_center[3 * sa + 1], M.shape_center[3 * sa + 2]});
+    ca = PA.p + qrot(PA.q, cla);
     f3 d = cb - ca;
     float rr = ra + rb + M.contact_offset;
     cull = dot(d, d) > rr * rr;
@@ -529,7 +555,8 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
   }
   // ---- free bodies: unconstrained velocities into LDS
   for (int b = 0; b < M.n_free; b++) {
-    const float* in = M.free_inertial + 10 * b;
+    float in[10];
+    free_inertial_of(M, N, b, e, in);
     pose_t P = pose_soa(S.free_s, 13 * b, N, e);
     m3 R = qmat(P.q);
     s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
@@ -795,7 +822,8 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
 #pragma unroll T::UNROLL
       for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; vpos[j] = v[j]; }
       for (int b = 0; b < M.n_free; b++) {
-        const float* in = M.free_inertial + 10 * b;
+        float in[10];
+        free_inertial_of(M, N, b, e, in);
         f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)} + f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)} * dt;
         f3 w = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
         q4 qq = q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)};
@@ -1216,6 +1244,21 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       for (int i = 0; i < 3; i++) ctr[3 * s2 + i] = f[i] + R[i][0] * b[0] + R[i][1] * b[1] + R[i][2] * b[2];
     }
     if ((rc = upload(S, ctr.data(), (size_t)3 * ns, &M.shape_center))) { mssim_destroy(S); return rc; }
+  }
+  {
+    const bool has_es = d->n_env_shape > 0, has_ef = d->n_env_free > 0;
+    if ((has_es || has_ef) && d->num_envs != num_envs) { g_create_error = "per-env arrays were built for a different num_envs"; mssim_destroy(S); return 7; }
+    std::vector<int32_t> sslot(ns > 0 ? ns : 1, -1), fslot(d->n_free > 0 ? d->n_free : 1, -1);
+    if (has_es) for (int i = 0; i < ns; i++) sslot[i] = d->shape_env_slot[i];
+    if (has_ef) for (int i = 0; i < d->n_free; i++) fslot[i] = d->free_env_slot[i];
+    if ((rc = upload(S, sslot.data(), sslot.size(), &M.shape_env_slot)) || (rc = upload(S, fslot.data(), fslot.size(), &M.free_env_slot)) ||
+        (rc = upload(S, d->env_shape_frame, (size_t)7 * d->n_env_shape * num_envs, &M.env_shape_frame)) ||
+        (rc = upload(S, d->env_shape_param, (size_t)4 * d->n_env_shape * num_envs, &M.env_shape_param)) ||
+        (rc = upload(S, d->env_shape_bound, (size_t)4 * d->n_env_shape * num_envs, &M.env_shape_bound)) ||
+        (rc = upload(S, d->env_free_inertial, (size_t)10 * d->n_env_free * num_envs, &M.env_free_inertial))) {
+      mssim_destroy(S);
+      return rc;
+    }
   }
   S->d_drive = const_cast<float*>(M.dof_drive);
   M.gx = d->gravity[0]; M.gy = d->gravity[1]; M.gz = d->gravity[2];

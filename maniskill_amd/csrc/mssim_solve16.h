@@ -276,7 +276,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   float v_c = art ? vstar : 0.f;
   f3 mycom = f3{0, 0, 0};
   for (int b = 0; b < nf; b++) {
-    const float* in = M.free_inertial + 10 * b;
+    float in[10];
+    free_inertial_of(M, N, b, e, in);
     pose_t P = pose_soa(S.free_s, 13 * b, N, e);
     m3 R = qmat(P.q);
     s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       vpos_c = v_c;
       q_c += dt * v_c;
       for (int b = 0; b < nf; b++) {
-        const float* in = M.free_inertial + 10 * b;
+        float in[10];
+        free_inertial_of(M, N, b, e, in);
         const int base = n + 6 * b;
         f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
         f3 ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};

@@ -35,6 +35,7 @@ class ManiSkillScene:
         self.sensors = {}
         self.human_render_cameras = {}
         self._builder = SceneModelBuilder()
+        self._fragments: Dict[str, Actor] = {}  # per-env actor fragments waiting for Actor.merge
         self._gpu_sim_initialized = False
         self._needs_fetch = False
         self._all_env_idx = torch.arange(self.num_envs, device=self.device)
@@ -140,8 +141,14 @@ class ManiSkillScene:
     # ------------------------------------------------------------------ setup / stepping
     def _setup(self, enable_gpu: bool = True):
         """px.gpu_init + initial apply/fetch (scene.py:897-939)"""
+        if self._fragments:
+            raise NotImplementedError(
+                f"actors {sorted(self._fragments)} exist in a subset of the envs and were never merged: per-env distinct "
+                "object sets are not supported by this core (only Actor.merge of one fragment per env)"
+            )
         sc = self.sim_config.scene_config
         model = self._builder.compile(
+            num_envs=self.num_envs,
             timestep=self.px.timestep,
             gravity=tuple(float(g) for g in np.asarray(sc.gravity)),
             contact_offset=sc.contact_offset,

@@ -1,1 +1,1 @@
-from .tabletop import PickCubeEnv, PushCubeEnv
+from .tabletop import PegInsertionSideEnv, PickCubeEnv, PushCubeEnv

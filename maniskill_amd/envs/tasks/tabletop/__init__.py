@@ -1,2 +1,3 @@
 from .pick_cube import PickCubeEnv
 from .push_cube import PushCubeEnv
+from .peg_insertion_side import PegInsertionSideEnv

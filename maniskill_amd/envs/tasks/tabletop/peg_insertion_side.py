@@ -1,0 +1,207 @@
+"""PegInsertionSide-v1: grasp a peg and insert it sideways into a box with a hole.
+
+Behavioural counterpart of mani_skill/envs/tasks/tabletop/peg_insertion_side.py (geometry sampling
+:114-131, per-env build + merge :134-181, episode init :183-245, success :268-286, state obs
+:288-298, dense reward :300-355), written against this package's API. The peg and the box differ in
+every env (length, radius, hole centre): each env contributes one single-env fragment and
+`Actor.merge` turns the N fragments into one actor whose shapes carry per-env sizes and frames
+(ABI v2 per-env overrides, include/mssim.h) instead of N distinct PhysX actors.
+"""
+from typing import Any, Dict, Union
+
+import numpy as np
+import sapien
+import torch
+
+from maniskill_amd.agents.robots.panda import PandaWristCam
+from maniskill_amd.envs.sapien_env import BaseEnv
+from maniskill_amd.envs.utils import randomization
+from maniskill_amd.sensors.camera import CameraConfig
+from maniskill_amd.utils import common, sapien_utils
+from maniskill_amd.utils.registration import register_env
+from maniskill_amd.utils.scene_builder.table import TableSceneBuilder
+from maniskill_amd.utils.structs import Actor, Pose
+from maniskill_amd.utils.structs.types import SimConfig
+
+
+def _build_box_with_hole(scene, inner_radius, outer_radius, depth, center=(0, 0)):
+    """four slabs around a square hole along local x (hole offset `center` in the local yz plane)"""
+    builder = scene.create_actor_builder()
+    wall = (outer_radius - inner_radius) * 0.5
+    cy, cz = 0.5 * center[0], 0.5 * center[1]
+    shift = wall + inner_radius
+    slabs = [
+        ([depth, wall - cy, outer_radius], [0, shift + cy, 0]),
+        ([depth, wall + cy, outer_radius], [0, -shift + cy, 0]),
+        ([depth, outer_radius, wall - cz], [0, 0, shift + cz]),
+        ([depth, outer_radius, wall + cz], [0, 0, -shift + cz]),
+    ]
+    mat = sapien.render.RenderMaterial(base_color=sapien_utils.hex2rgba("#FFD289"), roughness=0.5, specular=0.5)
+    for half_size, p in slabs:
+        builder.add_box_collision(sapien.Pose(p), half_size)
+        builder.add_box_visual(sapien.Pose(p), half_size, material=mat)
+    return builder
+
+
+@register_env("PegInsertionSide-v1", max_episode_steps=100)
+class PegInsertionSideEnv(BaseEnv):
+    SUPPORTED_ROBOTS = ["panda_wristcam"]
+    agent: Union[PandaWristCam]
+    _clearance = 0.003
+
+    def __init__(self, *args, robot_uids="panda_wristcam", num_envs=1, reconfiguration_freq=None, **kwargs):
+        if reconfiguration_freq is None:
+            reconfiguration_freq = 1 if num_envs == 1 else 0
+        super().__init__(*args, robot_uids=robot_uids, num_envs=num_envs, reconfiguration_freq=reconfiguration_freq, **kwargs)
+
+    @property
+    def _default_sim_config(self):
+        return SimConfig()
+
+    @property
+    def _default_sensor_configs(self):
+        pose = sapien_utils.look_at([0, -0.3, 0.2], [0, 0, 0.1])
+        return [CameraConfig("base_camera", pose, 128, 128, np.pi / 2, 0.01, 100)]
+
+    @property
+    def _default_human_render_camera_configs(self):
+        pose = sapien_utils.look_at([0.5, -0.5, 0.8], [0.05, -0.1, 0.4])
+        return CameraConfig("render_camera", pose, 512, 512, 1, 0.01, 100)
+
+    def _load_agent(self, options: dict):
+        super()._load_agent(options, sapien.Pose(p=[-0.615, 0, 0]))
+
+    def _load_scene(self, options: dict):
+        with torch.device(self.device):
+            self.table_scene = TableSceneBuilder(self)
+            self.table_scene.build()
+
+            lengths = self._batched_episode_rng.uniform(0.085, 0.125)
+            radii = self._batched_episode_rng.uniform(0.015, 0.025)
+            centers = 0.5 * (lengths - radii)[:, None] * self._batched_episode_rng.uniform(-1, 1, size=(2,))
+
+            self.peg_half_sizes = common.to_tensor(np.vstack([lengths, radii, radii]), device=self.device).T.float().contiguous()
+            head = torch.zeros((self.num_envs, 3))
+            head[:, 0] = self.peg_half_sizes[:, 0]
+            self.peg_head_offsets = Pose.create_from_pq(p=head)
+            hole = torch.zeros((self.num_envs, 3))
+            hole[:, 1:] = common.to_tensor(centers, device=self.device).float()
+            self.box_hole_offsets = Pose.create_from_pq(p=hole)
+            self.box_hole_radii = common.to_tensor(radii + self._clearance, device=self.device).float()
+
+            pegs, boxes = [], []
+            head_mat = sapien.render.RenderMaterial(base_color=sapien_utils.hex2rgba("#EC7357"), roughness=0.5, specular=0.5)
+            tail_mat = sapien.render.RenderMaterial(base_color=sapien_utils.hex2rgba("#EDF6F9"), roughness=0.5, specular=0.5)
+            for i in range(self.num_envs):
+                length, radius = float(lengths[i]), float(radii[i])
+                builder = self.scene.create_actor_builder()
+                builder.add_box_collision(half_size=[length, radius, radius])
+                builder.add_box_visual(sapien.Pose([length / 2, 0, 0]), half_size=[length / 2, radius, radius], material=head_mat)
+                builder.add_box_visual(sapien.Pose([-length / 2, 0, 0]), half_size=[length / 2, radius, radius], material=tail_mat)
+                builder.initial_pose = sapien.Pose(p=[0, 0, 0.1])
+                builder.set_scene_idxs([i])
+                peg = builder.build(f"peg_{i}")
+                self.remove_from_state_dict_registry(peg)
+
+                builder = _build_box_with_hole(self.scene, radius + self._clearance, length, length, center=centers[i])
+                builder.initial_pose = sapien.Pose(p=[0, 1, 0.1])
+                builder.set_scene_idxs([i])
+                box = builder.build_kinematic(f"box_with_hole_{i}")
+                self.remove_from_state_dict_registry(box)
+                pegs.append(peg)
+                boxes.append(box)
+            self.peg = Actor.merge(pegs, "peg")
+            self.box = Actor.merge(boxes, "box_with_hole")
+            self.add_to_state_dict_registry(self.peg)
+            self.add_to_state_dict_registry(self.box)
+
+    def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
+        with torch.device(self.device):
+            b = len(env_idx)
+            self.table_scene.initialize(env_idx)
+
+            xy = randomization.uniform(low=torch.tensor([-0.1, -0.3]), high=torch.tensor([0.1, 0]), size=(b, 2))
+            pos = torch.zeros((b, 3))
+            pos[:, :2] = xy
+            pos[:, 2] = self.peg_half_sizes[env_idx, 2]
+            quat = randomization.random_quaternions(b, self.device, lock_x=True, lock_y=True, bounds=(np.pi / 2 - np.pi / 3, np.pi / 2 + np.pi / 3))
+            self.peg.set_pose(Pose.create_from_pq(pos, quat))
+
+            xy = randomization.uniform(low=torch.tensor([-0.05, 0.2]), high=torch.tensor([0.05, 0.4]), size=(b, 2))
+            pos = torch.zeros((b, 3))
+            pos[:, :2] = xy
+            pos[:, 2] = self.peg_half_sizes[env_idx, 0]
+            quat = randomization.random_quaternions(b, self.device, lock_x=True, lock_y=True, bounds=(np.pi / 2 - np.pi / 8, np.pi / 2 + np.pi / 8))
+            self.box.set_pose(Pose.create_from_pq(pos, quat))
+
+            qpos = np.array([0.0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, -np.pi / 4, 0.04, 0.04])
+            qpos = self._episode_rng.normal(0, 0.02, (b, len(qpos))) + qpos
+            qpos[:, -2:] = 0.04
+            self.agent.robot.set_qpos(qpos)
+            self.agent.robot.set_pose(sapien.Pose([-0.615, 0, 0]))
+
+    # ---- frequently used frames -------------------------------------------------
+    @property
+    def peg_head_pos(self):
+        return self.peg.pose.p + self.peg_head_offsets.p
+
+    @property
+    def peg_head_pose(self):
+        return self.peg.pose * self.peg_head_offsets
+
+    @property
+    def box_hole_pose(self):
+        return self.box.pose * self.box_hole_offsets
+
+    @property
+    def goal_pose(self):
+        return self.box.pose * self.box_hole_offsets * self.peg_head_offsets.inv()
+
+    def has_peg_inserted(self):
+        """peg head within 0.015 m of the hole centre plane and inside the hole's cross-section"""
+        head_at_hole = (self.box_hole_pose.inv() * self.peg_head_pose).p
+        r = self.box_hole_radii
+        ok = (head_at_hole[:, 0] >= -0.015) & (head_at_hole[:, 1].abs() <= r) & (head_at_hole[:, 2].abs() <= r)
+        return ok, head_at_hole
+
+    def evaluate(self):
+        success, head_at_hole = self.has_peg_inserted()
+        return dict(success=success, peg_head_pos_at_hole=head_at_hole)
+
+    def _get_obs_extra(self, info: Dict):
+        obs = dict(tcp_pose=self.agent.tcp.pose.raw_pose)
+        if self.obs_mode_struct.use_state:
+            obs.update(
+                peg_pose=self.peg.pose.raw_pose,
+                peg_half_size=self.peg_half_sizes,
+                box_hole_pose=self.box_hole_pose.raw_pose,
+                box_hole_radius=self.box_hole_radii,
+            )
+        return obs
+
+    def compute_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        # reach the grasp point 6 cm behind the peg centre
+        grasp_target = self.peg.pose * sapien.Pose([-0.06, 0, 0])
+        reach_dist = torch.linalg.norm(self.agent.tcp.pose.p - grasp_target.p, axis=1)
+        reward = 1 - torch.tanh(4.0 * reach_dist)
+
+        is_grasped = self.agent.is_grasping(self.peg, max_angle=20)
+        reward = reward + is_grasped
+
+        # align the peg centre and head with the hole axis (yz of the goal frame)
+        goal_inv = self.goal_pose.inv()
+        head_yz = torch.linalg.norm((goal_inv * self.peg_head_pose).p[:, 1:], axis=1)
+        body_yz = torch.linalg.norm((goal_inv * self.peg.pose).p[:, 1:], axis=1)
+        pre_insertion = 3 * (1 - torch.tanh(0.5 * (head_yz + body_yz) + 4.5 * torch.maximum(head_yz, body_yz)))
+        reward = reward + pre_insertion * is_grasped
+
+        pre_inserted = (head_yz < 0.01) & (body_yz < 0.01)
+        head_in_hole = self.box_hole_pose.inv() * self.peg_head_pose
+        insertion = 5 * (1 - torch.tanh(5.0 * torch.linalg.norm(head_in_hole.p, axis=1)))
+        reward = reward + insertion * (is_grasped & pre_inserted)
+
+        reward[info["success"]] = 10
+        return reward
+
+    def compute_normalized_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
+        return self.compute_dense_reward(obs, action, info) / 10

@@ -113,6 +113,10 @@ class ActorRecord:
     linear_damping: float = 0.0
     angular_damping: float = 0.0
     disable_gravity: bool = False
+    # per-env geometry (same shape types in every env, different sizes / local poses): one list of
+    # ShapeRecords per env, e.g. PegInsertionSide's pegs and boxes-with-hole built per sub-scene and
+    # merged (reference: Actor.merge, utils/structs/actor.py:99-126)
+    env_shapes: Optional[List[List[ShapeRecord]]] = None
 
 
 @dataclass
@@ -227,6 +231,7 @@ class SceneModelBuilder:
     # ------------------------------------------------------------------ #
     def compile(
         self,
+        num_envs: int = 1,
         timestep=0.01,
         gravity=(0, 0, -9.81),
         contact_offset=0.02,
@@ -336,7 +341,14 @@ class SceneModelBuilder:
         free_names, kin_names, static_names = [], [], []
         free_inertial, free_damping, free_gravity = [], [], []
         init_free, init_kin = [], []
+        free_env_slot, env_free_inertial = [], []
         for a in self.actors:
+            if a.env_shapes is not None:
+                assert len(a.env_shapes) == num_envs, f"{a.name}: per-env shapes need one entry per env"
+                sig = [(s.type) for s in a.env_shapes[0]]
+                for es in a.env_shapes:
+                    assert [(s.type) for s in es] == sig, f"{a.name}: merged actors must have the same shape types in every env"
+                a.shapes = list(a.env_shapes[0])
             if a.body_type == "dynamic":
                 if a.mass is not None:
                     m, c, I = a.mass, np.zeros(3) if a.com is None else a.com, a.inertia
@@ -350,6 +362,16 @@ class SceneModelBuilder:
                         m, c, I = 1.0, np.zeros(3), np.eye(3)  # PhysX default for shapeless bodies
                 idx = len(free_names)
                 free_names.append(a.name)
+                if a.env_shapes is not None and a.mass is None:
+                    per = []
+                    for es in a.env_shapes:
+                        items = [geom.transform_inertial(s.pose, *s.mass_properties()) for s in es]
+                        me, ce, Ie = geom.combine_inertials(items)
+                        per.append([me, *ce, *geom.inertia_mat_to_vec(Ie)])
+                    free_env_slot.append(len(env_free_inertial))
+                    env_free_inertial.append(np.asarray(per, dtype=np.float64).T)  # [10, N]
+                else:
+                    free_env_slot.append(-1)
                 free_inertial.append([m, *c, *geom.inertia_mat_to_vec(I)])
                 free_damping.append([a.linear_damping, a.angular_damping])
                 free_gravity.append(0 if a.disable_gravity else 1)
@@ -366,9 +388,13 @@ class SceneModelBuilder:
                 kind, row = BODY_WORLD, -1
             else:
                 raise ValueError(a.body_type)
-            for s in a.shapes:
+            for si, s in enumerate(a.shapes):
                 frame = s.pose if kind != BODY_WORLD else geom.compose(a.initial_pose, s.pose)
-                shapes.append(dict(rec=s, kind=kind, index=idx if kind != BODY_WORLD else 0, row=row, frame=frame, owner=a.name, link=None))
+                env = None
+                if a.env_shapes is not None:
+                    env = [es[si] for es in a.env_shapes]
+                shapes.append(dict(rec=s, kind=kind, index=idx if kind != BODY_WORLD else 0, row=row, frame=frame, owner=a.name, link=None,
+                                   env=env, world_pose=a.initial_pose if kind == BODY_WORLD else None))
         n_free, n_kin = len(free_names), len(kin_names)
         if n_free > MAX_FREE:
             raise NotImplementedError(f"n_free={n_free} exceeds MSSIM_MAX_FREE={MAX_FREE}")
@@ -379,7 +405,24 @@ class SceneModelBuilder:
         # ---------------- shape tables ----------------
         hull_verts = []
         st, sk, si, srow, sframe, sparam, smat, shull, sbound = [], [], [], [], [], [], [], [], []
+        shape_env_slot, env_frame, env_param, env_bound = [], [], [], []
         for s in shapes:
+            if s.get("env") is not None:
+                if s["rec"].type == "convex":
+                    raise NotImplementedError("per-env convex meshes are not supported (sizes / poses of primitive shapes only)")
+                fr, pr, bd = [], [], []
+                for r_e in s["env"]:
+                    f_e = r_e.pose if s["world_pose"] is None else geom.compose(s["world_pose"], r_e.pose)
+                    c_e, rad_e = r_e.bound()
+                    fr.append(f_e)
+                    pr.append(r_e.param())
+                    bd.append([*geom.transform_point(f_e, c_e), rad_e])
+                shape_env_slot.append(len(env_frame))
+                env_frame.append(np.asarray(fr, dtype=np.float64).T)  # [7, N]
+                env_param.append(np.asarray(pr, dtype=np.float64).T)  # [4, N]
+                env_bound.append(np.asarray(bd, dtype=np.float64).T)  # [4, N]: centre in the BODY frame, radius
+            else:
+                shape_env_slot.append(-1)
             r: ShapeRecord = s["rec"]
             st.append(_SHAPE_NAMES[r.type])
             sk.append(s["kind"])
@@ -473,6 +516,14 @@ class SceneModelBuilder:
         A["shape_bound"] = arr(sbound, f32, (ns, 4))
         A["hull_verts"] = arr(hull_verts, f32, (len(hull_verts), 3))
         A["pair_shape"] = arr(pairs, i32, (len(pairs), 2))
+        # per-env overrides ([items][N], env fastest -- the layout the kernels read directly)
+        n_es, n_ef = len(env_frame), len(env_free_inertial)
+        A["shape_env_slot"] = arr(shape_env_slot, i32, (ns,))
+        A["env_shape_frame"] = arr(np.concatenate(env_frame) if n_es else [], f32, (7 * n_es, num_envs))
+        A["env_shape_param"] = arr(np.concatenate(env_param) if n_es else [], f32, (4 * n_es, num_envs))
+        A["env_shape_bound"] = arr(np.concatenate(env_bound) if n_es else [], f32, (4 * n_es, num_envs))
+        A["free_env_slot"] = arr(free_env_slot, i32, (n_free,))
+        A["env_free_inertial"] = arr(np.concatenate(env_free_inertial) if n_ef else [], f32, (10 * n_ef, num_envs))
         # initial state (not part of the C model; used by the python system at gpu_init)
         A["init_root_pose"] = arr(art.initial_pose if art is not None else geom.pose(), f32, (7,))
         A["init_free_pose"] = arr(init_free, f32, (n_free, 7))
@@ -487,6 +538,9 @@ class SceneModelBuilder:
             n_shape=ns,
             n_hull_verts=len(hull_verts),
             n_pair=len(pairs),
+            n_env_shape=n_es,
+            n_env_free=n_ef,
+            num_envs=int(num_envs),
             gravity=tuple(float(g) for g in gravity),
             timestep=float(timestep),
             contact_offset=float(contact_offset),

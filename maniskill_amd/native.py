@@ -13,7 +13,7 @@ import numpy as np
 from . import PACKAGE_DIR
 from .model.compile import CompiledModel
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NATIVE_LIB_PATH = os.path.join(PACKAGE_DIR, "_native", "libmssim.so")
 
 # apply / fetch selector bits (include/mssim.h)
@@ -83,6 +83,15 @@ class ModelDesc(C.Structure):
         ("erp", C.c_float),
         ("max_depenetration_velocity", C.c_float),
         ("sleep_threshold", C.c_float),
+        ("num_envs", C.c_int32),
+        ("n_env_shape", C.c_int32),
+        ("shape_env_slot", _I32P),
+        ("env_shape_frame", _F32P),
+        ("env_shape_param", _F32P),
+        ("env_shape_bound", _F32P),
+        ("n_env_free", C.c_int32),
+        ("free_env_slot", _I32P),
+        ("env_free_inertial", _F32P),
     ]
 
 

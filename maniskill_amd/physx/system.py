@@ -114,6 +114,10 @@ class MssimSystem:
         assert self._sim is None, "gpu_init called twice"
         self.model, self.num_envs = model, int(num_envs)
         model.scalars["timestep"] = self._timestep
+        if model.scalars.get("n_env_shape", 0) or model.scalars.get("n_env_free", 0):
+            assert model.scalars["num_envs"] == self.num_envs, "model with per-env geometry was compiled for a different num_envs"
+        else:
+            model.scalars["num_envs"] = self.num_envs
         N, R, n = self.num_envs, model.n_rows, model.n_dof
         dev = self.device
         f = dict(dtype=torch.float32, device=dev)

@@ -65,12 +65,11 @@ class ActorBuilder:
         return self
 
     def set_scene_idxs(self, scene_idxs=None):
-        if scene_idxs is not None and len(scene_idxs) != self.scene.num_envs:
-            raise NotImplementedError(
-                "per-env distinct object sets (scene_idxs subsets / Actor.merge) are not supported by this core yet "
-                "(SURVEY.md 8f rank 4)"
-            )
-        self.scene_idxs = scene_idxs
+        """Restrict the actor to some envs. A proper subset yields a *fragment* that must later be
+        combined with `Actor.merge` into one actor present in every env with per-env geometry
+        (same shape types, different sizes / poses), as PegInsertionSide does
+        (peg_insertion_side.py:114-181). Objects that exist in only some envs are not supported."""
+        self.scene_idxs = None if scene_idxs is None else [int(i) for i in scene_idxs]
         return self
 
     def set_collision_groups(self, groups):
@@ -154,6 +153,13 @@ class ActorBuilder:
         for s in self.shapes:
             s.collision_groups = tuple(self.collision_groups)
         init = Pose.create(self.initial_pose if self.initial_pose is not None else Pose.create_from_pq(), device=self.scene.device)
+        if self.scene_idxs is not None and len(self.scene_idxs) != self.scene.num_envs:
+            # fragment: lives in a subset of envs until merged
+            frag = Actor(self.scene, self.name, self.physx_body_type, init, has_collision_shapes=len(self.shapes) > 0)
+            frag._fragment = dict(scene_idxs=list(self.scene_idxs), shapes=list(self.shapes), linear_damping=self.linear_damping,
+                                  angular_damping=self.angular_damping)
+            self.scene._fragments[self.name] = frag
+            return frag
         raw = common.to_numpy(init.raw_pose)
         if raw.shape[0] != 1:
             # per-env initial poses: the model keeps env 0's pose; the rest are written after gpu_init

@@ -92,3 +92,11 @@ def apply_urdf_config(loader, urdf_config: dict):
     if "material" in urdf_config:
         m = urdf_config["material"]
         loader.set_material(m["static_friction"], m["dynamic_friction"], m["restitution"])
+
+
+def hex2rgba(h, correction=True):
+    """'#RRGGBB' -> linear rgba (gamma 2.2 undone when `correction`)"""
+    h = h.lstrip("#")
+    rgb = [int(h[i : i + 2], 16) / 255 for i in (0, 2, 4)]
+    rgba = np.array(rgb + [1.0])
+    return rgba**2.2 if correction else rgba

@@ -110,6 +110,45 @@ class Actor(_RigidBase):
         self.before_hide_pose = None
         self._body_row = None
         self.merged = False
+        self._fragment = None
+
+    @classmethod
+    def merge(cls, actors: List["Actor"], name: str = None) -> "Actor":
+        """Combine per-env fragments (built with `set_scene_idxs([i])`) into one actor that exists
+        in every env with per-env geometry. Counterpart of the reference's merged views
+        (utils/structs/actor.py:99-126), restricted to the case this core supports: every env gets
+        exactly one fragment and all fragments have the same shape types."""
+        from maniskill_amd.model import geom
+        from maniskill_amd.model.compile import ActorRecord
+
+        scene = actors[0].scene
+        N = scene.num_envs
+        by_env = {}
+        for a in actors:
+            assert a._fragment is not None, f"{a.name} is not a per-env fragment (build it with set_scene_idxs)"
+            for i in a._fragment["scene_idxs"]:
+                assert i not in by_env, f"env {i} has more than one fragment"
+                by_env[i] = a
+        assert sorted(by_env) == list(range(N)), "Actor.merge needs exactly one fragment per env (objects present in only some envs are not supported)"
+        first = by_env[0]
+        assert all(by_env[i].px_body_type == first.px_body_type for i in range(N))
+        name = name if name is not None else first.name
+        raw = torch.cat([by_env[i].initial_pose.raw_pose[:1] for i in range(N)], dim=0)
+        p0 = common.to_numpy(raw[0])
+        rec = ActorRecord(
+            name, first.px_body_type, list(first._fragment["shapes"]), initial_pose=geom.pose(p0[:3], p0[3:]),
+            linear_damping=first._fragment["linear_damping"], angular_damping=first._fragment["angular_damping"],
+            env_shapes=[list(by_env[i]._fragment["shapes"]) for i in range(N)],
+        )
+        masses = [sum(s.mass_properties()[0] for s in by_env[i]._fragment["shapes"]) for i in range(N)]
+        merged = cls(scene, name, first.px_body_type, Pose.create(raw), has_collision_shapes=first.has_collision_shapes, mass=0.0)
+        merged._mass_per_env = torch.tensor(masses, dtype=torch.float32)
+        merged.merged = True
+        for a in actors:
+            scene._fragments.pop(a.name, None)
+        scene._register_actor(merged, rec)
+        scene.remove_from_state_dict_registry(merged)  # callers add merged actors explicitly (peg_insertion_side.py:176-181)
+        return merged
 
     # ---- state dict ----------------------------------------------------------
     def get_state(self):
@@ -169,6 +208,8 @@ class Actor(_RigidBase):
 
     @property
     def mass(self):
+        if getattr(self, "_mass_per_env", None) is not None:
+            return self._mass_per_env.to(self.device)
         return torch.full((self.scene.num_envs,), float(self._mass), device=self.device)
 
     def get_mass(self):

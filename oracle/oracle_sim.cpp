@@ -62,6 +62,10 @@ struct Model {
   std::vector<float> free_inertial, free_damping;
   std::vector<int32_t> shape_type, shape_kind, shape_index, shape_row, shape_hull, pair_shape;
   std::vector<float> shape_frame, shape_param, shape_material, shape_bound, hull_verts;
+  // per-env overrides ([items][N])
+  int N = 0, n_env_shape = 0, n_env_free = 0;
+  std::vector<int32_t> shape_env_slot, free_env_slot;
+  std::vector<float> env_shape_frame, env_shape_param, env_shape_bound, env_free_inertial;
   Real gravity[3], dt, contact_offset, rest_offset, erp, max_depen;
   int pos_iters, vel_iters;
 };
@@ -157,31 +161,53 @@ Pose<Real> body_world_pose(const Model& M, const EnvState& E, int kind, int inde
   }
 }
 
-Shape<Real> make_shape(const Model& M, const EnvState& E, int s) {
+Shape<Real> make_shape(const Model& M, const EnvState& E, int s, int e) {
   Shape<Real> sh;
-  Pose<Real> W = pmul(body_world_pose(M, E, M.shape_kind[s], M.shape_index[s]), pose7(&M.shape_frame[7 * s]));
+  const int slot = M.shape_env_slot.empty() ? -1 : M.shape_env_slot[s];
+  float fr[7], pr[4];
+  for (int k = 0; k < 7; k++) fr[k] = slot < 0 ? M.shape_frame[7 * s + k] : M.env_shape_frame[(size_t)(7 * slot + k) * M.N + e];
+  for (int k = 0; k < 4; k++) pr[k] = slot < 0 ? M.shape_param[4 * s + k] : M.env_shape_param[(size_t)(4 * slot + k) * M.N + e];
+  Pose<Real> W = pmul(body_world_pose(M, E, M.shape_kind[s], M.shape_index[s]), pose7(fr));
   sh.type = M.shape_type[s];
   sh.c = W.p;
   sh.rot = qmat(W.q);
-  for (int k = 0; k < 4; k++) sh.param[k] = M.shape_param[4 * s + k];
+  for (int k = 0; k < 4; k++) sh.param[k] = pr[k];
   sh.verts = M.hull_verts.data() + 3 * M.shape_hull[2 * s];
   sh.nverts = M.shape_hull[2 * s + 1];
   return sh;
 }
 
 // ------------------------------------------------------------------ narrowphase over the pair table
-void narrowphase(const Model& M, EnvState& E, std::vector<Contact>& out) {
+// bounding sphere of shape s in env e: centre in the BODY frame, radius
+inline void shape_bound_body(const Model& M, int s, int e, Vec& c, Real& r) {
+  const int slot = M.shape_env_slot.empty() ? -1 : M.shape_env_slot[s];
+  if (slot >= 0) {
+    const float* b = M.env_shape_bound.data();
+    c = Vec(b[(size_t)(4 * slot) * M.N + e], b[(size_t)(4 * slot + 1) * M.N + e], b[(size_t)(4 * slot + 2) * M.N + e]);
+    r = b[(size_t)(4 * slot + 3) * M.N + e];
+  } else {
+    Pose<Real> F = pose7(&M.shape_frame[7 * s]);
+    c = F.p + qrot(F.q, Vec(M.shape_bound[4 * s], M.shape_bound[4 * s + 1], M.shape_bound[4 * s + 2]));
+    r = M.shape_bound[4 * s + 3];
+  }
+}
+
+void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) {
   out.clear();
   E.pair_count.assign(M.n_pair, 0);
   std::vector<Shape<Real>> sh(M.n_shape);
-  for (int s = 0; s < M.n_shape; s++) sh[s] = make_shape(M, E, s);
+  for (int s = 0; s < M.n_shape; s++) sh[s] = make_shape(M, E, s, e);
   for (int p = 0; p < M.n_pair; p++) {
     int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
     const Shape<Real>&A = sh[sa], &B = sh[sb];
     // bounding-sphere cull
-    Real ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
-    Vec ca = A.c + A.rot * Vec(M.shape_bound[4 * sa], M.shape_bound[4 * sa + 1], M.shape_bound[4 * sa + 2]);
-    Vec cb = B.c + B.rot * Vec(M.shape_bound[4 * sb], M.shape_bound[4 * sb + 1], M.shape_bound[4 * sb + 2]);
+    Real ra, rb;
+    Vec cla, clb;
+    shape_bound_body(M, sa, e, cla, ra);
+    shape_bound_body(M, sb, e, clb, rb);
+    Pose<Real> PA = body_world_pose(M, E, M.shape_kind[sa], M.shape_index[sa]), PB = body_world_pose(M, E, M.shape_kind[sb], M.shape_index[sb]);
+    Vec ca = PA.p + qrot(PA.q, cla);
+    Vec cb = PB.p + qrot(PB.q, clb);
     if (A.type == SH_PLANE) {
       if (dot(A.rot.col(0), cb - A.c) > rb + M.contact_offset) continue;
     } else {
@@ -241,7 +267,7 @@ struct Row {
 };
 
 // ------------------------------------------------------------------ one substep
-void substep(mssim_sim* S, EnvState& E) {
+void substep(mssim_sim* S, EnvState& E, int e) {
   const Model& M = S->M;
   const int n = M.n_dof, nf = M.n_free;
   const Real dt = M.dt;
@@ -253,7 +279,7 @@ void substep(mssim_sim* S, EnvState& E) {
   fk(M, E, &axis_w, &anchor);
   // 2. narrowphase
   std::vector<Contact> contacts;
-  narrowphase(M, E, contacts);
+  narrowphase(M, E, e, contacts);
 
   // 3. joint-space dynamics
   std::vector<SpatialV> Sj(n);
@@ -362,8 +388,14 @@ void substep(mssim_sim* S, EnvState& E) {
   std::vector<Vec> fv(nf), fw(nf), fcom(nf);
   std::vector<Mat> fIinv(nf);
   std::vector<Real> fminv(nf);
+  std::vector<float> finert(10 * (nf > 0 ? nf : 1));
   for (int b = 0; b < nf; b++) {
-    const float* in = &M.free_inertial[10 * b];
+    const int fslot = M.free_env_slot.empty() ? -1 : M.free_env_slot[b];
+    for (int k = 0; k < 10; k++)
+      finert[10 * b + k] = fslot < 0 ? M.free_inertial[10 * b + k] : M.env_free_inertial[(size_t)(10 * fslot + k) * M.N + e];
+  }
+  for (int b = 0; b < nf; b++) {
+    const float* in = &finert[10 * b];
     Mat Rm = qmat(E.free_pose[b].q);
     Real Iv[6] = {in[4], in[5], in[6], in[7], in[8], in[9]};
     Mat Iw = mmul(mmul(Rm, sym3(Iv)), mtranspose(Rm));
@@ -501,7 +533,7 @@ void substep(mssim_sim* S, EnvState& E) {
     E.qd[j] = v[j];
   }
   for (int b = 0; b < nf; b++) {
-    const float* in = &M.free_inertial[10 * b];
+    const float* in = &finert[10 * b];
     Vec com = fcom[b] + fv_pos[b] * dt;
     Quat q = E.free_pose[b].q;
     Vec w = fw_pos[b];
@@ -555,6 +587,16 @@ int mssim_ref_create(const mssim_model_desc* d, int32_t num_envs, int32_t device
   M.shape_row = cp(d->shape_row, ns); M.shape_frame = cp(d->shape_frame, 7 * ns); M.shape_param = cp(d->shape_param, 4 * ns);
   M.shape_material = cp(d->shape_material, 4 * ns); M.shape_hull = cp(d->shape_hull, 2 * ns); M.shape_bound = cp(d->shape_bound, 4 * ns);
   M.hull_verts = cp(d->hull_verts, 3 * d->n_hull_verts); M.pair_shape = cp(d->pair_shape, 2 * d->n_pair);
+  M.N = num_envs;
+  M.n_env_shape = d->n_env_shape; M.n_env_free = d->n_env_free;
+  if ((d->n_env_shape > 0 || d->n_env_free > 0) && d->num_envs != num_envs) { g_create_error = "per-env arrays were built for a different num_envs"; delete S; return 5; }
+  M.shape_env_slot = cp(d->shape_env_slot, ns); M.free_env_slot = cp(d->free_env_slot, d->n_free);
+  if (d->n_env_shape == 0) std::fill(M.shape_env_slot.begin(), M.shape_env_slot.end(), -1);
+  if (d->n_env_free == 0) std::fill(M.free_env_slot.begin(), M.free_env_slot.end(), -1);
+  M.env_shape_frame = cp(d->env_shape_frame, (size_t)7 * d->n_env_shape * num_envs);
+  M.env_shape_param = cp(d->env_shape_param, (size_t)4 * d->n_env_shape * num_envs);
+  M.env_shape_bound = cp(d->env_shape_bound, (size_t)4 * d->n_env_shape * num_envs);
+  M.env_free_inertial = cp(d->env_free_inertial, (size_t)10 * d->n_env_free * num_envs);
   for (int k = 0; k < 3; k++) M.gravity[k] = d->gravity[k];
   M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
   M.max_depen = d->max_depenetration_velocity; M.pos_iters = d->position_iterations; M.vel_iters = d->velocity_iterations;
@@ -675,7 +717,7 @@ int mssim_ref_step(mssim_handle h, int32_t n_substeps, void*) {
   const int N = h->N;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < N; e++)
-    for (int s = 0; s < n_substeps; s++) substep(h, h->env[e]);
+    for (int s = 0; s < n_substeps; s++) substep(h, h->env[e], e);
   return 0;
 }
 

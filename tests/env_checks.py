@@ -235,3 +235,45 @@ def check_scripted_pick_and_lift(sim_backend):
     assert base.cube.pose.p[0, 2].item() > 0.12, base.cube.pose.p
     assert r1.item() > r0.item() + 0.15  # grasp bonus of the dense reward
     env.close()
+
+
+def check_peg_insertion(sim_backend, device_type):
+    """PegInsertionSide-v1: per-env peg / box geometry reaches the collision core (the reference builds
+    one actor per env and merges them, peg_insertion_side.py:134-181; its tests only step the env,
+    tests/test_gpu_envs.py:39-118, so the physical expectations here are ours: parity unpinned)."""
+    N = 8
+    env = make("PegInsertionSide-v1", N, sim_backend)
+    base = env.unwrapped
+    obs, _ = env.reset(seed=3)
+    assert obs.shape == (N, 43) and obs.device.type == device_type
+    hs = base.peg_half_sizes
+    assert hs.shape == (N, 3) and len(torch.unique(hs[:, 0])) == N and len(torch.unique(hs[:, 1])) == N
+    assert torch.all((hs[:, 0] >= 0.085) & (hs[:, 0] <= 0.125) & (hs[:, 1] >= 0.015) & (hs[:, 1] <= 0.025))
+    assert torch.allclose(base.box_hole_radii, hs[:, 1] + 0.003)
+    assert torch.allclose(base.peg.mass.cpu(), (8 * hs[:, 0] * hs[:, 1] * hs[:, 2] * 1000).cpu(), rtol=1e-4)
+    zero = torch.zeros(N, 8, device=base.device)
+    for _ in range(10):
+        obs, rew, term, trunc, info = env.step(zero)
+    # every peg rests on the table at its own half-width
+    assert torch.allclose(base.peg.pose.p[:, 2], hs[:, 1], atol=1e-3), (base.peg.pose.p[:, 2] - hs[:, 1]).abs().max()
+    assert not info["success"].any()
+    assert base.scene.px.overflow_count() == 0
+    # teleport the peg into the hole: it fits (3 mm clearance), counts as inserted, and settles on the
+    # lower slab of that env's box (hole centres differ per env)
+    base.peg.set_pose(base.goal_pose)
+    base.peg.set_linear_velocity(torch.zeros(N, 3, device=base.device))
+    base.peg.set_angular_velocity(torch.zeros(N, 3, device=base.device))
+    base.scene._gpu_apply_all()
+    base.scene._gpu_fetch_all()
+    assert base.evaluate()["success"].all()
+    for _ in range(10):
+        obs, rew, term, trunc, info = env.step(zero)
+    assert info["success"].all()
+    head = info["peg_head_pos_at_hole"]
+    assert torch.allclose(head[:, 2], torch.full_like(head[:, 2], -0.003), atol=1.5e-3), head[:, 2]
+    assert torch.all(head[:, 1].abs() <= 0.003 + 1e-3)
+    assert torch.allclose(rew, torch.full_like(rew, 1.0))  # normalized dense reward: 10 / 10 on success
+    # state dict keeps the merged actors
+    sd = base.get_state_dict()
+    assert set(sd["actors"].keys()) >= {"peg", "box_with_hole"} and not any(k.startswith("peg_") for k in sd["actors"])
+    env.close()

@@ -46,6 +46,27 @@ def test_scripted_pick_and_lift():
     ec.check_scripted_pick_and_lift(BACKEND)
 
 
+def test_peg_insertion_per_env_geometry():
+    ec.check_peg_insertion(BACKEND, "cpu")
+
+
+def test_unmerged_fragment_is_rejected():
+    """objects that exist in only some envs are not supported: the scene must say so, not mis-simulate"""
+    import gymnasium as gym
+    from maniskill_amd.envs.tasks.tabletop.pick_cube import PickCubeEnv
+
+    class Partial(PickCubeEnv):
+        def _load_scene(self, options):
+            super()._load_scene(options)
+            b = self.scene.create_actor_builder()
+            b.add_box_collision(half_size=[0.02] * 3)
+            b.set_scene_idxs([0])
+            b.build("only_in_env0")
+
+    with pytest.raises(NotImplementedError):
+        Partial(num_envs=4, sim_backend=BACKEND)
+
+
 def test_hip_backend_fails_loudly_without_gpu():
     import gymnasium as gym
 

@@ -42,7 +42,12 @@ def test_scripted_pick_and_lift():
     ec.check_scripted_pick_and_lift(BACKEND)
 
 
-def test_env_rollout_matches_oracle_backend():
+def test_peg_insertion_per_env_geometry():
+    ec.check_peg_insertion(BACKEND, "cuda")
+
+
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PegInsertionSide-v1"])
+def test_env_rollout_matches_oracle_backend(env_id):
     """same seed, same actions: obs / reward of the HIP env track the oracle-backed env for the first
     control steps (contact-light PickCube start states), within 1e-3 (positions / angles)."""
     import gymnasium as gym
@@ -51,10 +56,12 @@ def test_env_rollout_matches_oracle_backend():
     N = 32
     g = torch.Generator().manual_seed(0)
     acts = [2 * torch.rand(N, 8, generator=g) - 1 for _ in range(5)]
+    # PegInsertionSide samples per-env geometry from the seeded numpy episode RNG, so both backends
+    # build the same pegs / boxes
     outs = []
     ref_state = None
     for backend in ("oracle_f64_env", BACKEND):
-        env = gym.make("PickCube-v1", num_envs=N, sim_backend=backend)
+        env = gym.make(env_id, num_envs=N, sim_backend=backend)
         obs, _ = env.reset(seed=11)
         # torch.rand differs between the CPU and the GPU generator (as in the reference, whose CPU
         # and GPU sims also place objects differently), so start both from the oracle env's state
