@@ -36,6 +36,24 @@
 #define S16_ENV_FLOATS (S16_U + S16_ROWLEN * S16_ROWS_LDS)  // 3248 floats = 12992 B per env
 #define S16_ROWS_GLB (16 + 3 * MAXC - S16_ROWS_LDS)
 
+// Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
+// thread 0 of every block adds the cycles spent since the previous mark to g_phase_clk[i].
+#ifdef MSSIM_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clk[16];
+#define PH_INIT long long ph_t = clock64();
+#define PH(i)                                                               \
+  do {                                                                      \
+    if (threadIdx.x == 0) {                                                 \
+      long long t_ = clock64();                                             \
+      atomicAdd(&g_phase_clk[i], (unsigned long long)(t_ - ph_t));          \
+      ph_t = t_;                                                            \
+    }                                                                       \
+  } while (0)
+#else
+#define PH_INIT
+#define PH(i)
+#endif
+
 template <int CTRL>
 MS_DEV float dpp_f(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
@@ -79,6 +97,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   const int fk = freel ? fc % 6 : 0;  // 0..2 linear xyz, 3..5 angular xyz
   const int fbase = n + 6 * fb_id;
 
+  PH_INIT
   // ---------------------------------------------------------------- state
   const pose_t root = pose_soa(S.root, 0, N, e);
   const f3 O = root.p;
@@ -107,6 +126,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   }
   const unsigned self_c = art ? (1u << c) : 0u;
 
+  PH(0);
   // ---------------------------------------------------------------- dynamics: RNEA bias + CRBA
   sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
   if (art) S_c = rev_c ? sv6{aw_c, cross(an_c - O, aw_c)} : sv6{f3{0, 0, 0}, aw_c};
@@ -218,6 +238,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   }
   float rhs_c = art ? mv + dt * (tau0 + tau_t - bias_c + qf_c) : 0.f;
 
+  PH(1);
   // ---------------------------------------------------------------- A^-1 by Gauss-Jordan (row per lane)
   float Irow[16];
   float vstar = 0.f;
@@ -272,6 +293,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     for (int k = 0; k < 16; k++) Irow[k] = 0.f;
   }
 
+  PH(2);
   // ---------------------------------------------------------------- free bodies
   float v_c = art ? vstar : 0.f;
   f3 mycom = f3{0, 0, 0};
@@ -309,6 +331,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   }
   __syncthreads();  // the dynamics staging area is dead from here on: rows overlay it
 
+  PH(3);
   // ---------------------------------------------------------------- rows
   float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
   // joint limits: row j for joint j. J = side_j e_j, W = side_j * column j of A^-1 (kept in LDS
@@ -423,6 +446,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   }
   __syncthreads();
 
+  PH(4);
   // ---------------------------------------------------------------- projected Gauss-Seidel
   const int nr_lds = nrow < lds_limit ? nrow : lds_limit;  // rows held in LDS (limits + whole contact blocks)
   const int nc_lds = (nr_lds - n) / 3, nc_glb = (nrow - nr_lds) / 3;
@@ -541,6 +565,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     }
   }
 
+  PH(5);
   // ---------------------------------------------------------------- contact impulses per pair
   {
     int prev_p = -1;
@@ -568,6 +593,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     if (prev_p >= 0 && c == 0 && live) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
   }
 
+  PH(6);
   // ---------------------------------------------------------------- write back + FK at the new state
   if (art && live) {
     SOA(S.qacc, c) = (v_c - qd_c) / dt;
@@ -629,4 +655,5 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     a[3 * (size_t)N] = nan.x; a[4 * (size_t)N] = nan.y; a[5 * (size_t)N] = nan.z;
   }
   if (live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
+  PH(7);
 }

@@ -89,6 +89,7 @@ class PegInsertionSideEnv(BaseEnv):
             self.box_hole_offsets = Pose.create_from_pq(p=hole)
             self.box_hole_radii = common.to_tensor(radii + self._clearance, device=self.device).float()
 
+            self._grasp_offset = Pose.create_from_pq(p=torch.tensor([[-0.06, 0.0, 0.0]]))  # panda gripper width + leeway
             pegs, boxes = [], []
             head_mat = sapien.render.RenderMaterial(base_color=sapien_utils.hex2rgba("#EC7357"), roughness=0.5, specular=0.5)
             tail_mat = sapien.render.RenderMaterial(base_color=sapien_utils.hex2rgba("#EDF6F9"), roughness=0.5, specular=0.5)
@@ -181,7 +182,7 @@ class PegInsertionSideEnv(BaseEnv):
 
     def compute_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
         # reach the grasp point 6 cm behind the peg centre
-        grasp_target = self.peg.pose * sapien.Pose([-0.06, 0, 0])
+        grasp_target = self.peg.pose * self._grasp_offset
         reach_dist = torch.linalg.norm(self.agent.tcp.pose.p - grasp_target.p, axis=1)
         reward = 1 - torch.tanh(4.0 * reach_dist)
 
@@ -200,8 +201,7 @@ class PegInsertionSideEnv(BaseEnv):
         insertion = 5 * (1 - torch.tanh(5.0 * torch.linalg.norm(head_in_hole.p, axis=1)))
         reward = reward + insertion * (is_grasped & pre_inserted)
 
-        reward[info["success"]] = 10
-        return reward
+        return torch.where(info["success"], torch.full_like(reward, 10.0), reward)
 
     def compute_normalized_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
         return self.compute_dense_reward(obs, action, info) / 10

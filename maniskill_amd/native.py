@@ -14,7 +14,7 @@ from . import PACKAGE_DIR
 from .model.compile import CompiledModel
 
 ABI_VERSION = 2
-NATIVE_LIB_PATH = os.path.join(PACKAGE_DIR, "_native", "libmssim.so")
+NATIVE_LIB_PATH = os.environ.get("MSSIM_LIB") or os.path.join(PACKAGE_DIR, "_native", "libmssim.so")  # MSSIM_LIB: debug builds of the same HIP library
 
 # apply / fetch selector bits (include/mssim.h)
 RIGID_DATA = 1 << 0

@@ -9,17 +9,13 @@ import torch
 
 
 def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    aw, ax, ay, az = torch.unbind(a, -1)
-    bw, bx, by, bz = torch.unbind(b, -1)
-    return torch.stack(
-        (
-            aw * bw - ax * bx - ay * by - az * bz,
-            aw * bx + ax * bw + ay * bz - az * by,
-            aw * by - ax * bz + ay * bw + az * bx,
-            aw * bz + ax * by - ay * bx + az * bw,
-        ),
-        -1,
-    )
+    """Hamilton product in scalar / vector form (w = aw bw - av.bv, v = aw bv + bw av + av x bv):
+    the same product as the component-wise expansion, in ~9 launches instead of ~30"""
+    aw, av = a[..., :1], a[..., 1:]
+    bw, bv = b[..., :1], b[..., 1:]
+    w = aw * bw - (av * bv).sum(-1, keepdim=True)
+    v = aw * bv + bw * av + torch.linalg.cross(av, bv, dim=-1)
+    return torch.cat((w, v), -1)
 
 
 def standardize_quaternion(q: torch.Tensor) -> torch.Tensor:
@@ -32,16 +28,18 @@ def quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def quaternion_invert(q: torch.Tensor) -> torch.Tensor:
-    return q * q.new_tensor([1, -1, -1, -1])
+    return torch.cat((q[..., :1], -q[..., 1:]), -1)
 
 
 def quaternion_apply(q: torch.Tensor, point: torch.Tensor) -> torch.Tensor:
+    """rotate points by unit quaternions: p + 2 w (v x p) + 2 v x (v x p), which equals the vector
+    part of q (0,p) q* for unit q"""
     if point.size(-1) != 3:
         raise ValueError(f"Points are not in 3D, {point.shape}.")
-    zero = point.new_zeros(point.shape[:-1] + (1,))
-    pq = torch.cat((zero, point), -1)
-    out = quaternion_raw_multiply(quaternion_raw_multiply(q, pq), quaternion_invert(q))
-    return out[..., 1:]
+    w, v = q[..., :1], q[..., 1:]
+    v, point = torch.broadcast_tensors(v, point)
+    t = 2 * torch.linalg.cross(v, point, dim=-1)
+    return point + w * t + torch.linalg.cross(v, t, dim=-1)
 
 
 def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:

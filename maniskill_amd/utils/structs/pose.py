@@ -91,10 +91,8 @@ class Pose:
         return Pose.create_from_pq(a.p + quaternion_apply(a.q, other.p), quaternion_multiply(a.q, other.q))
 
     def inv(self) -> "Pose":
-        inv = self.raw_pose.clone()
-        inv[..., 4:] = -inv[..., 4:]
-        inv[..., :3] = quaternion_apply(inv[..., 3:], -self.p)
-        return Pose.create(inv)
+        q = torch.cat((self.raw_pose[..., 3:4], -self.raw_pose[..., 4:]), -1)
+        return Pose.create(torch.cat((quaternion_apply(q, -self.p), q), -1))
 
     def to_transformation_matrix(self):
         b = self.raw_pose.shape[0]

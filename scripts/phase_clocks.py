@@ -1,0 +1,39 @@
+"""cycles per phase of k_solve16 (debug build with -DMSSIM_PHASE_CLOCKS, loaded through MSSIM_LIB).
+usage: python scripts/phase_clocks.py [env_id] [N] [steps]   (builds the variant library itself)"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib = os.path.join(ROOT, "maniskill_amd", "_native", "libmssim_clk.so")
+src = os.path.join(ROOT, "maniskill_amd", "csrc", "mssim_kernels.hip")
+if "--build" in sys.argv or not os.path.exists(lib):
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+                    "-DMSSIM_PHASE_CLOCKS", "-o", lib, src], check=True)
+    if "--build" in sys.argv:
+        sys.exit(0)
+os.environ["MSSIM_LIB"] = lib
+import torch
+import maniskill_amd.envs  # noqa
+import gymnasium as gym
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+env_id = args[0] if len(args) > 0 else "PickCube-v1"
+N = int(args[1]) if len(args) > 1 else 4096
+steps = int(args[2]) if len(args) > 2 else 100
+env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos")
+env.reset(seed=0)
+dbg = ctypes.CDLL(lib)
+buf = (ctypes.c_ulonglong * 16)()
+names = ["state load", "RNEA+CRBA", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK"]
+for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" % steps, steps)):
+    torch.cuda.synchronize()
+    dbg.mssim_debug_phase_clocks(buf, 1)
+    for _ in range(k):
+        env.step(2 * torch.rand(N, 8, device="cuda") - 1)
+    torch.cuda.synchronize()
+    dbg.mssim_debug_phase_clocks(buf, 1)
+    tot = sum(buf[i] for i in range(8))
+    launches = k * 5
+    blocks = (N + 3) // 4
+    print(f"{env_id} N={N} {phase_name}: {tot / launches / blocks:.0f} cycles per block-launch")
+    for i, nm in enumerate(names):
+        print(f"  {nm:14s} {buf[i] / launches / blocks:9.0f} cycles  {100.0 * buf[i] / tot:5.1f} %")
