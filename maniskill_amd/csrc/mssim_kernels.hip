@@ -1519,10 +1519,10 @@ int mssim_overflow_count(mssim_handle h, void* stream) {
 
 #ifdef MSSIM_PHASE_CLOCKS
 // debug builds only (not part of include/mssim.h): cycles per phase of k_solve16 summed over blocks
-extern "C" int mssim_debug_phase_clocks(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clk), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int mssim_debug_phase_clocks(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_clk), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

@@ -39,19 +39,27 @@
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // thread 0 of every block adds the cycles spent since the previous mark to g_phase_clk[i].
 #ifdef MSSIM_PHASE_CLOCKS
-__device__ unsigned long long g_phase_clk[16];
-#define PH_INIT long long ph_t = clock64();
-#define PH(i)                                                               \
-  do {                                                                      \
-    if (threadIdx.x == 0) {                                                 \
-      long long t_ = clock64();                                             \
-      atomicAdd(&g_phase_clk[i], (unsigned long long)(t_ - ph_t));          \
-      ph_t = t_;                                                            \
-    }                                                                       \
+__device__ unsigned long long g_phase_clk[32];
+// deltas are kept in registers and flushed once at the end (an atomic per mark costs more than a phase)
+#define PH_INIT                 \
+  unsigned ph_d[32];            \
+  _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) ph_d[i_] = 0u; \
+  unsigned ph_t = (unsigned)clock64();
+#define PH(i)                                   \
+  do {                                          \
+    __builtin_amdgcn_s_waitcnt(0);              \
+    ph_d[i] += (unsigned)clock64() - ph_t;      \
+    ph_t = (unsigned)clock64();                 \
   } while (0)
+#define PH_FLUSH                                                                  \
+  if (threadIdx.x == 0) {                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++)                             \
+      if (ph_d[i_]) atomicAdd(&g_phase_clk[i_], (unsigned long long)ph_d[i_]);    \
+  }
 #else
 #define PH_INIT
 #define PH(i)
+#define PH_FLUSH
 #endif
 
 template <int CTRL>
@@ -109,7 +117,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   float kp = 0.f, kd = 0.f, fmax = 3e38f, arm = 0.f, lo_c = -3e38f, hi_c = 3e38f;
   float inert[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool grav_c = false, accel_mode = false;
+  pose_t JF_c = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};  // joint frame in the parent body frame
+  f3 al_c = f3{0, 0, 0};                            // joint axis in the joint frame
+  int par_c = -1;
   if (art) {
+    JF_c = pose_from(M.dof_frame + 7 * c);
+    al_c = f3{M.dof_axis[3 * c], M.dof_axis[3 * c + 1], M.dof_axis[3 * c + 2]};
+    par_c = M.dof_parent[c];
     q_c = SOA(S.q, c); qd_c = SOA(S.qd, c); qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
     bp_c = pose_soa(S.bodypose, 7 * c, N, e);
     aw_c = f3{SOA(S.bodyaux, 6 * c), SOA(S.bodyaux, 6 * c + 1), SOA(S.bodyaux, 6 * c + 2)};
@@ -136,6 +150,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     L[S16_VEC + c] = qd_c;
   }
   __syncthreads();
+  PH(8);
   // V_c = sum over (ancestors + self) of S_i qd_i
   sv6 V = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
   for (int i = 0; i < n; i++) {
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     p[0] = T.w.x * qd_c; p[1] = T.w.y * qd_c; p[2] = T.w.z * qd_c; p[3] = T.v.x * qd_c; p[4] = T.v.y * qd_c; p[5] = T.v.z * qd_c;
   }
   __syncthreads();
+  PH(9);
   sv6 Ab = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
   for (int i = 0; i < n; i++) {
     float m = (((anc_c | self_c) >> i) & 1u) ? 1.f : 0.f;
@@ -157,8 +173,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     Ab.w += f3{p[0], p[1], p[2]} * m;
     Ab.v += f3{p[3], p[4], p[5]} * m;
   }
+  PH(10);
   si10 I_c = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
-  sf6 F_c = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
+  sf6 Fb_c = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
   if (art) {
     m3 R = qmat(bp_c.q);
     s3 Iw = srotate(R, s3{inert[4], inert[5], inert[6], inert[7], inert[8], inert[9]});
@@ -169,12 +186,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     I_c = si10{m, cm * m, Iw};
     sf6 f1 = imul(I_c, Ab);
     sf6 f2 = crossf(V, imul(I_c, V));
-    F_c = sf6{f1.n + f2.n, f1.f + f2.f};
-    if (grav_c) { F_c.f -= g3 * m; F_c.n -= cross(I_c.h, g3); }
+    Fb_c = sf6{f1.n + f2.n, f1.f + f2.f};
+    if (grav_c) { Fb_c.f -= g3 * m; Fb_c.n -= cross(I_c.h, g3); }
   }
   {
     float* p = L + S16_F + 6 * c;
-    p[0] = F_c.n.x; p[1] = F_c.n.y; p[2] = F_c.n.z; p[3] = F_c.f.x; p[4] = F_c.f.y; p[5] = F_c.f.z;
+    p[0] = Fb_c.n.x; p[1] = Fb_c.n.y; p[2] = Fb_c.n.z; p[3] = Fb_c.f.x; p[4] = Fb_c.f.y; p[5] = Fb_c.f.z;
     float* qI = L + S16_IC + 10 * c;
     qI[0] = I_c.m; qI[1] = I_c.h.x; qI[2] = I_c.h.y; qI[3] = I_c.h.z;
     qI[4] = I_c.I.xx; qI[5] = I_c.I.yy; qI[6] = I_c.I.zz; qI[7] = I_c.I.xy; qI[8] = I_c.I.xz; qI[9] = I_c.I.yz;
@@ -182,6 +199,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     for (int k = 0; k < 16; k++) L[S16_MAT + 16 * c + k] = 0.f;
   }
   __syncthreads();
+  PH(11);
   // composite force / inertia: sum over (descendants + self)
   sf6 Fc = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
   si10 Icc = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
@@ -198,6 +216,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     Icc.I.xy += qI[7] * m; Icc.I.xz += qI[8] * m; Icc.I.yz += qI[9] * m;
   }
   const float bias_c = sdot(S_c, Fc);
+  PH(12);
   {
     sf6 Fcol = imul(Icc, S_c);
     for (int i = 0; i < n; i++) {
@@ -210,6 +229,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     }
   }
   __syncthreads();
+  PH(13);
   float Mrow[16], qdv[16];
   ld16(L + S16_MAT + 16 * c, Mrow);
   ld16(L + S16_VEC, qdv);
@@ -398,34 +418,40 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
           if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
           const f3 r = x - mycom;
-          float Wprev0 = 0.f, Wprev1 = 0.f;
+          // the three directions of a contact at once: one LDS round trip for J -> W = A^-1 J^T
+          float J3[3], W3[3];
 #pragma unroll
           for (int dk = 0; dk < 3; dk++) {
             const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
             float J = 0.f;
             if (art) J = sgn_art * dot(d, col);
             else if (freel) J = sgn_free * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
-            __syncthreads();
-            L[S16_VEC + 32 + c] = J;
-            __syncthreads();
+            J3[dk] = J;
+          }
+          __syncthreads();
+          L[S16_VEC + 16 + c] = J3[0]; L[S16_VEC + 32 + c] = J3[1]; L[S16_VEC + 48 + c] = J3[2];
+          __syncthreads();
+#pragma unroll
+          for (int dk = 0; dk < 3; dk++) {
             float Jv[16];
-            ld16(L + S16_VEC + 32, Jv);
+            ld16(L + S16_VEC + 16 + 16 * dk, Jv);
             float W = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; j++) W += Irow[j] * Jv[j];
-            const float diag = gsum16(J * W);
-            // Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
-            float ga = 0.f, gb = 0.f;
-            if (dk == 1) ga = gsum16(J * Wprev0);
-            if (dk == 2) { ga = gsum16(J * Wprev0); gb = gsum16(J * Wprev1); }
-            if (dk == 0) Wprev0 = W;
-            if (dk == 1) Wprev1 = W;
-            const int r_idx = nrow + dk;
-            if (ck) {
+            W3[dk] = W;
+          }
+          // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
+          const float d0 = gsum16(J3[0] * W3[0]), d1 = gsum16(J3[1] * W3[1]), d2 = gsum16(J3[2] * W3[2]);
+          const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
+          if (ck) {
+#pragma unroll
+            for (int dk = 0; dk < 3; dk++) {
+              const int r_idx = nrow + dk;
               float* row = r_idx < lds_limit ? (L + S16_U + S16_ROWLEN * r_idx) : (grow + (size_t)S16_ROWLEN * (r_idx - lds_limit));
               if (r_idx < lds_limit || live) {
-                row[c] = J;
-                row[16 + c] = W;
+                const float diag = dk == 0 ? d0 : (dk == 1 ? d1 : d2);
+                row[c] = J3[dk];
+                row[16 + c] = W3[dk];
                 if (c == 0) {
                   row[32] = diag > 1e-12f ? 1.f / diag : 0.f;
                   row[33] = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
@@ -433,8 +459,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
                   row[35] = dk == 0 ? -1.f : mu;
                   row[36] = 0.f;
                   row[37] = __int_as_float(p);
-                  row[38] = ga;
-                  row[39] = gb;
+                  row[38] = dk == 0 ? 0.f : (dk == 1 ? g10 : g20);
+                  row[39] = dk == 2 ? g21 : 0.f;
                 }
               }
             }
@@ -496,7 +522,11 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
     }
   };
+#ifdef EXP_ITERS
+  const int n_iters = EXP_ITERS;
+#else
   const int n_iters = M.pos_iters + M.vel_iters;
+#endif
   float* const crow = L + S16_U + S16_ROWLEN * n;  // first contact row in LDS
   for (int it = 0; it <= n_iters; it++) {
     if (it == M.pos_iters) {
@@ -520,6 +550,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
     }
     if (it == n_iters) break;
+    PH(17);
     const bool use_bias = it < M.pos_iters;
     // joint-limit rows, exact sequential Gauss-Seidel semantics, but only rows that change are
     // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
@@ -542,6 +573,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         cursor = act ? j + 1 : 16;
       }
     }
+    PH(18);
     if (max_clds > 0) {
       ConRec A, B;
       con_load(crow, A);
@@ -556,6 +588,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (++k >= max_clds) break;
       }
     }
+    PH(19);
     for (int k = 0; k < max_cglb; k++) {
       const bool active = k < nc_glb;
       float* row = grow + (size_t)(3 * S16_ROWLEN) * (active ? k : 0);
@@ -563,6 +596,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       con_load(row, A);
       con_apply(A, row, active && live, use_bias);
     }
+    PH(20);
   }
 
   PH(5);
@@ -605,30 +639,53 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
   }
   __syncthreads();
-  // sequential FK (a product chain); every lane runs it, lane j keeps body j
+  PH(14);
+  // FK by pointer jumping: lane c starts from its joint-local transform T_c (parent body -> body c)
+  // and composes with its ancestor's partial product, doubling the covered chain length per round
+  // (4 rounds cover depth 16); sincos and the products run in all lanes at once instead of a
+  // 9-long sequential chain. Same transforms as the sequential product, different association.
   pose_t nb = root;
   f3 naw = f3{0, 0, 0}, nan = f3{0, 0, 0};
-  for (int j = 0; j < n; j++) {
-    const int pj = M.dof_parent[j];
-    pose_t P = root;
-    if (pj >= 0) {
-      const float* b = L + S16_BP + 7 * pj;
-      P = pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}};
+  {
+    pose_t T = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
+    int up = -1;
+    if (art) {
+      if (rev_c) T = pose_t{JF_c.p, qnormalized(qmul(JF_c.q, qaxis_angle(al_c, q_c)))};
+      else T = pose_t{JF_c.p + qrot(JF_c.q, al_c) * q_c, JF_c.q};
+      up = par_c;
     }
-    pose_t Jp = pmul(P, pose_from(M.dof_frame + 7 * j));
-    const f3 al = f3{M.dof_axis[3 * j], M.dof_axis[3 * j + 1], M.dof_axis[3 * j + 2]};
-    const f3 a = qrot(Jp.q, al);
-    const float qj = gbc(q_c, j);
-    pose_t B = Jp;
-    if (M.dof_type[j] == MSSIM_JOINT_REVOLUTE) B.q = qnormalized(qmul(Jp.q, qaxis_angle(al, qj)));
-    else B.p = Jp.p + a * qj;
-    if (c == 0) {
-      float* b = L + S16_BP + 7 * j;
-      b[0] = B.p.x; b[1] = B.p.y; b[2] = B.p.z; b[3] = B.q.w; b[4] = B.q.x; b[5] = B.q.y; b[6] = B.q.z;
+    int* const upv = reinterpret_cast<int*>(L + S16_VEC + 48);
+    float* const mine = L + S16_BP + 7 * c;
+#ifdef EXP_NO_FK
+    for (int round = 0; round < (N < 0 ? 4 : 0); round++) {
+#else
+    for (int round = 0; round < 4; round++) {
+#endif
+      if (!__any(up >= 0)) break;
+      mine[0] = T.p.x; mine[1] = T.p.y; mine[2] = T.p.z; mine[3] = T.q.w; mine[4] = T.q.x; mine[5] = T.q.y; mine[6] = T.q.z;
+      upv[c] = up;
+      __syncthreads();
+      if (up >= 0) {
+        const float* b = L + S16_BP + 7 * up;
+        const pose_t Tu = pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}};
+        up = upv[up];
+        T = pmul(Tu, T);
+      }
+      __syncthreads();
     }
-    if (c == j) { nb = B; naw = a; nan = Jp.p; }
+    nb = pmul(root, T);
+    mine[0] = nb.p.x; mine[1] = nb.p.y; mine[2] = nb.p.z; mine[3] = nb.q.w; mine[4] = nb.q.x; mine[5] = nb.q.y; mine[6] = nb.q.z;
     __syncthreads();
+    pose_t Wp = root;
+    if (par_c >= 0) {
+      const float* b = L + S16_BP + 7 * par_c;
+      Wp = pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}};
+    }
+    const pose_t Jw = pmul(Wp, JF_c);
+    naw = qrot(Jw.q, al_c);
+    nan = Jw.p;
   }
+  PH(15);
   // body velocities about O with the new subspaces
   sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
   if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
@@ -645,7 +702,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     nV.w += f3{p[0], p[1], p[2]} * m;
     nV.v += f3{p[3], p[4], p[5]} * m;
   }
+  PH(16);
+#ifdef EXP_NO_FINAL_STORES
+  if (art && live && N < 0) {
+#else
   if (art && live) {
+#endif
     pose_store_soa(S.bodypose, 7 * c, N, e, nb);
     float* o = S.bodyvel + (size_t)(6 * c) * N + e;
     o[0] = nV.w.x; o[(size_t)N] = nV.w.y; o[2 * (size_t)N] = nV.w.z;
@@ -656,4 +718,5 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   }
   if (live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
   PH(7);
+  PH_FLUSH
 }

@@ -22,8 +22,10 @@ steps = int(args[2]) if len(args) > 2 else 100
 env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos")
 env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
-buf = (ctypes.c_ulonglong * 16)()
-names = ["state load", "RNEA+CRBA", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK"]
+buf = (ctypes.c_ulonglong * 32)()
+names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
+         "dyn: S stage", "dyn: V sum", "dyn: Ab sum", "dyn: inertia/force", "dyn: composite sum", "dyn: M columns",
+         "end: state stores", "end: FK chain", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)"]
 for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" % steps, steps)):
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
@@ -31,9 +33,11 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
         env.step(2 * torch.rand(N, 8, device="cuda") - 1)
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
-    tot = sum(buf[i] for i in range(8))
+    tot = sum(buf[i] for i in range(32))
     launches = k * 5
     blocks = (N + 3) // 4
     print(f"{env_id} N={N} {phase_name}: {tot / launches / blocks:.0f} cycles per block-launch")
     for i, nm in enumerate(names):
+        if not buf[i]:
+            continue
         print(f"  {nm:14s} {buf[i] / launches / blocks:9.0f} cycles  {100.0 * buf[i] / tot:5.1f} %")
