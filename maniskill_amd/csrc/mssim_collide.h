@@ -57,15 +57,26 @@ MS_DEV f3 support(const shape_t& s, f3 d) {
       break;
     }
     case SH_CONVEX: {
+      // batches of 8 vertices: the 24 loads of a batch are issued together (one memory latency per
+      // batch instead of one per vertex). Indices past the end re-read vertex 0, which can never win
+      // the strict comparison, so the result equals the plain first-maximum scan.
       const float* __restrict__ v = s.verts;
       float bx = v[0], by = v[1], bz = v[2];
       float bd = bx * dl.x + by * dl.y + bz * dl.z;
-      for (int i = 1; i < s.nverts; i++) {
-        float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
-        float t = x * dl.x + y * dl.y + z * dl.z;
-        bool g = t > bd;
-        bd = g ? t : bd;
-        bx = g ? x : bx; by = g ? y : by; bz = g ? z : bz;
+      for (int i0 = 0; i0 < s.nverts; i0 += 8) {
+        float x[8], y[8], z[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int i = i0 + k < s.nverts ? i0 + k : 0;
+          x[k] = v[3 * i]; y[k] = v[3 * i + 1]; z[k] = v[3 * i + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          float t = x[k] * dl.x + y[k] * dl.y + z[k] * dl.z;
+          bool g = t > bd;
+          bd = g ? t : bd;
+          bx = g ? x[k] : bx; by = g ? y[k] : by; bz = g ? z[k] : bz;
+        }
       }
       pl = f3{bx, by, bz};
       break;
@@ -125,29 +136,45 @@ MS_DEV void collide_plane(const shape_t& pl, const shape_t& b, float offset, man
 // box-box.  LDS scratch: 2 polygon buffers of 8 points (x,y,z) + 8 separations -> 56 slots,
 // [slot][64 lanes] (a quad clipped by 4 planes has at most 8 vertices)
 #define CLIP_SLOTS 56
+// STRIDE = distance (floats) between consecutive slots of one lane: 64 for [slot][64 lanes]
+// (k_narrow), 16 when the scratch of a 16-lane group lives inside its env's LDS area (k_solve16 fused)
+template <int STRIDE>
 struct lds_poly {
   float* base;  // already offset by lane
   int buf;
-  MS_DEV f3 get(int i) const { float* p = base + (size_t)(buf * 24 + 3 * i) * 64; return f3{p[0], p[64], p[128]}; }
-  MS_DEV void put(int i, f3 v) { float* p = base + (size_t)(buf * 24 + 3 * i) * 64; p[0] = v.x; p[64] = v.y; p[128] = v.z; }
+  MS_DEV f3 get(int i) const { float* p = base + (size_t)(buf * 24 + 3 * i) * STRIDE; return f3{p[0], p[STRIDE], p[2 * STRIDE]}; }
+  MS_DEV void put(int i, f3 v) { float* p = base + (size_t)(buf * 24 + 3 * i) * STRIDE; p[0] = v.x; p[STRIDE] = v.y; p[2 * STRIDE] = v.z; }
 };
 
+// One Sutherland-Hodgman pass. All 8 input slots are read with static indices first (one LDS
+// latency, values in registers; slots >= n are stale and masked), only the appends use a dynamic
+// slot. Same arithmetic and vertex order as the vertex-by-vertex loop.
+template <int STRIDE>
 MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
-  lds_poly in{lds, src}, out{lds, src ^ 1};
+  lds_poly<STRIDE> in{lds, src}, out{lds, src ^ 1};
+  f3 P[8];
+  float d[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { P[i] = in.get(i); d[i] = dot(pn, P[i]) - pd; }
   int m = 0;
-  for (int i = 0; i < n; i++) {
-    f3 a = in.get(i);
-    f3 b = in.get(i + 1 < n ? i + 1 : 0);
-    float da = dot(pn, a) - pd, db = dot(pn, b) - pd;
-    if (da <= 0.f && m < 8) out.put(m++, a);
-    if (((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) && m < 8) {
-      float t = da / (da - db);
-      out.put(m++, a + (b - a) * t);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (i < n) {
+      const bool wrap = !(i + 1 < n);
+      const f3 a = P[i];
+      const f3 b = (i == 7 || wrap) ? P[0] : P[(i + 1) & 7];
+      const float da = d[i], db = (i == 7 || wrap) ? d[0] : d[(i + 1) & 7];
+      if (da <= 0.f && m < 8) out.put(m++, a);
+      if (((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) && m < 8) {
+        float t = da / (da - db);
+        out.put(m++, a + (b - a) * t);
+      }
     }
   }
   return m;
 }
 
+template <int STRIDE = 64>
 MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, manifold_t& m, float* lds) {
   m.count = 0;
   const float eps = 1e-6f;
@@ -248,7 +275,7 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   float hY2 = jinc == 0 ? hY[2] : (jinc == 1 ? hY[0] : hY[1]);
   f3 ninc = dot(nref, yi) > 0.f ? -yi : yi;
   f3 fc = Yc + ninc * hYi;
-  lds_poly P{lds, 0};
+  lds_poly<STRIDE> P{lds, 0};
   P.put(0, fc + y1 * hY1 + y2 * hY2);
   P.put(1, fc - y1 * hY1 + y2 * hY2);
   P.put(2, fc - y1 * hY1 - y2 * hY2);
@@ -258,51 +285,74 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   float hX1 = ir == 0 ? hX[1] : (ir == 1 ? hX[2] : hX[0]);
   float hX2 = ir == 0 ? hX[2] : (ir == 1 ? hX[0] : hX[1]);
   int np = 4;
-  np = clip_poly(lds, 0, np, x1, dot(x1, Xc) + hX1);
-  np = clip_poly(lds, 1, np, -x1, -dot(x1, Xc) + hX1);
-  np = clip_poly(lds, 0, np, x2, dot(x2, Xc) + hX2);
-  np = clip_poly(lds, 1, np, -x2, -dot(x2, Xc) + hX2);
+  np = clip_poly<STRIDE>(lds, 0, np, x1, dot(x1, Xc) + hX1);
+  np = clip_poly<STRIDE>(lds, 1, np, -x1, -dot(x1, Xc) + hX1);
+  np = clip_poly<STRIDE>(lds, 0, np, x2, dot(x2, Xc) + hX2);
+  np = clip_poly<STRIDE>(lds, 1, np, -x2, -dot(x2, Xc) + hX2);
   // result polygon is in buffer 0; compact the points within the offset into buffer 1 (x,y,z) and
   // their separations into the tail slots of buffer 1
-  lds_poly Q{lds, 0}, Rb{lds, 1};
-  float* seps = lds + (size_t)48 * 64;  // slots 48..55 of the scratch
+  lds_poly<STRIDE> Q{lds, 0}, Rb{lds, 1};
+  float* seps = lds + (size_t)48 * STRIDE;  // slots 48..55 of the scratch
   int n = 0;
-  for (int i = 0; i < np; i++) {
-    f3 p = Q.get(i);
-    float s = dot(p - Xc, nref) - hXr;
-    if (s <= offset) { Rb.put(n, p - nref * (0.5f * s)); seps[(size_t)n * 64] = s; n++; }
+  {
+    f3 Qp[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) Qp[i] = Q.get(i);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (i < np) {
+        f3 p = Qp[i];
+        float s = dot(p - Xc, nref) - hXr;
+        if (s <= offset) { Rb.put(n, p - nref * (0.5f * s)); seps[(size_t)n * STRIDE] = s; n++; }
+      }
+    }
   }
   m.n = refA ? -nref : nref;
   if (n <= 4) {
     m.count = n;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (k < n) { m.x[k] = Rb.get(k); m.sep[k] = seps[(size_t)k * 64]; }
+      if (k < n) { m.x[k] = Rb.get(k); m.sep[k] = seps[(size_t)k * STRIDE]; }
     return;
   }
+  // more than 4 candidates: deepest, farthest from it, then the two of largest area on either side
+  // (candidates in registers; "first extremum wins" as in the sequential scans)
+  f3 R[8];
+  float sp[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { R[i] = Rb.get(i); sp[i] = seps[(size_t)i * STRIDE]; }
   int i0 = 0;
-  float s0 = seps[0];
-  for (int i = 1; i < n; i++) { float s = seps[(size_t)i * 64]; if (s < s0) { s0 = s; i0 = i; } }
-  f3 p0 = Rb.get(i0);
+  float s0 = sp[0];
+  f3 p0 = R[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++)
+    if (i < n && sp[i] < s0) { s0 = sp[i]; i0 = i; p0 = R[i]; }
   int i1 = -1; float best = -1.f;
-  for (int i = 0; i < n; i++) {
-    if (i == i0) continue;
-    f3 d = Rb.get(i) - p0; float v = dot(d, d);
-    if (v > best) { best = v; i1 = i; }
+  f3 p1 = p0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (i < n && i != i0) {
+      f3 d = R[i] - p0; float v = dot(d, d);
+      if (v > best) { best = v; i1 = i; p1 = R[i]; }
+    }
   }
-  f3 e = Rb.get(i1) - p0;
+  f3 e = p1 - p0;
   int i2 = -1; best = -1.f; float sgn2 = 0.f;
-  for (int i = 0; i < n; i++) {
-    if (i == i0 || i == i1) continue;
-    float ar = dot(cross(e, Rb.get(i) - p0), nref);
-    if (fabsf(ar) > best) { best = fabsf(ar); i2 = i; sgn2 = ar; }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (i < n && i != i0 && i != i1) {
+      float ar = dot(cross(e, R[i] - p0), nref);
+      if (fabsf(ar) > best) { best = fabsf(ar); i2 = i; sgn2 = ar; }
+    }
   }
   int i3 = -1; best = 0.f;
-  for (int i = 0; i < n; i++) {
-    if (i == i0 || i == i1 || i == i2) continue;
-    float ar = dot(cross(e, Rb.get(i) - p0), nref);
-    float v = sgn2 >= 0.f ? -ar : ar;
-    if (v > best) { best = v; i3 = i; }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (i < n && i != i0 && i != i1 && i != i2) {
+      float ar = dot(cross(e, R[i] - p0), nref);
+      float v = sgn2 >= 0.f ? -ar : ar;
+      if (v > best) { best = v; i3 = i; }
+    }
   }
   int idx[4] = {i0, i1, i2, i3};
   m.count = 0;
@@ -310,7 +360,7 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   for (int k = 0; k < 4; k++)
     if (idx[k] >= 0) {
       f3 p = Rb.get(idx[k]);
-      float s = seps[(size_t)idx[k] * 64];
+      float s = seps[(size_t)idx[k] * STRIDE];
 #pragma unroll
       for (int t = 0; t < 4; t++)
         if (t == m.count) { m.x[t] = p; m.sep[t] = s; }

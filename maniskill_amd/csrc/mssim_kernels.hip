@@ -55,6 +55,7 @@ struct DevState {
   float* pair_data;                             // [n_pair*19][N]: n(3), 4 x (x(3), sep)
   float* pair_imp;                              // [n_pair*3][N]
   unsigned* hit_mask;                           // [n_words][N]
+  int* hit_list;                                // [1 + MAXC][N]: count, then the pairs in contact after the last fused step
   float* rows;                                  // [3*MAXC * RF][N] solver scratch
   int* overflow;                                // [N]
   int row_slots;                                // LDS slots per lane for packed solver rows
@@ -100,6 +101,13 @@ MS_DEV sf6 imul(const si10& I, sv6 a) { return sf6{smulv(I.I, a.w) + cross(I.h, 
 MS_DEV float sdot(sv6 s, sf6 f) { return dot(s.w, f.n) + dot(s.v, f.f); }
 
 #define SOA(ptr, item) ((ptr)[(size_t)(item) * N + e])
+
+// XCD-aware block -> env-chunk mapping. Workgroups are dealt round-robin to the 8 XCDs (each with its
+// own L2), so with the identity mapping every XCD touches a 1/8 slice of every cache line of the
+// [item][N] arrays (false sharing across the 8 L2s, 8x fetch amplification). Grids are padded to a
+// multiple of 8 blocks and block b works on chunk (b % 8) * (grid / 8) + b / 8: XCD x owns one
+// contiguous range of envs in every kernel, so the state a kernel writes is re-read from the same L2.
+MS_DEV int xcd_chunk(int b, int grid) { return (b & 7) * (grid >> 3) + (b >> 3); }
 
 template <class T>
 MS_DEV void fk_bodies(const T& topo, const DevModel& M, pose_t root, const float* q, pose_t* bp, f3* aw, f3* anchor) {
@@ -167,7 +175,7 @@ MS_DEV void write_kinematics(const T& topo, const DevModel& M, const DevState& S
 template <class T>
 __global__ __launch_bounds__(64) void k_fk(DevModel M, DevState S) {
   const int N = S.N;
-  int e = blockIdx.x * 64 + threadIdx.x;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (e >= N) return;
   T topo(M);
   pose_t root = pose_soa(S.root, 0, N, e);
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
   __shared__ float lds[CLIP_SLOTS * 64];
   const int N = S.N;
   const int p = blockIdx.y;
-  int e = blockIdx.x * 64 + threadIdx.x;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (e >= N) return;
   const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
   const int ta = M.shape_type[sa], tb = M.shape_type[sb];
@@ -928,7 +936,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
 // apply / fetch: transposes between the user-visible AoS buffers and the SoA state
 __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) {
   const int N = S.N;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= N) return;
   const int n = M.n_dof;
   if ((what & MSSIM_RIGID_DATA) && B.rigid_body_data) {
@@ -961,7 +969,7 @@ __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) 
 // lanes write consecutive 52-byte records (coalesced); blockIdx.y == n_rows: the articulation arrays
 __global__ __launch_bounds__(64) void k_fetch(DevModel M, DevState S, mssim_buffers B, unsigned what) {
   const int N = S.N;
-  const int e = blockIdx.x * 64 + threadIdx.x;
+  const int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (e >= N) return;
   const int n = M.n_dof;
   const int R = M.n_link + M.n_free + M.n_kin;
@@ -1029,7 +1037,7 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
                                const int* __restrict__ col, const float* __restrict__ lo, const float* __restrict__ hi,
                                const int* __restrict__ flags) {
   const int N = S.N;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= N) return;
   const int n = M.n_dof;
   for (int j = 0; j < n; j++) {
@@ -1051,7 +1059,7 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
 __global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_task T, float* __restrict__ obs, float* __restrict__ reward,
                             uint8_t* __restrict__ flags) {
   const int N = S.N;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= N) return;
   const int n = M.n_dof;
   const int D = 2 * n + 24;
@@ -1142,7 +1150,8 @@ struct mssim_sim {
   // profiling (bench roofline block): event pairs recorded on the launch stream
   int* d_act_col = nullptr; float* d_act_lo = nullptr; float* d_act_hi = nullptr; int* d_act_flags = nullptr;
   unsigned solve_lds_bytes = 0;
-  bool coop = false;  // use k_solve16
+  bool coop = false;   // use k_solve16
+  bool fused = false;  // k_solve16<true>: one launch per control step, narrowphase in the kernel
   bool profiling = false;
   std::vector<hipEvent_t> ev[2];  // [kernel] start/stop interleaved
   size_t ev_used[2] = {0, 0};
@@ -1284,10 +1293,14 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   }
   // cooperative 16-lanes-per-env kernel when every velocity component fits one DPP row
   S->coop = (n + 6 * d->n_free <= S16_LANES);
+  // whole control step in one launch (in-kernel narrowphase) when the scene fits the LDS tables
+  S->fused = S->coop && d->n_free <= S16_MAX_FREE && d->n_kin <= S16_MAX_KIN && ns <= S16_MAX_SHAPE && d->n_pair < 65536 && d->n_pair > 0;
   if (const char* ev = getenv("MSSIM_SOLVER")) {
-    if (!strcmp(ev, "lane")) S->coop = false;
+    if (!strcmp(ev, "lane")) S->coop = S->fused = false;
+    if (!strcmp(ev, "split")) S->fused = false;
   }
   AL(overflow, 1)
+  AL(hit_list, 1 + MAXC)
 #undef AL
   // LDS budget of the solve kernel: one 64-lane block per CU when the grid is small enough to give
   // every block its own CU (N <= 256*64 envs), otherwise 64 KB so two blocks share a CU
@@ -1330,7 +1343,8 @@ int mssim_set_drive_properties(mssim_handle h, const float* drive) {
   return 0;
 }
 
-static inline dim3 env_grid(int N, int block) { return dim3((N + block - 1) / block); }
+static inline int pad8(int n) { return (n + 7) / 8 * 8; }
+static inline dim3 env_grid(int N, int block) { return dim3(pad8((N + block - 1) / block)); }  // kernels map blocks with xcd_chunk
 
 int mssim_apply(mssim_handle h, uint32_t what, void* stream) {
   hipLaunchKernelGGL(k_apply, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
@@ -1340,7 +1354,7 @@ int mssim_apply(mssim_handle h, uint32_t what, void* stream) {
 }
 
 int mssim_fetch(mssim_handle h, uint32_t what, void* stream) {
-  hipLaunchKernelGGL(k_fetch, dim3((h->N + 63) / 64, h->M.n_link + h->M.n_free + h->M.n_kin + 1), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
+  hipLaunchKernelGGL(k_fetch, dim3(pad8((h->N + 63) / 64), h->M.n_link + h->M.n_free + h->M.n_kin + 1), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1365,16 +1379,23 @@ static inline void prof_mark(mssim_handle h, int k, hipStream_t st) {
 int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+  if (h->fused && n_substeps > 0) {
+    prof_mark(h, 0, st);
+    hipLaunchKernelGGL(k_solve16<true>, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, (int)n_substeps);
+    prof_mark(h, 0, st);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
   for (int s = 0; s < n_substeps; s++) {
     if (h->M.n_pair > 0) {
       prof_mark(h, 1, st);
-      hipLaunchKernelGGL(k_narrow, dim3((h->N + 63) / 64, h->M.n_pair), dim3(64), 0, st, h->M, h->S);
+      hipLaunchKernelGGL(k_narrow, dim3(pad8((h->N + 63) / 64), h->M.n_pair), dim3(64), 0, st, h->M, h->S);
       prof_mark(h, 1, st);
     }
     prof_mark(h, 0, st);
-    if (h->coop) hipLaunchKernelGGL(k_solve16, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S);
-    else if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
-    else hipLaunchKernelGGL(k_solve<TopoDyn>, env_grid(h->N, 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
+    if (h->coop) hipLaunchKernelGGL(k_solve16<false>, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, 1);
+    else if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
+    else hipLaunchKernelGGL(k_solve<TopoDyn>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);
   }
   HIPCHK(h, hipGetLastError());

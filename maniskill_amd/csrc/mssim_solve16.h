@@ -1,18 +1,25 @@
-// mssim_solve16.h -- the cooperative solve kernel: 16 lanes per env, 4 envs per wave.
+// mssim_solve16.h -- the cooperative step kernel: 16 lanes per env, 4 envs per wave.
 //
 // Why: with one env per lane N = 4096 envs are 64 wavefronts on a chip with 1024 SIMDs and the
 // kernel is instruction-issue bound at one wave per SIMD. Here every env is
 // spread over a 16-lane DPP row: lane c owns velocity component c (joint c, or one linear /
 // angular component of a free body), so N = 4096 is 1024 waves and the long serial chains become
 //   * tree recursions  -> sums over ancestor / descendant bit sets of per-body quantities staged
-//                         in LDS (no sequential pass except FK),
+//                         in LDS; FK by pointer jumping,
 //   * dense 9x9 algebra-> Gauss-Jordan with one matrix row per lane, pivot row broadcast via LDS,
 //   * Gauss-Seidel row -> one multiply, a 4-step DPP row-rotate all-reduce, a clamp, one FMA.
-// Solver rows (J[16], W[16], 8 scalars) live in LDS, overflow rows in a per-env global scratch.
+//
+// k_solve16<true>  (FUSED): one launch runs a whole control step. The wave keeps its 4 envs' state in
+//   registers / LDS across the substeps and does the narrowphase itself between them (per-env
+//   world shape table in LDS, 16 pairs per env culled per round, surviving pairs spread over all
+//   64 lanes for the manifold computation, contact records in LDS). State crosses HBM once per
+//   control step; there is no global contact buffer.
+// k_solve16<false> (split): one substep; contacts come from k_narrow through the global pair
+//   buffers (kept as the A/B reference of the fused path and for per-substep stepping).
 //
 // Same math and the same row order as k_solve / the oracle (limits, then contacts in pair order,
-// normal + 2 friction rows each), so the parity tests cover it unchanged.
-// Requires n_dof + 6 * n_free <= 16.
+// normal + 2 friction rows each), so the parity tests cover both unchanged.
+// Requires n_dof + 6 * n_free <= 16 (and n_free <= 2, n_kin <= 6, n_shape <= 32 for FUSED).
 #pragma once
 
 #define S16_LANES 16
@@ -20,10 +27,19 @@
 #define S16_ENVS_PER_BLOCK 4
 #endif
 // per-env LDS layout (floats)
-#define S16_COM 0      // [8][3] free-body centres of mass
+#define S16_COM 0      // [2][3] free-body centres of mass | [8..23] ancestor-or-self masks of the dofs
+#define S16_ANC 8
 #define S16_VEC 32     // 4 x [16] scratch vectors
-#define S16_BP 96      // [16][7] body poses (FK staging)
-#define S16_U 208      // union: dynamics staging | solver rows
+#define S16_PT 96      // pose table [25][7]: root | 16 links | 2 free | 6 kinematic
+#define S16_PT_LINK 1
+#define S16_PT_FREE 17
+#define S16_PT_KIN 19
+#define S16_MAX_FREE 2
+#define S16_MAX_KIN 6
+#define S16_MAX_SHAPE 32
+#define S16_MAX_HIT 64
+#define S16_BP (S16_PT + 7 * S16_PT_LINK)  // link poses
+#define S16_U 272      // union: dynamics staging | solver rows | narrowphase scratch
 #define S16_S (S16_U)          // [16][6]
 #define S16_V (S16_U + 96)     // [16][6]
 #define S16_T (S16_U + 192)    // [16][6]
@@ -31,16 +47,24 @@
 #define S16_IC (S16_U + 384)   // [16][10]
 #define S16_MAT (S16_U + 544)  // [16][16]
 #define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
-#define S16_ROWLEN 40          // J[16] W[16] | invd bpos bvel mu lam pair dk pad
-#define S16_ROWS_LDS 58
-#define S16_ENV_FLOATS (S16_U + S16_ROWLEN * S16_ROWS_LDS)  // 3248 floats = 12992 B per env
-#define S16_ROWS_GLB (16 + 3 * MAXC - S16_ROWS_LDS)
+#define S16_LIMW (S16_U)       // [16][16] W = A^-1 J^T of the joint-limit rows
+#define S16_CROW (S16_U + 256) // contact rows, 3 per contact
+#define S16_ROWLEN 40          // J[16] W[16] | invd bpos bvel mu lam pair g g
+#define S16_CON_LDS 12         // contacts whose rows live in LDS; the rest go to the global scratch
+#define S16_REC (S16_CROW + 3 * S16_ROWLEN * S16_CON_LDS)  // contact records [MAXC][10]
+#define S16_REC_LEN 10         // n(3) x(3) sep pair bodies mu
+#define S16_ENV_FLOATS (S16_REC + S16_REC_LEN * MAXC)  // 2448 floats = 9792 B per env (== 16 mod 32 banks)
+#define S16_ROWS_GLB (3 * (MAXC - S16_CON_LDS))
+// narrowphase scratch (FUSED), overlays the union below the contact records
+#define S16_NP_SHP (S16_U)        // [32][16] world shape table
+#define S16_NP_HIT (S16_U + 512)  // [64] surviving pairs: pair | sa << 16 | sb << 24
+#define S16_NP_CNT (S16_U + 576)  // [64] manifold sizes
+#define S16_NP_SCR (S16_U + 640)  // [56][16] box-box clip scratch of the group's 16 lanes
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
-// thread 0 of every block adds the cycles spent since the previous mark to g_phase_clk[i].
+// per-phase cycle deltas are kept in registers and flushed once at the end.
 #ifdef MSSIM_PHASE_CLOCKS
 __device__ unsigned long long g_phase_clk[32];
-// deltas are kept in registers and flushed once at the end (an atomic per mark costs more than a phase)
 #define PH_INIT                 \
   unsigned ph_d[32];            \
   _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) ph_d[i_] = 0u; \
@@ -51,6 +75,7 @@ __device__ unsigned long long g_phase_clk[32];
     ph_d[i] += (unsigned)clock64() - ph_t;      \
     ph_t = (unsigned)clock64();                 \
   } while (0)
+#define PH_ADD(i, v) ph_d[i] += (unsigned)(v)
 #define PH_FLUSH                                                                  \
   if (threadIdx.x == 0) {                                                         \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++)                             \
@@ -59,6 +84,7 @@ __device__ unsigned long long g_phase_clk[32];
 #else
 #define PH_INIT
 #define PH(i)
+#define PH_ADD(i, v)
 #define PH_FLUSH
 #endif
 
@@ -85,12 +111,38 @@ MS_DEV void ld16(const float* p, float* out) {  // 16 consecutive floats (16-B a
     out[4 * i] = t.x; out[4 * i + 1] = t.y; out[4 * i + 2] = t.z; out[4 * i + 3] = t.w;
   }
 }
+MS_DEV pose_t lds_pose(const float* b) { return pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}}; }
+MS_DEV void lds_pose_store(float* b, pose_t P) {
+  b[0] = P.p.x; b[1] = P.p.y; b[2] = P.p.z; b[3] = P.q.w; b[4] = P.q.x; b[5] = P.q.y; b[6] = P.q.z;
+}
+// pose-table slot of a body: -1 = fixed in the env frame
+MS_DEV int pose_slot(int kind, int index) {
+  if (kind == MSSIM_BODY_ART) return index < 0 ? 0 : S16_PT_LINK + index;
+  if (kind == MSSIM_BODY_FREE) return S16_PT_FREE + index;
+  if (kind == MSSIM_BODY_KIN) return S16_PT_KIN + index;
+  return -1;
+}
+// world shape from the LDS shape table of one env
+MS_DEV shape_t shape_from_table(const DevModel& M, const float* t) {
+  shape_t sh;
+  sh.c = f3{t[0], t[1], t[2]};
+  sh.rot = qmat(q4{t[3], t[4], t[5], t[6]});
+  sh.p0 = t[7]; sh.p1 = t[8]; sh.p2 = t[9];
+  const unsigned pk = __float_as_uint(t[14]);  // type:3 | nverts:7 | (pose slot + 1):5 | first hull vertex:17
+  sh.type = (int)(pk & 7u);
+  sh.nverts = (int)((pk >> 3) & 127u);
+  sh.verts = M.hull_verts + 3 * (size_t)(pk >> 15);
+  return sh;
+}
 
-__global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S) {
+template <bool FUSED>
+__global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S, int n_sub) {
   __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   const int N = S.N;
   const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
-  const int e_raw = blockIdx.x * S16_ENVS_PER_BLOCK + g;
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  if (chunk * S16_ENVS_PER_BLOCK >= N) return;  // grid padding
+  const int e_raw = chunk * S16_ENVS_PER_BLOCK + g;
   const bool live = e_raw < N;
   const int e = live ? e_raw : N - 1;  // dead groups shadow the last env and never store
   float* L = sm + g * S16_ENV_FLOATS;
@@ -104,9 +156,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   const int fb_id = freel ? fc / 6 : 0;
   const int fk = freel ? fc % 6 : 0;  // 0..2 linear xyz, 3..5 angular xyz
   const int fbase = n + 6 * fb_id;
+  if (!FUSED) n_sub = 1;
 
   PH_INIT
-  // ---------------------------------------------------------------- state
+  // ---------------------------------------------------------------- state (loaded once)
   const pose_t root = pose_soa(S.root, 0, N, e);
   const f3 O = root.p;
   float q_c = 0.f, qd_c = 0.f, qt_c = 0.f, qdt_c = 0.f, qf_c = 0.f;
@@ -114,7 +167,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   f3 aw_c = f3{0, 0, 0}, an_c = f3{0, 0, 0};
   bool rev_c = false;
   unsigned anc_c = 0u;
-  float kp = 0.f, kd = 0.f, fmax = 3e38f, arm = 0.f, lo_c = -3e38f, hi_c = 3e38f;
+  float kp0 = 0.f, kd0 = 0.f, fmax = 3e38f, arm = 0.f, lo_c = -3e38f, hi_c = 3e38f;
   float inert[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool grav_c = false, accel_mode = false;
   pose_t JF_c = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};  // joint frame in the parent body frame
@@ -130,7 +183,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     an_c = f3{SOA(S.bodyaux, 6 * c + 3), SOA(S.bodyaux, 6 * c + 4), SOA(S.bodyaux, 6 * c + 5)};
     rev_c = M.dof_type[c] == MSSIM_JOINT_REVOLUTE;
     anc_c = M.dof_anc[c];
-    kp = M.dof_drive[4 * c]; kd = M.dof_drive[4 * c + 1]; fmax = M.dof_drive[4 * c + 2];
+    kp0 = M.dof_drive[4 * c]; kd0 = M.dof_drive[4 * c + 1]; fmax = M.dof_drive[4 * c + 2];
     accel_mode = (int)M.dof_drive[4 * c + 3] == MSSIM_DRIVE_ACCELERATION;
     arm = M.dof_armature[c];
     lo_c = M.dof_limit[2 * c]; hi_c = M.dof_limit[2 * c + 1];
@@ -139,498 +192,802 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     grav_c = M.body_gravity[c] != 0;
   }
   const unsigned self_c = art ? (1u << c) : 0u;
-
-  PH(0);
-  // ---------------------------------------------------------------- dynamics: RNEA bias + CRBA
-  sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
-  if (art) S_c = rev_c ? sv6{aw_c, cross(an_c - O, aw_c)} : sv6{f3{0, 0, 0}, aw_c};
+  float qacc_c = 0.f;
+  // free-body velocity component of this lane; pose and the external force live in the pose table / registers
+  float vfree_c = freel ? SOA(S.free_s, 13 * fb_id + 7 + fk) : 0.f;
+  float fforce_c = (freel && fk < 3) ? SOA(S.free_force, 3 * fb_id + fk) : 0.f;
+  float fin[S16_MAX_FREE][10];
+#pragma unroll
+  for (int b = 0; b < S16_MAX_FREE; b++) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) fin[b][k] = 0.f;
+    if (b < nf) free_inertial_of(M, N, b, e, fin[b]);
+  }
+  // pose table: root, links, free bodies, kinematic bodies
   {
-    float* p = L + S16_S + 6 * c;
-    p[0] = S_c.w.x; p[1] = S_c.w.y; p[2] = S_c.w.z; p[3] = S_c.v.x; p[4] = S_c.v.y; p[5] = S_c.v.z;
-    L[S16_VEC + c] = qd_c;
+    reinterpret_cast<unsigned*>(L)[S16_ANC + c] = anc_c | self_c;
+    if (c == 0) lds_pose_store(L + S16_PT, root);
+    if (art) lds_pose_store(L + S16_BP + 7 * c, bp_c);
+    if (c < nf) lds_pose_store(L + S16_PT + 7 * (S16_PT_FREE + c), pose_soa(S.free_s, 13 * c, N, e));
+    if (FUSED && c < M.n_kin) lds_pose_store(L + S16_PT + 7 * (S16_PT_KIN + c), pose_soa(S.kin, 7 * c, N, e));
   }
-  __syncthreads();
-  PH(8);
-  // V_c = sum over (ancestors + self) of S_i qd_i
-  sv6 V = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
-  for (int i = 0; i < n; i++) {
-    float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;
-    const float* p = L + S16_S + 6 * i;
-    V.w += f3{p[0], p[1], p[2]} * m;
-    V.v += f3{p[3], p[4], p[5]} * m;
-  }
-  {
-    sv6 T = crossm(V, S_c);
-    float* p = L + S16_T + 6 * c;
-    p[0] = T.w.x * qd_c; p[1] = T.w.y * qd_c; p[2] = T.w.z * qd_c; p[3] = T.v.x * qd_c; p[4] = T.v.y * qd_c; p[5] = T.v.z * qd_c;
-  }
-  __syncthreads();
-  PH(9);
-  sv6 Ab = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
-  for (int i = 0; i < n; i++) {
-    float m = (((anc_c | self_c) >> i) & 1u) ? 1.f : 0.f;
-    const float* p = L + S16_T + 6 * i;
-    Ab.w += f3{p[0], p[1], p[2]} * m;
-    Ab.v += f3{p[3], p[4], p[5]} * m;
-  }
-  PH(10);
-  si10 I_c = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
-  sf6 Fb_c = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
-  if (art) {
-    m3 R = qmat(bp_c.q);
-    s3 Iw = srotate(R, s3{inert[4], inert[5], inert[6], inert[7], inert[8], inert[9]});
-    f3 cm = bp_c.p + mmulv(R, f3{inert[1], inert[2], inert[3]}) - O;
-    float m = inert[0], cc = dot(cm, cm);
-    Iw.xx += m * (cc - cm.x * cm.x); Iw.yy += m * (cc - cm.y * cm.y); Iw.zz += m * (cc - cm.z * cm.z);
-    Iw.xy -= m * cm.x * cm.y; Iw.xz -= m * cm.x * cm.z; Iw.yz -= m * cm.y * cm.z;
-    I_c = si10{m, cm * m, Iw};
-    sf6 f1 = imul(I_c, Ab);
-    sf6 f2 = crossf(V, imul(I_c, V));
-    Fb_c = sf6{f1.n + f2.n, f1.f + f2.f};
-    if (grav_c) { Fb_c.f -= g3 * m; Fb_c.n -= cross(I_c.h, g3); }
-  }
-  {
-    float* p = L + S16_F + 6 * c;
-    p[0] = Fb_c.n.x; p[1] = Fb_c.n.y; p[2] = Fb_c.n.z; p[3] = Fb_c.f.x; p[4] = Fb_c.f.y; p[5] = Fb_c.f.z;
-    float* qI = L + S16_IC + 10 * c;
-    qI[0] = I_c.m; qI[1] = I_c.h.x; qI[2] = I_c.h.y; qI[3] = I_c.h.z;
-    qI[4] = I_c.I.xx; qI[5] = I_c.I.yy; qI[6] = I_c.I.zz; qI[7] = I_c.I.xy; qI[8] = I_c.I.xz; qI[9] = I_c.I.yz;
+  // FUSED: shape-local data of shapes c and c + 16 (constant over the step)
+  pose_t shF[2];
+  float shP[2][3], shBr[2], shMu[2];
+  f3 shBc[2];
+  unsigned shPk[2];
+  int shSlot[2];
+  if (FUSED) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) L[S16_MAT + 16 * c + k] = 0.f;
-  }
-  __syncthreads();
-  PH(11);
-  // composite force / inertia: sum over (descendants + self)
-  sf6 Fc = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
-  si10 Icc = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
-  for (int k = 0; k < n; k++) {
-    unsigned ak = M.dof_anc[k] | (1u << k);
-    float m = (art && ((ak >> c) & 1u)) ? 1.f : 0.f;
-    const float* p = L + S16_F + 6 * k;
-    Fc.n += f3{p[0], p[1], p[2]} * m;
-    Fc.f += f3{p[3], p[4], p[5]} * m;
-    const float* qI = L + S16_IC + 10 * k;
-    Icc.m += qI[0] * m;
-    Icc.h += f3{qI[1], qI[2], qI[3]} * m;
-    Icc.I.xx += qI[4] * m; Icc.I.yy += qI[5] * m; Icc.I.zz += qI[6] * m;
-    Icc.I.xy += qI[7] * m; Icc.I.xz += qI[8] * m; Icc.I.yz += qI[9] * m;
-  }
-  const float bias_c = sdot(S_c, Fc);
-  PH(12);
-  {
-    sf6 Fcol = imul(Icc, S_c);
-    for (int i = 0; i < n; i++) {
-      if (art && (((anc_c | self_c) >> i) & 1u)) {
-        const float* p = L + S16_S + 6 * i;
-        float v = dot(f3{p[0], p[1], p[2]}, Fcol.n) + dot(f3{p[3], p[4], p[5]}, Fcol.f);
-        L[S16_MAT + 16 * c + i] = v;
-        L[S16_MAT + 16 * i + c] = v;
-      }
-    }
-  }
-  __syncthreads();
-  PH(13);
-  float Mrow[16], qdv[16];
-  ld16(L + S16_MAT + 16 * c, Mrow);
-  ld16(L + S16_VEC, qdv);
-  const float Mdiag = L[S16_MAT + 16 * c + c];
-  if (accel_mode) { kp *= Mdiag; kd *= Mdiag; }
-  const float tau0 = kp * (qt_c - q_c) + kd * qdt_c;
-  float Dj = dt * kd + dt * dt * kp;
-  float mv = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; k++) mv += Mrow[k] * qdv[k];
-  // tendons: torque into rhs, implicit stiffness into the matrix row
-  float tau_t = 0.f;
-  float Trow[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) Trow[k] = 0.f;
-  for (int t = 0; t < M.n_tendon; t++) {
-    const int a = M.tendon_dof[2 * t], b = M.tendon_dof[2 * t + 1];
-    const float* tp = M.tendon_param + 5 * t;
-    const float ca = tp[0], cb = tp[1];
-    const float cval = ca * gbc(q_c, a) + cb * gbc(q_c, b) - tp[2];
-    const float w = dt * dt * tp[3] + dt * tp[4];
-    const float cj = c == a ? ca : (c == b ? cb : 0.f);
-    tau_t -= tp[3] * cval * cj;
-#pragma unroll
-    for (int k = 0; k < 16; k++) Trow[k] += w * cj * (k == a ? ca : (k == b ? cb : 0.f));
-  }
-  float rhs_c = art ? mv + dt * (tau0 + tau_t - bias_c + qf_c) : 0.f;
-
-  PH(1);
-  // ---------------------------------------------------------------- A^-1 by Gauss-Jordan (row per lane)
-  float Irow[16];
-  float vstar = 0.f;
-  for (int pass = 0; pass < 2; pass++) {
-    float Arow[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      Arow[k] = art ? (Mrow[k] + Trow[k] + (k == c ? Dj + arm : 0.f)) : (k == c ? 1.f : 0.f);
-      Irow[k] = k == c ? 1.f : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k >= n) break;
-      __syncthreads();
-      if (c == k) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + 16 + j] = Irow[j]; }
-      }
-      __syncthreads();
-      float PA[16], PI[16];
-      ld16(L + S16_PIV, PA);
-      ld16(L + S16_PIV + 16, PI);
-      const float inv = 1.f / PA[k];
-      const float fac = Arow[k] * inv;
-      const bool piv = c == k;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        Arow[j] = piv ? PA[j] * inv : Arow[j] - fac * PA[j];
-        Irow[j] = piv ? PI[j] * inv : Irow[j] - fac * PI[j];
-      }
-    }
-    __syncthreads();
-    L[S16_VEC + 16 + c] = rhs_c;
-    __syncthreads();
-    float rv[16];
-    ld16(L + S16_VEC + 16, rv);
-    vstar = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; k++) vstar += Irow[k] * rv[k];
-    if (pass == 1) break;
-    // drive force limit: saturated joints get the constant limit torque, lose their implicit terms
-    const float td = kp * (qt_c - q_c - dt * vstar) + kd * (qdt_c - vstar);
-    const bool sat = art && fmax < 1e30f && fabsf(td) > fmax;
-    if (!__any(sat)) break;
-    if (sat) {
-      rhs_c += dt * ((td > 0.f ? fmax : -fmax) - tau0);
-      Dj = 0.f;
-    }
-  }
-  if (!art) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) Irow[k] = 0.f;
-  }
-
-  PH(2);
-  // ---------------------------------------------------------------- free bodies
-  float v_c = art ? vstar : 0.f;
-  f3 mycom = f3{0, 0, 0};
-  for (int b = 0; b < nf; b++) {
-    float in[10];
-    free_inertial_of(M, N, b, e, in);
-    pose_t P = pose_soa(S.free_s, 13 * b, N, e);
-    m3 R = qmat(P.q);
-    s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
-    s3 Ii = sinverse(Iw);
-    const float minv = 1.f / in[0];
-    f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
-    f3 v0 = f3{SOA(S.free_s, 13 * b + 7), SOA(S.free_s, 13 * b + 8), SOA(S.free_s, 13 * b + 9)};
-    f3 w0 = f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)};
-    f3 acc = f3{SOA(S.free_force, 3 * b), SOA(S.free_force, 3 * b + 1), SOA(S.free_force, 3 * b + 2)} * minv;
-    if (M.free_gravity[b]) acc += g3;
-    f3 vv = v0 + acc * dt;
-    f3 ww = w0 - smulv(Ii, cross(w0, smulv(Iw, w0))) * dt;
-    const float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
-    vv = vv * (ld > 0.f ? ld : 0.f);
-    ww = ww * (ad > 0.f ? ad : 0.f);
-    if (c == 0) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
-    if (freel && fb_id == b) {
-      mycom = com;
-      v_c = fk < 3 ? comp(vv, fk) : comp(ww, fk - 3);
-      const f3 irow = fk == 3 ? f3{Ii.xx, Ii.xy, Ii.xz} : (fk == 4 ? f3{Ii.xy, Ii.yy, Ii.yz} : f3{Ii.xz, Ii.yz, Ii.zz});
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        float val = 0.f;
-        if (fk < 3) val = k == c ? minv : 0.f;
-        else val = k == fbase + 3 ? irow.x : (k == fbase + 4 ? irow.y : (k == fbase + 5 ? irow.z : 0.f));
-        Irow[k] = val;
-      }
-    }
-  }
-  __syncthreads();  // the dynamics staging area is dead from here on: rows overlay it
-
-  PH(3);
-  // ---------------------------------------------------------------- rows
-  float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
-  // joint limits: row j for joint j. J = side_j e_j, W = side_j * column j of A^-1 (kept in LDS
-  // row j); the scalars and the multiplier stay in lane j's registers.
-  float lim_inv = 0.f, lim_bpos = 0.f, lim_bvel = 0.f, lim_side = 0.f, lim_lam = 0.f;
-  {
-    const bool has = art && (lo_c > -1e30f || hi_c < 1e30f);
-    const float dlo = q_c - lo_c, dhi = hi_c - q_c;
-    const float C = dlo <= dhi ? dlo : dhi;
-    lim_side = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
-    float dself = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      if (j >= n) break;
-      const float sj = gbc(lim_side, j);
-      L[S16_U + S16_ROWLEN * j + 16 + c] = sj * Irow[j];
-      if (c == j) dself = Irow[j];
-    }
-    lim_inv = (has && dself > 1e-12f) ? 1.f / dself : 0.f;
-    lim_bpos = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
-    lim_bvel = C >= 0.f ? C / dt : 0.f;
-  }
-  int nrow = n;
-  // contact rows come in blocks of 3 (normal, t1, t2): keep whole blocks on one side of the LDS boundary
-  const int lds_limit = n + 3 * ((S16_ROWS_LDS - n) / 3);
-  {
-    int ncontact = 0;
-    for (int w = 0; w < M.n_words; w++) {
-      unsigned bits = S.hit_mask[(size_t)w * N + e];
-      while (__any(bits != 0u)) {
-        const bool act = bits != 0u;
-        const int bit = act ? (__ffs(bits) - 1) : 0;
-        bits = act ? (bits & (bits - 1u)) : 0u;
-        const int p = act ? (w * 32 + bit) : 0;
-        const int cnt = act ? S.pair_cnt[(size_t)p * N + e] : 0;
-        const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
-        if (act && live && c < 3) SOA(S.pair_imp, 3 * p + c) = 0.f;
-        const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
-        const int ka = M.shape_kind[sa], kb = M.shape_kind[sb], ia = M.shape_index[sa], ib = M.shape_index[sb];
-        const float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
-        const f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
-        const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
-        const f3 t2 = cross(nrm, t1);
-        // does this lane's component move with side A / side B of the pair?
-        float sgn_art = 0.f;  // for articulation lanes: +1 (A), -1 (B), 0, or both cancel
-        bool mineA = false, mineB = false;
-        if (art) {
-          if (ka == MSSIM_BODY_ART && ia >= 0 && (((M.dof_anc[ia] | (1u << ia)) >> c) & 1u)) mineA = true;
-          if (kb == MSSIM_BODY_ART && ib >= 0 && (((M.dof_anc[ib] | (1u << ib)) >> c) & 1u)) mineB = true;
-          sgn_art = (mineA ? 1.f : 0.f) - (mineB ? 1.f : 0.f);
-        } else if (freel) {
-          mineA = ka == MSSIM_BODY_FREE && ia == fb_id;
-          mineB = kb == MSSIM_BODY_FREE && ib == fb_id;
+    for (int k = 0; k < 2; k++) {
+      const int s = c + 16 * k;
+      shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
+      shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
+      if (s < M.n_shape) {
+        const int slot = M.shape_env_slot[s];
+        if (slot < 0) {
+          shF[k] = pose_from(M.shape_frame + 7 * s);
+          shP[k][0] = M.shape_param[4 * s]; shP[k][1] = M.shape_param[4 * s + 1]; shP[k][2] = M.shape_param[4 * s + 2];
+          shBc[k] = f3{M.shape_center[3 * s], M.shape_center[3 * s + 1], M.shape_center[3 * s + 2]};
+          shBr[k] = M.shape_bound[4 * s + 3];
+        } else {
+          shF[k] = pose_soa(M.env_shape_frame, 7 * slot, N, e);
+          const float* pp = M.env_shape_param + (size_t)(4 * slot) * N + e;
+          shP[k][0] = pp[0]; shP[k][1] = pp[(size_t)N]; shP[k][2] = pp[2 * (size_t)N];
+          const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
+          shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
+          shBr[k] = bb[3 * (size_t)N];
         }
-        const float sgn_free = (mineA ? 1.f : 0.f) - (mineB ? 1.f : 0.f);
-        for (int k = 0; k < 4; k++) {
-          const bool ck = act && k < cnt && ncontact < MAXC;
-          if (act && k < cnt && ncontact >= MAXC && live && c == 0) S.overflow[e] = 1;
-          if (!__any(ck)) break;
-          const int kk = ck ? k : 0;
-          const f3 x = f3{pd[(size_t)(3 + 4 * kk) * N], pd[(size_t)(4 + 4 * kk) * N], pd[(size_t)(5 + 4 * kk) * N]};
-          const float sep = pd[(size_t)(6 + 4 * kk) * N];
-          // per-lane geometric factor of this contact point
-          f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
-          if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
-          const f3 r = x - mycom;
-          // the three directions of a contact at once: one LDS round trip for J -> W = A^-1 J^T
-          float J3[3], W3[3];
+        shMu[k] = M.shape_material[4 * s + 1];
+        shSlot[k] = pose_slot(M.shape_kind[s], M.shape_index[s]);
+        shPk[k] = (unsigned)M.shape_type[s] | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
+      }
+    }
+  }
+  // FUSED: the shape pair this lane tests in cull round r (pair 16 r + c), packed sa | sb << 8
+  constexpr int PR = 12;
+  int cullp[PR];
+  if (FUSED) {
 #pragma unroll
-          for (int dk = 0; dk < 3; dk++) {
-            const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
-            float J = 0.f;
-            if (art) J = sgn_art * dot(d, col);
-            else if (freel) J = sgn_free * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
-            J3[dk] = J;
+    for (int r = 0; r < PR; r++) {
+      const int p = 16 * r + c;
+      cullp[r] = p < M.n_pair ? (M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8)) : -1;
+    }
+  }
+  __syncthreads();
+  PH(0);
+
+  float v_c = 0.f;
+  int nrow_con = 0;  // contacts of this env in the current substep (group-uniform)
+  float lim_lam = 0.f;
+  pose_t nb = bp_c;
+  f3 naw = aw_c, nan = an_c;
+
+  for (int sub = 0; sub < n_sub; sub++) {
+    const bool last = sub == n_sub - 1;
+    // ================================================================ contacts -> LDS records
+    int nc = 0;
+    if (FUSED) {
+      // ---- world shape table of this env
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int s = c + 16 * k;
+        if (s < M.n_shape) {
+          pose_t P = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
+          if (shSlot[k] >= 0) P = lds_pose(L + S16_PT + 7 * shSlot[k]);
+          const pose_t W = pmul(P, shF[k]);
+          const f3 bcw = P.p + qrot(P.q, shBc[k]);
+          float* o = L + S16_NP_SHP + 16 * s;
+          lds_pose_store(o, W);
+          o[7] = shP[k][0]; o[8] = shP[k][1]; o[9] = shP[k][2];
+          o[10] = bcw.x; o[11] = bcw.y; o[12] = bcw.z; o[13] = shBr[k];
+          o[14] = __uint_as_float(shPk[k]);
+          o[15] = shMu[k];
+        }
+      }
+      __syncthreads();
+      PH(22);
+      // ---- cull: 16 pairs of this env per round, survivors appended in pair order
+      int nh = 0;
+      bool hit_over = false;
+      auto cull_round = [&](int p, int sab) __attribute__((always_inline)) {
+        bool surv = false;
+        const int sa = sab & 0xFF, sb = (sab >> 8) & 0xFF;
+        if (sab >= 0) {
+          const float* ta_ = L + S16_NP_SHP + 16 * sa;
+          const float* tb_ = L + S16_NP_SHP + 16 * sb;
+          const int ta = (int)(__float_as_uint(ta_[14]) & 7u), tb = (int)(__float_as_uint(tb_[14]) & 7u);
+          const f3 cb = f3{tb_[10], tb_[11], tb_[12]};
+          const float ra = ta_[13], rb = tb_[13];
+          f3 ca = f3{0, 0, 0};
+          bool cull;
+          if (ta == SH_PLANE) {
+            const m3 R = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]});
+            cull = dot(mcol(R, 0), cb - f3{ta_[0], ta_[1], ta_[2]}) > rb + M.contact_offset;
+          } else {
+            ca = f3{ta_[10], ta_[11], ta_[12]};
+            const f3 d = cb - ca;
+            const float rr = ra + rb + M.contact_offset;
+            cull = dot(d, d) > rr * rr;
           }
-          __syncthreads();
-          L[S16_VEC + 16 + c] = J3[0]; L[S16_VEC + 32 + c] = J3[1]; L[S16_VEC + 48 + c] = J3[2];
-          __syncthreads();
-#pragma unroll
-          for (int dk = 0; dk < 3; dk++) {
-            float Jv[16];
-            ld16(L + S16_VEC + 16 + 16 * dk, Jv);
-            float W = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; j++) W += Irow[j] * Jv[j];
-            W3[dk] = W;
+          // tighter, still conservative: the other shape's bounding sphere against an oriented box
+          if (!cull && ta == SH_BOX) {
+            const shape_t A = shape_from_table(M, ta_);
+            const float rr = rb + M.contact_offset;
+            cull = point_box_dist2(A, cb) > rr * rr;
           }
-          // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
-          const float d0 = gsum16(J3[0] * W3[0]), d1 = gsum16(J3[1] * W3[1]), d2 = gsum16(J3[2] * W3[2]);
-          const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
-          if (ck) {
+          if (!cull && tb == SH_BOX && ta != SH_PLANE) {
+            const shape_t B = shape_from_table(M, tb_);
+            const float rr = ra + M.contact_offset;
+            cull = point_box_dist2(B, ca) > rr * rr;
+          }
+          surv = !cull;
+        }
+        const unsigned long long bal = __ballot(surv);
+        const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
+        const int rank = nh + __popc(m16 & ((1u << c) - 1u));
+        if (surv) {
+          if (rank < S16_MAX_HIT) reinterpret_cast<int*>(L)[S16_NP_HIT + rank] = p | (sa << 16) | (sb << 24);
+          else hit_over = true;
+        }
+        nh += __popc(m16);
+      };
 #pragma unroll
-            for (int dk = 0; dk < 3; dk++) {
-              const int r_idx = nrow + dk;
-              float* row = r_idx < lds_limit ? (L + S16_U + S16_ROWLEN * r_idx) : (grow + (size_t)S16_ROWLEN * (r_idx - lds_limit));
-              if (r_idx < lds_limit || live) {
-                const float diag = dk == 0 ? d0 : (dk == 1 ? d1 : d2);
-                row[c] = J3[dk];
-                row[16 + c] = W3[dk];
-                if (c == 0) {
-                  row[32] = diag > 1e-12f ? 1.f / diag : 0.f;
-                  row[33] = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
-                  row[34] = dk == 0 ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
-                  row[35] = dk == 0 ? -1.f : mu;
-                  row[36] = 0.f;
-                  row[37] = __int_as_float(p);
-                  row[38] = dk == 0 ? 0.f : (dk == 1 ? g10 : g20);
-                  row[39] = dk == 2 ? g21 : 0.f;
-                }
+      for (int r = 0; r < PR; r++) {
+        if (16 * r >= M.n_pair) break;
+        cull_round(16 * r + c, cullp[r]);
+      }
+      for (int base = 16 * PR; base < M.n_pair; base += 16) {
+        const int p = base + c;
+        cull_round(p, p < M.n_pair ? (M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8)) : -1);
+      }
+      if (__any(hit_over) && hit_over && live) S.overflow[e] = 1;
+      nh = nh < S16_MAX_HIT ? nh : S16_MAX_HIT;
+      __syncthreads();
+      PH(23);
+      // ---- manifolds: all surviving (env, pair) tasks of the wave spread over the 64 lanes
+      int cum[S16_ENVS_PER_BLOCK + 1];
+      cum[0] = 0;
+#pragma unroll
+      for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) cum[j + 1] = cum[j] + __shfl(nh, 16 * j);
+      const int T = cum[S16_ENVS_PER_BLOCK];
+      PH_ADD(26, T);
+      for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + (int)threadIdx.x;
+        const bool has = t < T;
+        int ge = 0;
+#pragma unroll
+        for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += (has && t >= cum[j]) ? 1 : 0;
+        const int idx = has ? t - cum[ge] : 0;
+        float* Lg = sm + ge * S16_ENV_FLOATS;
+        manifold_t m;
+        m.count = 0;
+        int pk = 0;
+        if (has) {
+          pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 16) & 0xFF));
+          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF));
+          PH_ADD(27, __popcll(__ballot(A.type == SH_PLANE)));
+          PH_ADD(28, __popcll(__ballot(A.type == SH_BOX && B.type == SH_BOX)));
+          if (A.type == SH_PLANE) collide_plane(A, B, M.contact_offset, m);
+          else if (A.type == SH_BOX && B.type == SH_BOX) collide_box_box<16>(A, B, M.contact_offset, m, sm + g * S16_ENV_FLOATS + S16_NP_SCR + c);
+          else collide_mpr(A, B, M.contact_offset, m);
+          reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
+        }
+        __syncthreads();
+        if (has && m.count > 0) {
+          int off = 0;
+          for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(Lg)[S16_NP_CNT + j];
+          const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
+          const float mu = 0.5f * (Lg[S16_NP_SHP + 16 * sa + 15] + Lg[S16_NP_SHP + 16 * sb + 15]);
+          const int bodies = (int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) |
+                             ((int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) << 8);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (k < m.count && off + k < MAXC) {
+              float* r = Lg + S16_REC + S16_REC_LEN * (off + k);
+              r[0] = m.n.x; r[1] = m.n.y; r[2] = m.n.z;
+              r[3] = m.x[k].x; r[4] = m.x[k].y; r[5] = m.x[k].z;
+              r[6] = m.sep[k] - M.rest_offset;
+              r[7] = __int_as_float(pk & 0xFFFF);
+              r[8] = __int_as_float(bodies);
+              r[9] = mu;
+            }
+        }
+        __syncthreads();
+      }
+      PH(24);
+      {
+        int tot = 0;
+        for (int j = c; j < nh; j += 16) tot += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
+        tot += __shfl_xor(tot, 8, 16); tot += __shfl_xor(tot, 4, 16); tot += __shfl_xor(tot, 2, 16); tot += __shfl_xor(tot, 1, 16);
+        if (tot > MAXC) { if (live && c == 0) S.overflow[e] = 1; tot = MAXC; }
+        nc = tot;
+      }
+      __syncthreads();
+    } else {
+      // ---- split path: copy this env's manifolds (k_narrow output, pair order) into LDS records
+      int ncontact = 0;
+      for (int w = 0; w < M.n_words; w++) {
+        unsigned bits = S.hit_mask[(size_t)w * N + e];
+        while (__any(bits != 0u)) {
+          const bool act = bits != 0u;
+          const int bit = act ? (__ffs(bits) - 1) : 0;
+          bits = act ? (bits & (bits - 1u)) : 0u;
+          const int p = act ? (w * 32 + bit) : 0;
+          const int cnt = act ? S.pair_cnt[(size_t)p * N + e] : 0;
+          const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
+          if (act && live && c < 3) SOA(S.pair_imp, 3 * p + c) = 0.f;
+          const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+          const int bodies = (pose_slot(M.shape_kind[sa], M.shape_index[sa]) + 1) | ((pose_slot(M.shape_kind[sb], M.shape_index[sb]) + 1) << 8);
+          const float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
+          for (int k = 0; k < 4; k++) {
+            const bool ck = act && k < cnt;
+            if (ck && ncontact >= MAXC && live && c == 0) S.overflow[e] = 1;
+            if (ck && ncontact < MAXC) {
+              if (c < 10) {
+                float val;
+                if (c < 3) val = pd[(size_t)c * N];
+                else if (c < 7) val = pd[(size_t)(3 + 4 * k + (c - 3)) * N];
+                else val = c == 7 ? __int_as_float(p) : (c == 8 ? __int_as_float(bodies) : mu);
+                L[S16_REC + S16_REC_LEN * ncontact + c] = val;
               }
+              ncontact++;
             }
           }
-          if (ck) { nrow += 3; ncontact++; }
         }
       }
+      nc = ncontact;
+      __syncthreads();
     }
-  }
-  __syncthreads();
+    PH(21);
 
-  PH(4);
-  // ---------------------------------------------------------------- projected Gauss-Seidel
-  const int nr_lds = nrow < lds_limit ? nrow : lds_limit;  // rows held in LDS (limits + whole contact blocks)
-  const int nc_lds = (nr_lds - n) / 3, nc_glb = (nrow - nr_lds) / 3;
-  int max_clds = nc_lds, max_cglb = nc_glb;
-#pragma unroll
-  for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) {
-    max_clds = max(max_clds, __shfl_xor(max_clds, o));
-    max_cglb = max(max_cglb, __shfl_xor(max_cglb, o));
-  }
-  float vpos_c = v_c;
-  // one contact = block of 3 rows. The three J.v reductions are independent (issued back to back);
-  // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
-  // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
-  // the dependent reduction chains.
-  struct ConRec {
-    float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, g10, g20, g21;
-    float4 s0, s1, s2;
-  };
-  auto con_load = [&](const float* row, ConRec& R) __attribute__((always_inline)) {
-    R.J0 = row[c]; R.W0 = row[16 + c];
-    R.J1 = row[S16_ROWLEN + c]; R.W1 = row[S16_ROWLEN + 16 + c];
-    R.J2 = row[2 * S16_ROWLEN + c]; R.W2 = row[2 * S16_ROWLEN + 16 + c];
-    R.s0 = *reinterpret_cast<const float4*>(row + 32);
-    R.s1 = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
-    R.s2 = *reinterpret_cast<const float4*>(row + 2 * S16_ROWLEN + 32);
-    R.lam0 = row[36]; R.lam1 = row[S16_ROWLEN + 36]; R.lam2 = row[2 * S16_ROWLEN + 36];
-    R.g10 = row[S16_ROWLEN + 38];
-    R.g20 = row[2 * S16_ROWLEN + 38]; R.g21 = row[2 * S16_ROWLEN + 39];
-  };
-  auto con_apply = [&](const ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
-    const float jv0 = gsum16(R.J0 * v_c);
-    const float jv1 = gsum16(R.J1 * v_c);
-    const float jv2 = gsum16(R.J2 * v_c);
-    float nl0 = fmaxf(R.lam0 - (jv0 + (use_bias ? R.s0.y : R.s0.z)) * R.s0.x, 0.f);
-    nl0 = (active && R.s0.x > 0.f) ? nl0 : R.lam0;
-    const float dl0 = nl0 - R.lam0;
-    const float h1 = R.s1.w * nl0;
-    float nl1 = fminf(fmaxf(R.lam1 - (jv1 + R.g10 * dl0) * R.s1.x, -h1), h1);
-    nl1 = (active && R.s1.x > 0.f) ? nl1 : R.lam1;
-    const float dl1 = nl1 - R.lam1;
-    const float h2 = R.s2.w * nl0;
-    float nl2 = fminf(fmaxf(R.lam2 - (jv2 + R.g20 * dl0 + R.g21 * dl1) * R.s2.x, -h2), h2);
-    nl2 = (active && R.s2.x > 0.f) ? nl2 : R.lam2;
-    const float dl2 = nl2 - R.lam2;
-    if (active) {
-      v_c = fmaf(R.W0, dl0, fmaf(R.W1, dl1, fmaf(R.W2, dl2, v_c)));
-      if (c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
-    }
-  };
-#ifdef EXP_ITERS
-  const int n_iters = EXP_ITERS;
-#else
-  const int n_iters = M.pos_iters + M.vel_iters;
-#endif
-  float* const crow = L + S16_U + S16_ROWLEN * n;  // first contact row in LDS
-  for (int it = 0; it <= n_iters; it++) {
-    if (it == M.pos_iters) {
-      vpos_c = v_c;
-      q_c += dt * v_c;
-      for (int b = 0; b < nf; b++) {
-        float in[10];
-        free_inertial_of(M, N, b, e, in);
-        const int base = n + 6 * b;
-        f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
-        f3 ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
-        f3 com = f3{L[S16_COM + 3 * b], L[S16_COM + 3 * b + 1], L[S16_COM + 3 * b + 2]} + vv * dt;
-        q4 qq = qnormalized(q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)});
-        q4 dq = qmul(q4{0.f, ww.x, ww.y, ww.z}, qq);
-        qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
-        f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
-        if (c == 0 && live) {
-          SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
-          SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
-        }
-      }
-    }
-    if (it == n_iters) break;
-    PH(17);
-    const bool use_bias = it < M.pos_iters;
-    // joint-limit rows, exact sequential Gauss-Seidel semantics, but only rows that change are
-    // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
-    // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
+    // ================================================================ dynamics: RNEA bias + CRBA
+    sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+    if (art) S_c = rev_c ? sv6{aw_c, cross(an_c - O, aw_c)} : sv6{f3{0, 0, 0}, aw_c};
     {
-      int cursor = 0;
-      const float bl = use_bias ? lim_bpos : lim_bvel;
-      while (true) {
-        const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
-        const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
-        const unsigned long long bal = __ballot(cand);
-        if (bal == 0ull) break;
-        const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
-        const bool act = m16 != 0u;
-        const int j = act ? (__ffs(m16) - 1) : 0;
-        float dl = gbc(nl - lim_lam, j);
-        dl = act ? dl : 0.f;
-        if (act && c == j) lim_lam = nl;
-        v_c = fmaf(L[S16_U + S16_ROWLEN * j + 16 + c], dl, v_c);
-        cursor = act ? j + 1 : 16;
+      float* p = L + S16_S + 6 * c;
+      p[0] = S_c.w.x; p[1] = S_c.w.y; p[2] = S_c.w.z; p[3] = S_c.v.x; p[4] = S_c.v.y; p[5] = S_c.v.z;
+      L[S16_VEC + c] = qd_c;
+    }
+    __syncthreads();
+    // V_c = sum over (ancestors + self) of S_i qd_i
+    sv6 V = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+    for (int i = 0; i < n; i++) {
+      float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;
+      const float* p = L + S16_S + 6 * i;
+      V.w += f3{p[0], p[1], p[2]} * m;
+      V.v += f3{p[3], p[4], p[5]} * m;
+    }
+    {
+      sv6 T = crossm(V, S_c);
+      float* p = L + S16_T + 6 * c;
+      p[0] = T.w.x * qd_c; p[1] = T.w.y * qd_c; p[2] = T.w.z * qd_c; p[3] = T.v.x * qd_c; p[4] = T.v.y * qd_c; p[5] = T.v.z * qd_c;
+    }
+    __syncthreads();
+    sv6 Ab = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+    for (int i = 0; i < n; i++) {
+      float m = (((anc_c | self_c) >> i) & 1u) ? 1.f : 0.f;
+      const float* p = L + S16_T + 6 * i;
+      Ab.w += f3{p[0], p[1], p[2]} * m;
+      Ab.v += f3{p[3], p[4], p[5]} * m;
+    }
+    si10 I_c = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
+    sf6 Fb_c = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
+    if (art) {
+      m3 R = qmat(bp_c.q);
+      s3 Iw = srotate(R, s3{inert[4], inert[5], inert[6], inert[7], inert[8], inert[9]});
+      f3 cm = bp_c.p + mmulv(R, f3{inert[1], inert[2], inert[3]}) - O;
+      float m = inert[0], cc = dot(cm, cm);
+      Iw.xx += m * (cc - cm.x * cm.x); Iw.yy += m * (cc - cm.y * cm.y); Iw.zz += m * (cc - cm.z * cm.z);
+      Iw.xy -= m * cm.x * cm.y; Iw.xz -= m * cm.x * cm.z; Iw.yz -= m * cm.y * cm.z;
+      I_c = si10{m, cm * m, Iw};
+      sf6 f1 = imul(I_c, Ab);
+      sf6 f2 = crossf(V, imul(I_c, V));
+      Fb_c = sf6{f1.n + f2.n, f1.f + f2.f};
+      if (grav_c) { Fb_c.f -= g3 * m; Fb_c.n -= cross(I_c.h, g3); }
+    }
+    {
+      float* p = L + S16_F + 6 * c;
+      p[0] = Fb_c.n.x; p[1] = Fb_c.n.y; p[2] = Fb_c.n.z; p[3] = Fb_c.f.x; p[4] = Fb_c.f.y; p[5] = Fb_c.f.z;
+      float* qI = L + S16_IC + 10 * c;
+      qI[0] = I_c.m; qI[1] = I_c.h.x; qI[2] = I_c.h.y; qI[3] = I_c.h.z;
+      qI[4] = I_c.I.xx; qI[5] = I_c.I.yy; qI[6] = I_c.I.zz; qI[7] = I_c.I.xy; qI[8] = I_c.I.xz; qI[9] = I_c.I.yz;
+#pragma unroll
+      for (int k = 0; k < 16; k++) L[S16_MAT + 16 * c + k] = 0.f;
+    }
+    __syncthreads();
+    // composite force / inertia: sum over (descendants + self)
+    sf6 Fc = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
+    si10 Icc = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
+    for (int k = 0; k < n; k++) {
+      const unsigned ak = reinterpret_cast<const unsigned*>(L)[S16_ANC + k];
+      float m = (art && ((ak >> c) & 1u)) ? 1.f : 0.f;
+      const float* p = L + S16_F + 6 * k;
+      Fc.n += f3{p[0], p[1], p[2]} * m;
+      Fc.f += f3{p[3], p[4], p[5]} * m;
+      const float* qI = L + S16_IC + 10 * k;
+      Icc.m += qI[0] * m;
+      Icc.h += f3{qI[1], qI[2], qI[3]} * m;
+      Icc.I.xx += qI[4] * m; Icc.I.yy += qI[5] * m; Icc.I.zz += qI[6] * m;
+      Icc.I.xy += qI[7] * m; Icc.I.xz += qI[8] * m; Icc.I.yz += qI[9] * m;
+    }
+    const float bias_c = sdot(S_c, Fc);
+    {
+      sf6 Fcol = imul(Icc, S_c);
+      for (int i = 0; i < n; i++) {
+        if (art && (((anc_c | self_c) >> i) & 1u)) {
+          const float* p = L + S16_S + 6 * i;
+          float v = dot(f3{p[0], p[1], p[2]}, Fcol.n) + dot(f3{p[3], p[4], p[5]}, Fcol.f);
+          L[S16_MAT + 16 * c + i] = v;
+          L[S16_MAT + 16 * i + c] = v;
+        }
       }
     }
-    PH(18);
-    if (max_clds > 0) {
-      ConRec A, B;
-      con_load(crow, A);
-      int k = 0;
-      while (true) {
-        // next block is loaded before the dependent chain of the current one (index clamped: in range)
-        con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), B);
-        con_apply(A, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
-        if (++k >= max_clds) break;
-        con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), A);
-        con_apply(B, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
-        if (++k >= max_clds) break;
-      }
+    __syncthreads();
+    float Mrow[16], qdv[16];
+    ld16(L + S16_MAT + 16 * c, Mrow);
+    ld16(L + S16_VEC, qdv);
+    const float Mdiag = L[S16_MAT + 16 * c + c];
+    float kp = kp0, kd = kd0;
+    if (accel_mode) { kp *= Mdiag; kd *= Mdiag; }
+    const float tau0 = kp * (qt_c - q_c) + kd * qdt_c;
+    float Dj = dt * kd + dt * dt * kp;
+    float mv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) mv += Mrow[k] * qdv[k];
+    // tendons: torque into rhs, implicit stiffness into the matrix row
+    float tau_t = 0.f;
+    float Trow[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) Trow[k] = 0.f;
+    for (int t = 0; t < M.n_tendon; t++) {
+      const int a = M.tendon_dof[2 * t], b = M.tendon_dof[2 * t + 1];
+      const float* tp = M.tendon_param + 5 * t;
+      const float ca = tp[0], cb = tp[1];
+      const float cval = ca * gbc(q_c, a) + cb * gbc(q_c, b) - tp[2];
+      const float w = dt * dt * tp[3] + dt * tp[4];
+      const float cj = c == a ? ca : (c == b ? cb : 0.f);
+      tau_t -= tp[3] * cval * cj;
+#pragma unroll
+      for (int k = 0; k < 16; k++) Trow[k] += w * cj * (k == a ? ca : (k == b ? cb : 0.f));
     }
-    PH(19);
-    for (int k = 0; k < max_cglb; k++) {
-      const bool active = k < nc_glb;
-      float* row = grow + (size_t)(3 * S16_ROWLEN) * (active ? k : 0);
-      ConRec A;
-      con_load(row, A);
-      con_apply(A, row, active && live, use_bias);
-    }
-    PH(20);
-  }
+    float rhs_c = art ? mv + dt * (tau0 + tau_t - bias_c + qf_c) : 0.f;
+    PH(1);
 
-  PH(5);
-  // ---------------------------------------------------------------- contact impulses per pair
-  {
-    int prev_p = -1;
-    f3 acc = f3{0, 0, 0};
-    const int ncon = (nrow - n) / 3;
-    for (int i = 0; i < ncon; i++) {
-      const int r = n + 3 * i;
-      // a contact's three rows never straddle the LDS / global boundary (lds_limit is block aligned)
-      const float* row = r < lds_limit ? (L + S16_U + S16_ROWLEN * r) : (grow + (size_t)S16_ROWLEN * (r - lds_limit));
-      const float* row1 = row + S16_ROWLEN;
-      const float* row2 = row + 2 * S16_ROWLEN;
-      const int p = __float_as_int(row[37]);
-      const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
-      const f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
+    // ================================================================ A^-1 by Gauss-Jordan (row per lane)
+    float Irow[16];
+    float vstar = 0.f;
+    for (int pass = 0; pass < 2; pass++) {
+      float Arow[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        Arow[k] = art ? (Mrow[k] + Trow[k] + (k == c ? Dj + arm : 0.f)) : (k == c ? 1.f : 0.f);
+        Irow[k] = k == c ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        if (k >= n) break;
+        __syncthreads();
+        if (c == k) {
+#pragma unroll
+          for (int j = 0; j < 16; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + 16 + j] = Irow[j]; }
+        }
+        __syncthreads();
+        float PA[16], PI[16];
+        ld16(L + S16_PIV, PA);
+        ld16(L + S16_PIV + 16, PI);
+        const float inv = 1.f / PA[k];
+        const float fac = Arow[k] * inv;
+        const bool piv = c == k;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          Arow[j] = piv ? PA[j] * inv : Arow[j] - fac * PA[j];
+          Irow[j] = piv ? PI[j] * inv : Irow[j] - fac * PI[j];
+        }
+      }
+      __syncthreads();
+      L[S16_VEC + 16 + c] = rhs_c;
+      __syncthreads();
+      float rv[16];
+      ld16(L + S16_VEC + 16, rv);
+      vstar = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) vstar += Irow[k] * rv[k];
+      if (pass == 1) break;
+      // drive force limit: saturated joints get the constant limit torque, lose their implicit terms
+      const float td = kp * (qt_c - q_c - dt * vstar) + kd * (qdt_c - vstar);
+      const bool sat = art && fmax < 1e30f && fabsf(td) > fmax;
+      if (!__any(sat)) break;
+      if (sat) {
+        rhs_c += dt * ((td > 0.f ? fmax : -fmax) - tau0);
+        Dj = 0.f;
+      }
+    }
+    if (!art) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) Irow[k] = 0.f;
+    }
+    PH(2);
+
+    // ================================================================ free bodies
+    v_c = art ? vstar : 0.f;
+    f3 mycom = f3{0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < S16_MAX_FREE; b++) {
+      if (b >= nf) break;
+      const float* in = fin[b];
+      const pose_t P = lds_pose(L + S16_PT + 7 * (S16_PT_FREE + b));
+      m3 R = qmat(P.q);
+      s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
+      s3 Ii = sinverse(Iw);
+      const float minv = 1.f / in[0];
+      f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
+      const int base = n + 6 * b;
+      f3 v0 = f3{gbc(vfree_c, base), gbc(vfree_c, base + 1), gbc(vfree_c, base + 2)};
+      f3 w0 = f3{gbc(vfree_c, base + 3), gbc(vfree_c, base + 4), gbc(vfree_c, base + 5)};
+      f3 acc = f3{gbc(fforce_c, base), gbc(fforce_c, base + 1), gbc(fforce_c, base + 2)} * minv;
+      if (M.free_gravity[b]) acc += g3;
+      f3 vv = v0 + acc * dt;
+      f3 ww = w0 - smulv(Ii, cross(w0, smulv(Iw, w0))) * dt;
+      const float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
+      vv = vv * (ld > 0.f ? ld : 0.f);
+      ww = ww * (ad > 0.f ? ad : 0.f);
+      if (c == 0) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
+      if (freel && fb_id == b) {
+        mycom = com;
+        v_c = fk < 3 ? comp(vv, fk) : comp(ww, fk - 3);
+        const f3 irow = fk == 3 ? f3{Ii.xx, Ii.xy, Ii.xz} : (fk == 4 ? f3{Ii.xy, Ii.yy, Ii.yz} : f3{Ii.xz, Ii.yz, Ii.zz});
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          float val = 0.f;
+          if (fk < 3) val = k == c ? minv : 0.f;
+          else val = k == fbase + 3 ? irow.x : (k == fbase + 4 ? irow.y : (k == fbase + 5 ? irow.z : 0.f));
+          Irow[k] = val;
+        }
+      }
+    }
+    fforce_c = 0.f;  // an applied force acts during one substep only
+    __syncthreads();  // the dynamics staging area is dead from here on: rows overlay it
+    PH(3);
+
+    // ================================================================ rows
+    float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
+    // joint limits: row j for joint j. J = side_j e_j, W = side_j * column j of A^-1 (LDS [j][16]);
+    // the scalars and the multiplier stay in lane j's registers.
+    float lim_inv = 0.f, lim_bpos = 0.f, lim_bvel = 0.f, lim_side = 0.f;
+    lim_lam = 0.f;
+    {
+      const bool has = art && (lo_c > -1e30f || hi_c < 1e30f);
+      const float dlo = q_c - lo_c, dhi = hi_c - q_c;
+      const float C = dlo <= dhi ? dlo : dhi;
+      lim_side = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
+      float dself = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if (j >= n) break;
+        const float sj = gbc(lim_side, j);
+        L[S16_LIMW + 16 * j + c] = sj * Irow[j];
+        if (c == j) dself = Irow[j];
+      }
+      lim_inv = (has && dself > 1e-12f) ? 1.f / dself : 0.f;
+      lim_bpos = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
+      lim_bvel = C >= 0.f ? C / dt : 0.f;
+    }
+    // contacts: 3 rows each (normal, t1, t2), built from the LDS records
+    int max_nc = nc;
+#pragma unroll
+    for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, o));
+    for (int i = 0; i < max_nc; i++) {
+      const bool ck = i < nc;
+      const float* rec = L + S16_REC + S16_REC_LEN * (ck ? i : 0);
+      const f3 nrm = f3{rec[0], rec[1], rec[2]};
+      const f3 x = f3{rec[3], rec[4], rec[5]};
+      const float sep = rec[6];
+      const int p = __float_as_int(rec[7]);
+      const int bodies = __float_as_int(rec[8]);
+      const float mu = rec[9];
       const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
       const f3 t2 = cross(nrm, t1);
-      const f3 imp = nrm * row[36] + t1 * row1[36] + t2 * row2[36];
-      if (p != prev_p) {
-        if (prev_p >= 0 && c == 0 && live) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
-        acc = f3{0, 0, 0};
-        prev_p = p;
+      // does this lane's component move with side A / side B of the pair?
+      const int slA = (bodies & 0xFF) - 1, slB = ((bodies >> 8) & 0xFF) - 1;
+      float sgn = 0.f;
+      if (art) {
+        const bool mineA = slA >= S16_PT_LINK && slA < S16_PT_FREE && ((reinterpret_cast<const unsigned*>(L)[S16_ANC + slA - S16_PT_LINK] >> c) & 1u);
+        const bool mineB = slB >= S16_PT_LINK && slB < S16_PT_FREE && ((reinterpret_cast<const unsigned*>(L)[S16_ANC + slB - S16_PT_LINK] >> c) & 1u);
+        sgn = (mineA ? 1.f : 0.f) - (mineB ? 1.f : 0.f);
+      } else if (freel) {
+        sgn = (slA == S16_PT_FREE + fb_id ? 1.f : 0.f) - (slB == S16_PT_FREE + fb_id ? 1.f : 0.f);
       }
-      acc += imp;
+      // per-lane geometric factor of this contact point
+      f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
+      if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
+      const f3 r = x - mycom;
+      // the three directions of a contact at once: one LDS round trip for J -> W = A^-1 J^T
+      float J3[3], W3[3];
+#pragma unroll
+      for (int dk = 0; dk < 3; dk++) {
+        const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
+        float J = 0.f;
+        if (art) J = sgn * dot(d, col);
+        else if (freel) J = sgn * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
+        J3[dk] = J;
+      }
+      __syncthreads();
+      L[S16_VEC + 16 + c] = J3[0]; L[S16_VEC + 32 + c] = J3[1]; L[S16_VEC + 48 + c] = J3[2];
+      __syncthreads();
+#pragma unroll
+      for (int dk = 0; dk < 3; dk++) {
+        float Jv[16];
+        ld16(L + S16_VEC + 16 + 16 * dk, Jv);
+        float W = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) W += Irow[j] * Jv[j];
+        W3[dk] = W;
+      }
+      // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
+      const float d0 = gsum16(J3[0] * W3[0]), d1 = gsum16(J3[1] * W3[1]), d2 = gsum16(J3[2] * W3[2]);
+      const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
+      if (ck && (i < S16_CON_LDS || live)) {
+        float* row0 = i < S16_CON_LDS ? (L + S16_CROW + 3 * S16_ROWLEN * i) : (grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++) {
+          float* row = row0 + S16_ROWLEN * dk;
+          const float diag = dk == 0 ? d0 : (dk == 1 ? d1 : d2);
+          row[c] = J3[dk];
+          row[16 + c] = W3[dk];
+          if (c == 0) {
+            row[32] = diag > 1e-12f ? 1.f / diag : 0.f;
+            row[33] = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
+            row[34] = dk == 0 ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
+            row[35] = dk == 0 ? -1.f : mu;
+            row[36] = 0.f;
+            row[37] = __int_as_float(p);
+            row[38] = dk == 0 ? 0.f : (dk == 1 ? g10 : g20);
+            row[39] = dk == 2 ? g21 : 0.f;
+          }
+        }
+      }
     }
-    if (prev_p >= 0 && c == 0 && live) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
+    nrow_con = nc;
+    PH_ADD(29, max_nc);
+    PH_ADD(30, __shfl(nc, 0) + __shfl(nc, 16) + __shfl(nc, 32) + __shfl(nc, 48));
+    __syncthreads();
+    PH(4);
+
+    // ================================================================ projected Gauss-Seidel
+    const int nc_lds = nc < S16_CON_LDS ? nc : S16_CON_LDS, nc_glb = nc - nc_lds;
+    int max_clds = nc_lds, max_cglb = nc_glb;
+#pragma unroll
+    for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) {
+      max_clds = max(max_clds, __shfl_xor(max_clds, o));
+      max_cglb = max(max_cglb, __shfl_xor(max_cglb, o));
+    }
+    // one contact = block of 3 rows. The three J.v reductions are independent (issued back to back);
+    // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
+    // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
+    // the dependent reduction chains.
+    struct ConRec {
+      float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, g10, g20, g21;
+      float4 s0, s1, s2;
+    };
+    auto con_load = [&](const float* row, ConRec& R) __attribute__((always_inline)) {
+      R.J0 = row[c]; R.W0 = row[16 + c];
+      R.J1 = row[S16_ROWLEN + c]; R.W1 = row[S16_ROWLEN + 16 + c];
+      R.J2 = row[2 * S16_ROWLEN + c]; R.W2 = row[2 * S16_ROWLEN + 16 + c];
+      R.s0 = *reinterpret_cast<const float4*>(row + 32);
+      R.s1 = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
+      R.s2 = *reinterpret_cast<const float4*>(row + 2 * S16_ROWLEN + 32);
+      R.lam0 = row[36]; R.lam1 = row[S16_ROWLEN + 36]; R.lam2 = row[2 * S16_ROWLEN + 36];
+      R.g10 = row[S16_ROWLEN + 38];
+      R.g20 = row[2 * S16_ROWLEN + 38]; R.g21 = row[2 * S16_ROWLEN + 39];
+    };
+    auto con_apply = [&](const ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
+      const float jv0 = gsum16(R.J0 * v_c);
+      const float jv1 = gsum16(R.J1 * v_c);
+      const float jv2 = gsum16(R.J2 * v_c);
+      float nl0 = fmaxf(R.lam0 - (jv0 + (use_bias ? R.s0.y : R.s0.z)) * R.s0.x, 0.f);
+      nl0 = (active && R.s0.x > 0.f) ? nl0 : R.lam0;
+      const float dl0 = nl0 - R.lam0;
+      const float h1 = R.s1.w * nl0;
+      float nl1 = fminf(fmaxf(R.lam1 - (jv1 + R.g10 * dl0) * R.s1.x, -h1), h1);
+      nl1 = (active && R.s1.x > 0.f) ? nl1 : R.lam1;
+      const float dl1 = nl1 - R.lam1;
+      const float h2 = R.s2.w * nl0;
+      float nl2 = fminf(fmaxf(R.lam2 - (jv2 + R.g20 * dl0 + R.g21 * dl1) * R.s2.x, -h2), h2);
+      nl2 = (active && R.s2.x > 0.f) ? nl2 : R.lam2;
+      const float dl2 = nl2 - R.lam2;
+      if (active) {
+        v_c = fmaf(R.W0, dl0, fmaf(R.W1, dl1, fmaf(R.W2, dl2, v_c)));
+        if (c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
+      }
+    };
+#ifdef EXP_ITERS
+    const int n_iters = EXP_ITERS;
+#else
+    const int n_iters = M.pos_iters + M.vel_iters;
+#endif
+    float* const crow = L + S16_CROW;
+    for (int it = 0; it <= n_iters; it++) {
+      if (it == M.pos_iters) {
+        q_c += dt * v_c;
+#pragma unroll
+        for (int b = 0; b < S16_MAX_FREE; b++) {
+          if (b >= nf) break;
+          const float* in = fin[b];
+          const int base = n + 6 * b;
+          f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
+          f3 ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
+          f3 com = f3{L[S16_COM + 3 * b], L[S16_COM + 3 * b + 1], L[S16_COM + 3 * b + 2]} + vv * dt;
+          float* pt = L + S16_PT + 7 * (S16_PT_FREE + b);
+          q4 qq = qnormalized(q4{pt[3], pt[4], pt[5], pt[6]});
+          q4 dq = qmul(q4{0.f, ww.x, ww.y, ww.z}, qq);
+          qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
+          f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
+          __syncthreads();
+          if (c == 0) lds_pose_store(pt, pose_t{pp, qq});
+          if (c == 0 && live && last) {
+            SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
+            SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
+          }
+          __syncthreads();
+        }
+      }
+      if (it == n_iters) break;
+      PH(17);
+      const bool use_bias = it < M.pos_iters;
+      // joint-limit rows, exact sequential Gauss-Seidel semantics, but only rows that change are
+      // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
+      // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
+      {
+        int cursor = 0;
+        const float bl = use_bias ? lim_bpos : lim_bvel;
+        while (true) {
+          const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
+          const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
+          const unsigned long long bal = __ballot(cand);
+          if (bal == 0ull) break;
+          const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
+          const bool act = m16 != 0u;
+          const int j = act ? (__ffs(m16) - 1) : 0;
+          float dl = gbc(nl - lim_lam, j);
+          dl = act ? dl : 0.f;
+          if (act && c == j) lim_lam = nl;
+          v_c = fmaf(L[S16_LIMW + 16 * j + c], dl, v_c);
+          cursor = act ? j + 1 : 16;
+        }
+      }
+      PH(18);
+      if (max_clds > 0) {
+        ConRec A, B;
+        con_load(crow, A);
+        int k = 0;
+        while (true) {
+          // next block is loaded before the dependent chain of the current one (index clamped: in range)
+          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), B);
+          con_apply(A, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
+          if (++k >= max_clds) break;
+          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), A);
+          con_apply(B, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
+          if (++k >= max_clds) break;
+        }
+      }
+      PH(19);
+      for (int k = 0; k < max_cglb; k++) {
+        const bool active = k < nc_glb;
+        float* row = grow + (size_t)(3 * S16_ROWLEN) * (active ? k : 0);
+        ConRec A;
+        con_load(row, A);
+        con_apply(A, row, active && live, use_bias);
+      }
+      PH(20);
+    }
+    PH(5);
+
+    // ================================================================ contact impulses per pair (last substep)
+    if (last) {
+      // FUSED keeps the dense pair_cnt / pair_imp arrays valid with sparse updates: pairs of the
+      // previous step's hit list that are no longer in contact are zeroed, the new list is written
+      int* const newl = reinterpret_cast<int*>(L + S16_VEC);  // up to MAXC pair ids
+      int nnew = 0;
+      int nold = 0, oldp[3] = {-1, -1, -1};  // previous list, lane c holds entries c, c + 16, c + 32
+      if (FUSED) {
+        nold = S.hit_list[e];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+          if (c + 16 * k < nold) oldp[k] = S.hit_list[(size_t)(1 + c + 16 * k) * N + e];
+      }
+      int prev_p = -1, run = 0;
+      f3 acc = f3{0, 0, 0};
+      auto flush = [&]() __attribute__((always_inline)) {
+        if (prev_p >= 0 && live) {
+          if (c == 0) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
+          if (FUSED && c == 0) { S.pair_cnt[(size_t)prev_p * N + e] = run; S.hit_list[(size_t)(1 + nnew) * N + e] = prev_p; }
+        }
+        if (FUSED && prev_p >= 0) { if (c == 0) newl[nnew] = prev_p; nnew++; }
+      };
+      for (int i = 0; i < nc; i++) {
+        // a contact's three rows never straddle the LDS / global boundary
+        const float* row = i < S16_CON_LDS ? (L + S16_CROW + 3 * S16_ROWLEN * i) : (grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
+        const float* rec = L + S16_REC + S16_REC_LEN * i;
+        const int p = __float_as_int(rec[7]);
+        const f3 nrm = f3{rec[0], rec[1], rec[2]};
+        const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
+        const f3 t2 = cross(nrm, t1);
+        const f3 imp = nrm * row[36] + t1 * row[S16_ROWLEN + 36] + t2 * row[2 * S16_ROWLEN + 36];
+        if (p != prev_p) {
+          flush();
+          acc = f3{0, 0, 0};
+          run = 0;
+          prev_p = p;
+        }
+        acc += imp;
+        run++;
+      }
+      flush();
+      if (FUSED) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int po = oldp[k];
+          bool still = po < 0;
+          for (int j = 0; j < nnew; j++) still = still || (newl[j] == po);
+          if (!still && live) S.pair_cnt[(size_t)po * N + e] = 0;
+        }
+        if (c == 0 && live) S.hit_list[e] = nnew;
+        __syncthreads();
+      }
+    }
+    PH(6);
+
+    // ================================================================ FK at the new state
+    // FK by pointer jumping: lane c starts from its joint-local transform T_c (parent body -> body c)
+    // and composes with its ancestor's partial product, doubling the covered chain length per round
+    // (4 rounds cover depth 16); sincos and the products run in all lanes at once instead of a
+    // 9-long sequential chain. Same transforms as the sequential product, different association.
+    __syncthreads();
+    {
+      pose_t T = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
+      int up = -1;
+      if (art) {
+        if (rev_c) T = pose_t{JF_c.p, qnormalized(qmul(JF_c.q, qaxis_angle(al_c, q_c)))};
+        else T = pose_t{JF_c.p + qrot(JF_c.q, al_c) * q_c, JF_c.q};
+        up = par_c;
+      }
+      int* const upv = reinterpret_cast<int*>(L + S16_VEC + 48);
+      float* const mine = L + S16_BP + 7 * c;
+      for (int round = 0; round < 4; round++) {
+        if (!__any(up >= 0)) break;
+        if (art) lds_pose_store(mine, T);
+        upv[c] = up;
+        __syncthreads();
+        if (up >= 0) {
+          const pose_t Tu = lds_pose(L + S16_BP + 7 * up);
+          up = upv[up];
+          T = pmul(Tu, T);
+        }
+        __syncthreads();
+      }
+      nb = pmul(root, T);
+      if (art) lds_pose_store(mine, nb);
+      __syncthreads();
+      pose_t Wp = root;
+      if (par_c >= 0) Wp = lds_pose(L + S16_BP + 7 * par_c);
+      const pose_t Jw = pmul(Wp, JF_c);
+      naw = qrot(Jw.q, al_c);
+      nan = Jw.p;
+    }
+    // carry the state into the next substep
+    qacc_c = (v_c - qd_c) / dt;
+    qd_c = art ? v_c : 0.f;
+    vfree_c = freel ? v_c : 0.f;
+    bp_c = nb; aw_c = naw; an_c = nan;
+    PH(15);
   }
 
-  PH(6);
-  // ---------------------------------------------------------------- write back + FK at the new state
+  // ---------------------------------------------------------------- write back
   if (art && live) {
-    SOA(S.qacc, c) = (v_c - qd_c) / dt;
+    SOA(S.qacc, c) = qacc_c;
     SOA(S.q, c) = q_c;
     SOA(S.qd, c) = v_c;
   }
@@ -638,57 +995,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
     if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
   }
-  __syncthreads();
-  PH(14);
-  // FK by pointer jumping: lane c starts from its joint-local transform T_c (parent body -> body c)
-  // and composes with its ancestor's partial product, doubling the covered chain length per round
-  // (4 rounds cover depth 16); sincos and the products run in all lanes at once instead of a
-  // 9-long sequential chain. Same transforms as the sequential product, different association.
-  pose_t nb = root;
-  f3 naw = f3{0, 0, 0}, nan = f3{0, 0, 0};
-  {
-    pose_t T = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
-    int up = -1;
-    if (art) {
-      if (rev_c) T = pose_t{JF_c.p, qnormalized(qmul(JF_c.q, qaxis_angle(al_c, q_c)))};
-      else T = pose_t{JF_c.p + qrot(JF_c.q, al_c) * q_c, JF_c.q};
-      up = par_c;
-    }
-    int* const upv = reinterpret_cast<int*>(L + S16_VEC + 48);
-    float* const mine = L + S16_BP + 7 * c;
-#ifdef EXP_NO_FK
-    for (int round = 0; round < (N < 0 ? 4 : 0); round++) {
-#else
-    for (int round = 0; round < 4; round++) {
-#endif
-      if (!__any(up >= 0)) break;
-      mine[0] = T.p.x; mine[1] = T.p.y; mine[2] = T.p.z; mine[3] = T.q.w; mine[4] = T.q.x; mine[5] = T.q.y; mine[6] = T.q.z;
-      upv[c] = up;
-      __syncthreads();
-      if (up >= 0) {
-        const float* b = L + S16_BP + 7 * up;
-        const pose_t Tu = pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}};
-        up = upv[up];
-        T = pmul(Tu, T);
-      }
-      __syncthreads();
-    }
-    nb = pmul(root, T);
-    mine[0] = nb.p.x; mine[1] = nb.p.y; mine[2] = nb.p.z; mine[3] = nb.q.w; mine[4] = nb.q.x; mine[5] = nb.q.y; mine[6] = nb.q.z;
-    __syncthreads();
-    pose_t Wp = root;
-    if (par_c >= 0) {
-      const float* b = L + S16_BP + 7 * par_c;
-      Wp = pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}};
-    }
-    const pose_t Jw = pmul(Wp, JF_c);
-    naw = qrot(Jw.q, al_c);
-    nan = Jw.p;
-  }
-  PH(15);
   // body velocities about O with the new subspaces
   sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
   if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
+  __syncthreads();
   {
     float* p = L + S16_S + 6 * c;
     p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
@@ -703,11 +1013,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     nV.v += f3{p[3], p[4], p[5]} * m;
   }
   PH(16);
-#ifdef EXP_NO_FINAL_STORES
-  if (art && live && N < 0) {
-#else
   if (art && live) {
-#endif
     pose_store_soa(S.bodypose, 7 * c, N, e, nb);
     float* o = S.bodyvel + (size_t)(6 * c) * N + e;
     o[0] = nV.w.x; o[(size_t)N] = nV.w.y; o[2 * (size_t)N] = nV.w.z;
@@ -716,7 +1022,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     a[0] = naw.x; a[(size_t)N] = naw.y; a[2 * (size_t)N] = naw.z;
     a[3 * (size_t)N] = nan.x; a[4 * (size_t)N] = nan.y; a[5 * (size_t)N] = nan.z;
   }
-  if (live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
+  if (!FUSED && live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
+  (void)nrow_con;
   PH(7);
   PH_FLUSH
 }

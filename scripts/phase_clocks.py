@@ -25,7 +25,9 @@ dbg = ctypes.CDLL(lib)
 buf = (ctypes.c_ulonglong * 32)()
 names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
          "dyn: S stage", "dyn: V sum", "dyn: Ab sum", "dyn: inertia/force", "dyn: composite sum", "dyn: M columns",
-         "end: state stores", "end: FK chain", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)"]
+         "", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
+         "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: manifolds", "np: count",
+         "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
 for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" % steps, steps)):
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
@@ -34,7 +36,7 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
     tot = sum(buf[i] for i in range(32))
-    launches = k * 5
+    launches = k * (1 if os.environ.get('MSSIM_SOLVER', 'fused') == 'fused' else 5)
     blocks = (N + 3) // 4
     print(f"{env_id} N={N} {phase_name}: {tot / launches / blocks:.0f} cycles per block-launch")
     for i, nm in enumerate(names):
