@@ -57,25 +57,26 @@ MS_DEV f3 support(const shape_t& s, f3 d) {
       break;
     }
     case SH_CONVEX: {
-      // batches of 8 vertices: the 24 loads of a batch are issued together (one memory latency per
-      // batch instead of one per vertex). Indices past the end re-read vertex 0, which can never win
-      // the strict comparison, so the result equals the plain first-maximum scan.
+      // batches of 8 vertices read as six aligned 16-byte loads (the host pads every hull to a
+      // multiple of 8 vertices with copies of vertex 0 and aligns its start; a copy of vertex 0 can
+      // never win the strict comparison, so the result equals the plain first-maximum scan)
       const float* __restrict__ v = s.verts;
       float bx = v[0], by = v[1], bz = v[2];
       float bd = bx * dl.x + by * dl.y + bz * dl.z;
       for (int i0 = 0; i0 < s.nverts; i0 += 8) {
-        float x[8], y[8], z[8];
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(v + 3 * i0);
+        float f[24];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int i = i0 + k < s.nverts ? i0 + k : 0;
-          x[k] = v[3 * i]; y[k] = v[3 * i + 1]; z[k] = v[3 * i + 2];
+        for (int k = 0; k < 6; k++) {
+          const float4 t = q[k];
+          f[4 * k] = t.x; f[4 * k + 1] = t.y; f[4 * k + 2] = t.z; f[4 * k + 3] = t.w;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          float t = x[k] * dl.x + y[k] * dl.y + z[k] * dl.z;
+          float t = f[3 * k] * dl.x + f[3 * k + 1] * dl.y + f[3 * k + 2] * dl.z;
           bool g = t > bd;
           bd = g ? t : bd;
-          bx = g ? x[k] : bx; by = g ? y[k] : by; bz = g ? z[k] : bz;
+          bx = g ? f[3 * k] : bx; by = g ? f[3 * k + 1] : by; bz = g ? f[3 * k + 2] : bz;
         }
       }
       pl = f3{bx, by, bz};
@@ -405,6 +406,12 @@ MS_DEV void closest_on_triangle(f3 a, f3 b, f3 c, float w[3]) {
   w[1] = vb * den; w[2] = vc * den; w[0] = 1.f - w[1] - w[2];
 }
 
+#ifdef MSSIM_PHASE_CLOCKS
+__device__ unsigned g_mpr_hist[2][16];  // [0]: portal discovery iterations, [1]: refinement iterations (bins of 4)
+#define MPR_COUNT(k, it) atomicAdd(&g_mpr_hist[k][(it) / 4 < 15 ? (it) / 4 : 15], 1u)
+#else
+#define MPR_COUNT(k, it)
+#endif
 MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifold_t& m) {
   m.count = 0;
   const float margin = offset;
@@ -435,6 +442,7 @@ MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifo
     if (dot(cross(v1.v, v3.v), v0.v) < 0.f) { v2 = v3; dir = cross(v1.v - v0.v, v3.v - v0.v); continue; }
     if (dot(cross(v3.v, v2.v), v0.v) < 0.f) { v1 = v3; dir = cross(v3.v - v0.v, v2.v - v0.v); continue; }
     found = true;
+    MPR_COUNT(0, it);
     break;
   }
   if (!found) return;
@@ -449,6 +457,7 @@ MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifo
     float reach = dot(v4.v, dir);
     if (reach < 0.f && !hit) return;
     if (reach - dot(v3.v, dir) <= tol || it == 47) {
+      MPR_COUNT(1, it);
       if (!hit) return;
       break;
     }

@@ -1233,9 +1233,35 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   UP(dof_parent, n) UP(dof_type, n) UP(body_gravity, n) UP(tendon_dof, 2 * d->n_tendon) UP(link_body, d->n_link) UP(free_gravity, d->n_free)
   UP(dof_frame, 7 * n) UP(dof_axis, 3 * n) UP(dof_limit, 2 * n) UP(dof_drive, 4 * n) UP(dof_armature, n) UP(body_inertial, 10 * n)
   UP(tendon_param, 5 * d->n_tendon) UP(link_frame, 7 * d->n_link) UP(free_inertial, 10 * d->n_free) UP(free_damping, 2 * d->n_free)
-  UP(shape_type, ns) UP(shape_row, ns) UP(shape_hull, 2 * ns) UP(pair_shape, 2 * d->n_pair)
-  UP(shape_frame, 7 * ns) UP(shape_param, 4 * ns) UP(shape_material, 4 * ns) UP(shape_bound, 4 * ns) UP(hull_verts, 3 * d->n_hull_verts)
+  UP(shape_type, ns) UP(shape_row, ns) UP(pair_shape, 2 * d->n_pair)
+  UP(shape_frame, 7 * ns) UP(shape_param, 4 * ns) UP(shape_material, 4 * ns) UP(shape_bound, 4 * ns)
 #undef UP
+  {
+    // hull vertices are repacked so that every hull starts on a multiple of 8 vertices and is padded
+    // to a multiple of 8 with copies of its vertex 0: `support()` reads whole 8-vertex batches as six
+    // aligned 16-byte loads, and a copy of vertex 0 can never win its strict first-maximum scan
+    std::vector<float> hv;
+    std::vector<int32_t> sh(2 * (ns > 0 ? ns : 1), 0);
+    std::vector<std::pair<std::pair<int, int>, int>> seen;  // (start, count) -> new start
+    for (int s2 = 0; s2 < ns; s2++) {
+      const int st = d->shape_hull[2 * s2], cnt = d->shape_hull[2 * s2 + 1];
+      sh[2 * s2 + 1] = cnt;
+      if (cnt <= 0) continue;
+      int found = -1;
+      for (auto& kv : seen) if (kv.first.first == st && kv.first.second == cnt) found = kv.second;
+      if (found < 0) {
+        found = (int)(hv.size() / 3);
+        for (int i = 0; i < (cnt + 7) / 8 * 8; i++) {
+          const float* v = d->hull_verts + 3 * (size_t)(st + (i < cnt ? i : 0));
+          hv.push_back(v[0]); hv.push_back(v[1]); hv.push_back(v[2]);
+        }
+        seen.push_back({{st, cnt}, found});
+      }
+      sh[2 * s2] = found;
+    }
+    if (hv.size() / 3 >= (1u << 17)) { g_create_error = "too many hull vertices"; mssim_destroy(S); return 8; }
+    if ((rc = upload(S, sh.data(), sh.size(), &M.shape_hull)) || (rc = upload(S, hv.data(), hv.size(), &M.hull_verts))) { mssim_destroy(S); return rc; }
+  }
   if ((rc = upload(S, d->shape_body_kind, (size_t)ns, &M.shape_kind))) { mssim_destroy(S); return rc; }
   if ((rc = upload(S, d->shape_body_index, (size_t)ns, &M.shape_index))) { mssim_destroy(S); return rc; }
   if ((rc = upload(S, anc.data(), (size_t)n, &M.dof_anc))) { mssim_destroy(S); return rc; }
@@ -1542,10 +1568,17 @@ int mssim_overflow_count(mssim_handle h, void* stream) {
 // debug builds only (not part of include/mssim.h): cycles per phase of k_solve16 summed over blocks
 extern "C" int mssim_debug_phase_clocks(unsigned long long* out32, int reset) {
   if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_clk), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset < 0) return 0;
   if (reset) {
     unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
+}
+extern "C" int mssim_debug_mpr_hist(unsigned* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mpr_hist), 32 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
+}
+extern "C" int mssim_debug_phase_blocks(unsigned* out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_blk), (size_t)nblocks * 32 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
 }
 #endif

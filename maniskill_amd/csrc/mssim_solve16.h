@@ -52,7 +52,7 @@
 #define S16_ROWLEN 40          // J[16] W[16] | invd bpos bvel mu lam pair g g
 #define S16_CON_LDS 12         // contacts whose rows live in LDS; the rest go to the global scratch
 #define S16_REC (S16_CROW + 3 * S16_ROWLEN * S16_CON_LDS)  // contact records [MAXC][10]
-#define S16_REC_LEN 10         // n(3) x(3) sep pair bodies mu
+#define S16_REC_LEN 10         // n(3) x(3) sep pair lane-masks(A | B << 16) mu
 #define S16_ENV_FLOATS (S16_REC + S16_REC_LEN * MAXC)  // 2448 floats = 9792 B per env (== 16 mod 32 banks)
 #define S16_ROWS_GLB (3 * (MAXC - S16_CON_LDS))
 // narrowphase scratch (FUSED), overlays the union below the contact records
@@ -65,6 +65,7 @@
 // per-phase cycle deltas are kept in registers and flushed once at the end.
 #ifdef MSSIM_PHASE_CLOCKS
 __device__ unsigned long long g_phase_clk[32];
+__device__ unsigned g_phase_blk[2048 * 32];  // per-block deltas of the most recent launch
 #define PH_INIT                 \
   unsigned ph_d[32];            \
   _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) ph_d[i_] = 0u; \
@@ -80,6 +81,9 @@ __device__ unsigned long long g_phase_clk[32];
   if (threadIdx.x == 0) {                                                         \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++)                             \
       if (ph_d[i_]) atomicAdd(&g_phase_clk[i_], (unsigned long long)ph_d[i_]);    \
+    if (blockIdx.x < 2048) {                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) g_phase_blk[blockIdx.x * 32 + i_] = ph_d[i_]; \
+    }                                                                             \
   }
 #else
 #define PH_INIT
@@ -121,6 +125,13 @@ MS_DEV int pose_slot(int kind, int index) {
   if (kind == MSSIM_BODY_FREE) return S16_PT_FREE + index;
   if (kind == MSSIM_BODY_KIN) return S16_PT_KIN + index;
   return -1;
+}
+// lanes (velocity components) that move with the body in pose-table slot `sl`: the dofs on the path
+// to a link, the 6 components of a free body, nothing for fixed / kinematic bodies
+MS_DEV unsigned slot_lane_mask(const float* L, int sl, int n) {
+  if (sl >= S16_PT_LINK && sl < S16_PT_FREE) return reinterpret_cast<const unsigned*>(L)[S16_ANC + sl - S16_PT_LINK];
+  if (sl >= S16_PT_FREE && sl < S16_PT_KIN) return 0x3Fu << (n + 6 * (sl - S16_PT_FREE));
+  return 0u;
 }
 // world shape from the LDS shape table of one env
 MS_DEV shape_t shape_from_table(const DevModel& M, const float* t) {
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(Lg)[S16_NP_CNT + j];
           const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
           const float mu = 0.5f * (Lg[S16_NP_SHP + 16 * sa + 15] + Lg[S16_NP_SHP + 16 * sb + 15]);
-          const int bodies = (int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) |
-                             ((int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) << 8);
+          const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) - 1, n) |
+                                   (slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) - 1, n) << 16));
 #pragma unroll
           for (int k = 0; k < 4; k++)
             if (k < m.count && off + k < MAXC) {
@@ -419,7 +430,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
           if (act && live && c < 3) SOA(S.pair_imp, 3 * p + c) = 0.f;
           const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
-          const int bodies = (pose_slot(M.shape_kind[sa], M.shape_index[sa]) + 1) | ((pose_slot(M.shape_kind[sb], M.shape_index[sb]) + 1) << 8);
+          const int bodies = (int)(slot_lane_mask(L, pose_slot(M.shape_kind[sa], M.shape_index[sa]), n) |
+                                   (slot_lane_mask(L, pose_slot(M.shape_kind[sb], M.shape_index[sb]), n) << 16));
           const float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
           for (int k = 0; k < 4; k++) {
             const bool ck = act && k < cnt;
@@ -689,16 +701,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       const float mu = rec[9];
       const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
       const f3 t2 = cross(nrm, t1);
-      // does this lane's component move with side A / side B of the pair?
-      const int slA = (bodies & 0xFF) - 1, slB = ((bodies >> 8) & 0xFF) - 1;
-      float sgn = 0.f;
-      if (art) {
-        const bool mineA = slA >= S16_PT_LINK && slA < S16_PT_FREE && ((reinterpret_cast<const unsigned*>(L)[S16_ANC + slA - S16_PT_LINK] >> c) & 1u);
-        const bool mineB = slB >= S16_PT_LINK && slB < S16_PT_FREE && ((reinterpret_cast<const unsigned*>(L)[S16_ANC + slB - S16_PT_LINK] >> c) & 1u);
-        sgn = (mineA ? 1.f : 0.f) - (mineB ? 1.f : 0.f);
-      } else if (freel) {
-        sgn = (slA == S16_PT_FREE + fb_id ? 1.f : 0.f) - (slB == S16_PT_FREE + fb_id ? 1.f : 0.f);
-      }
+      // does this lane's component move with side A / side B of the pair? (lane masks in the record)
+      const float sgn = (float)((bodies >> c) & 1) - (float)((bodies >> (16 + c)) & 1);
       // per-lane geometric factor of this contact point
       f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
       if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         float J = 0.f;
         if (art) J = sgn * dot(d, col);
         else if (freel) J = sgn * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
-        J3[dk] = J;
+        J3[dk] = ck ? J : 0.f;  // padding slots (this env has fewer contacts than the wave's longest) become zero rows
       }
       __syncthreads();
       L[S16_VEC + 16 + c] = J3[0]; L[S16_VEC + 32 + c] = J3[1]; L[S16_VEC + 48 + c] = J3[2];
@@ -728,23 +732,26 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
       const float d0 = gsum16(J3[0] * W3[0]), d1 = gsum16(J3[1] * W3[1]), d2 = gsum16(J3[2] * W3[2]);
       const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
-      if (ck && (i < S16_CON_LDS || live)) {
+      // zero rows are written for the padding slots too: the solver sweeps max over the wave's envs and
+      // must read finite values there
+      if (i < S16_CON_LDS || live) {
         float* row0 = i < S16_CON_LDS ? (L + S16_CROW + 3 * S16_ROWLEN * i) : (grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
 #pragma unroll
         for (int dk = 0; dk < 3; dk++) {
           float* row = row0 + S16_ROWLEN * dk;
           const float diag = dk == 0 ? d0 : (dk == 1 ? d1 : d2);
+          const float invd = diag > 1e-12f ? 1.f / diag : 0.f;
           row[c] = J3[dk];
           row[16 + c] = W3[dk];
           if (c == 0) {
-            row[32] = diag > 1e-12f ? 1.f / diag : 0.f;
-            row[33] = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
-            row[34] = dk == 0 ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
-            row[35] = dk == 0 ? -1.f : mu;
+            row[32] = invd;
+            row[33] = (dk == 0 && ck) ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
+            row[34] = (dk == 0 && ck) ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
+            row[35] = ck ? (dk == 0 ? -1.f : mu) : 0.f;
             row[36] = 0.f;
             row[37] = __int_as_float(p);
-            row[38] = dk == 0 ? 0.f : (dk == 1 ? g10 : g20);
-            row[39] = dk == 2 ? g21 : 0.f;
+            row[38] = dk == 0 ? 0.f : (dk == 1 ? g10 : g20) * invd;  // cross terms scaled by this row's 1/diag
+            row[39] = dk == 2 ? g21 * invd : 0.f;
           }
         }
       }
@@ -768,10 +775,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
     // the dependent reduction chains.
     struct ConRec {
-      float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, g10, g20, g21;
+      float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, k10, k20, k21;
       float4 s0, s1, s2;
     };
-    auto con_load = [&](const float* row, ConRec& R) __attribute__((always_inline)) {
+    // padding slots (up to the wave's longest env) hold all-zero rows: every update below then
+    // reproduces the zero multipliers and moves nothing
+    auto con_load = [&](const float* row, ConRec& R, bool active) __attribute__((always_inline)) {
       R.J0 = row[c]; R.W0 = row[16 + c];
       R.J1 = row[S16_ROWLEN + c]; R.W1 = row[S16_ROWLEN + 16 + c];
       R.J2 = row[2 * S16_ROWLEN + c]; R.W2 = row[2 * S16_ROWLEN + 16 + c];
@@ -779,28 +788,28 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       R.s1 = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
       R.s2 = *reinterpret_cast<const float4*>(row + 2 * S16_ROWLEN + 32);
       R.lam0 = row[36]; R.lam1 = row[S16_ROWLEN + 36]; R.lam2 = row[2 * S16_ROWLEN + 36];
-      R.g10 = row[S16_ROWLEN + 38];
-      R.g20 = row[2 * S16_ROWLEN + 38]; R.g21 = row[2 * S16_ROWLEN + 39];
+      R.k10 = row[S16_ROWLEN + 38];
+      R.k20 = row[2 * S16_ROWLEN + 38]; R.k21 = row[2 * S16_ROWLEN + 39];
+      (void)active;  // padding slots hold zero rows (row build), nothing to mask here
     };
+    // The dependent chain per contact is jv0 -> nl0 -> nl1 -> nl2 -> v; everything that does not
+    // depend on the previous multiplier of the block (a1, a2, the first two W updates) is computed
+    // off the chain. k10 = g10 / d1, k20 = g20 / d2, k21 = g21 / d2 (Delassus cross terms).
     auto con_apply = [&](const ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
       const float jv0 = gsum16(R.J0 * v_c);
       const float jv1 = gsum16(R.J1 * v_c);
       const float jv2 = gsum16(R.J2 * v_c);
-      float nl0 = fmaxf(R.lam0 - (jv0 + (use_bias ? R.s0.y : R.s0.z)) * R.s0.x, 0.f);
-      nl0 = (active && R.s0.x > 0.f) ? nl0 : R.lam0;
+      const float a1 = fmaf(-jv1, R.s1.x, R.lam1);
+      const float a2 = fmaf(-jv2, R.s2.x, R.lam2);
+      const float nl0 = fmaxf(fmaf(-(jv0 + (use_bias ? R.s0.y : R.s0.z)), R.s0.x, R.lam0), 0.f);
       const float dl0 = nl0 - R.lam0;
-      const float h1 = R.s1.w * nl0;
-      float nl1 = fminf(fmaxf(R.lam1 - (jv1 + R.g10 * dl0) * R.s1.x, -h1), h1);
-      nl1 = (active && R.s1.x > 0.f) ? nl1 : R.lam1;
+      const float h1 = R.s1.w * nl0, h2 = R.s2.w * nl0;
+      const float nl1 = fminf(fmaxf(fmaf(-R.k10, dl0, a1), -h1), h1);
       const float dl1 = nl1 - R.lam1;
-      const float h2 = R.s2.w * nl0;
-      float nl2 = fminf(fmaxf(R.lam2 - (jv2 + R.g20 * dl0 + R.g21 * dl1) * R.s2.x, -h2), h2);
-      nl2 = (active && R.s2.x > 0.f) ? nl2 : R.lam2;
+      const float nl2 = fminf(fmaxf(fmaf(-R.k21, dl1, fmaf(-R.k20, dl0, a2)), -h2), h2);
       const float dl2 = nl2 - R.lam2;
-      if (active) {
-        v_c = fmaf(R.W0, dl0, fmaf(R.W1, dl1, fmaf(R.W2, dl2, v_c)));
-        if (c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
-      }
+      v_c = fmaf(R.W2, dl2, fmaf(R.W1, dl1, fmaf(R.W0, dl0, v_c)));
+      if (active && c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
     };
 #ifdef EXP_ITERS
     const int n_iters = EXP_ITERS;
@@ -860,25 +869,32 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       PH(18);
       if (max_clds > 0) {
         ConRec A, B;
-        con_load(crow, A);
+        con_load(crow, A, 0 < nc_lds);
         int k = 0;
         while (true) {
           // next block is loaded before the dependent chain of the current one (index clamped: in range)
-          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), B);
+          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), B, k + 1 < nc_lds);
           con_apply(A, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
           if (++k >= max_clds) break;
-          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), A);
+          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), A, k + 1 < nc_lds);
           con_apply(B, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
           if (++k >= max_clds) break;
         }
       }
       PH(19);
-      for (int k = 0; k < max_cglb; k++) {
-        const bool active = k < nc_glb;
-        float* row = grow + (size_t)(3 * S16_ROWLEN) * (active ? k : 0);
-        ConRec A;
-        con_load(row, A);
-        con_apply(A, row, active && live, use_bias);
+      if (max_cglb > 0) {
+        // contacts beyond the LDS capacity stream from the per-env global scratch, one block ahead
+        ConRec A, B;
+        con_load(grow, A, 0 < nc_glb);
+        int k = 0;
+        while (true) {
+          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), B, k + 1 < nc_glb);
+          con_apply(A, grow + (size_t)(3 * S16_ROWLEN) * k, k < nc_glb && live, use_bias);
+          if (++k >= max_cglb) break;
+          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), A, k + 1 < nc_glb);
+          con_apply(B, grow + (size_t)(3 * S16_ROWLEN) * k, k < nc_glb && live, use_bias);
+          if (++k >= max_cglb) break;
+        }
       }
       PH(20);
     }

@@ -43,3 +43,23 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
         if not buf[i]:
             continue
         print(f"  {nm:14s} {buf[i] / launches / blocks:9.0f} cycles  {100.0 * buf[i] / tot:5.1f} %")
+
+# slowest blocks of the last launch
+import numpy as np
+nb = min(2048, 8 * (((N + 3) // 4 + 7) // 8))
+arr = (ctypes.c_uint * (nb * 32))()
+dbg.mssim_debug_phase_blocks(arr, nb)
+a = np.frombuffer(arr, dtype=np.uint32).reshape(nb, 32).astype(np.float64)
+cyc = a[:, :26].sum(1)
+order = np.argsort(-cyc)
+print(f"last launch: block cycles mean {cyc.mean():.0f}  p50 {np.median(cyc):.0f}  p99 {np.percentile(cyc, 99):.0f}  max {cyc.max():.0f}")
+for b in order[:3]:
+    print(f" block {b}: total {cyc[b]:.0f}; contacts(4 envs, summed over substeps) {a[b, 30]:.0f}, max-per-env sum {a[b, 29]:.0f}, survivor tasks {a[b, 26]:.0f}, box-box {a[b, 28]:.0f}, plane {a[b, 27]:.0f}")
+    for i, nm in enumerate(names):
+        if i < 26 and a[b, i] > 0.01 * cyc[b]:
+            print(f"    {nm:40s} {a[b, i]:9.0f}  {100 * a[b, i] / cyc[b]:5.1f} %")
+
+h = (ctypes.c_uint * 32)()
+dbg.mssim_debug_mpr_hist(h)
+print("MPR portal-discovery iterations (bins of 4):", list(h)[:16])
+print("MPR refinement iterations       (bins of 4):", list(h)[16:])
