@@ -374,11 +374,17 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
 struct mvert {
   f3 v, a, b;
 };
-MS_DEV mvert msupport(const shape_t& A, const shape_t& B, f3 d, float margin) {
+// support-function policy of the MPR: SupDirect evaluates `support()` per lane; the fused step kernel
+// plugs in a 16-lane cooperative hull scan (mssim_solve16.h) with the same first-maximum result
+struct SupDirect {
+  MS_DEV f3 operator()(int /*which*/, const shape_t& s, f3 d) const { return support(s, d); }
+};
+template <class SUP>
+MS_DEV mvert msupport(const SUP& sup, const shape_t& A, const shape_t& B, f3 d, float margin) {
   mvert r;
   f3 dn = normalized(d);
-  r.a = support(A, dn);
-  r.b = support(B, -dn);
+  r.a = sup(0, A, dn);
+  r.b = sup(1, B, -dn);
   r.v = r.a + dn * margin - r.b;
   return r;
 }
@@ -412,7 +418,8 @@ __device__ unsigned g_mpr_hist[2][16];  // [0]: portal discovery iterations, [1]
 #else
 #define MPR_COUNT(k, it)
 #endif
-MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifold_t& m) {
+template <class SUP>
+MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, manifold_t& m, const SUP& sup) {
   m.count = 0;
   const float margin = offset;
   const float tol = 1e-5f;
@@ -420,7 +427,7 @@ MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifo
   v0.a = A.c; v0.b = B.c; v0.v = A.c - B.c;
   if (dot(v0.v, v0.v) < 1e-12f) v0.v = f3{1e-5f, 0.f, 0.f};
   f3 dir = -v0.v;
-  v1 = msupport(A, B, dir, margin);
+  v1 = msupport(sup, A, B, dir, margin);
   if (dot(v1.v, dir) <= 0.f) return;
   dir = cross(v1.v, v0.v);
   if (dot(dir, dir) < 1e-14f) {
@@ -431,13 +438,13 @@ MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifo
     m.x[0] = (v1.a + v1.b) * 0.5f;
     return;
   }
-  v2 = msupport(A, B, dir, margin);
+  v2 = msupport(sup, A, B, dir, margin);
   if (dot(v2.v, dir) <= 0.f) return;
   dir = cross(v1.v - v0.v, v2.v - v0.v);
   if (dot(dir, v0.v) > 0.f) { mvert t = v1; v1 = v2; v2 = t; dir = -dir; }
   bool found = false;
   for (int it = 0; it < 32; it++) {
-    v3 = msupport(A, B, dir, margin);
+    v3 = msupport(sup, A, B, dir, margin);
     if (dot(v3.v, dir) <= 0.f) return;
     if (dot(cross(v1.v, v3.v), v0.v) < 0.f) { v2 = v3; dir = cross(v1.v - v0.v, v3.v - v0.v); continue; }
     if (dot(cross(v3.v, v2.v), v0.v) < 0.f) { v1 = v3; dir = cross(v3.v - v0.v, v2.v - v0.v); continue; }
@@ -453,7 +460,7 @@ MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifo
     if (dl < 1e-14f) break;
     dir = dir * (1.f / dl);
     if (dot(dir, v1.v) >= 0.f) hit = true;
-    v4 = msupport(A, B, dir, margin);
+    v4 = msupport(sup, A, B, dir, margin);
     float reach = dot(v4.v, dir);
     if (reach < 0.f && !hit) return;
     if (reach - dot(v3.v, dir) <= tol || it == 47) {
@@ -481,3 +488,4 @@ MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifo
   f3 pb = v1.b * w[0] + v2.b * w[1] + v3.b * w[2];
   m.x[0] = (pa + pb) * 0.5f;
 }
+MS_DEV void collide_mpr(const shape_t& A, const shape_t& B, float offset, manifold_t& m) { collide_mpr_t(A, B, offset, m, SupDirect{}); }

@@ -146,6 +146,52 @@ MS_DEV shape_t shape_from_table(const DevModel& M, const float* t) {
   return sh;
 }
 
+// MPR support policy of a 16-lane group working on ONE pair: lane c keeps hull vertices c, c + 16,
+// c + 32, c + 48 of each convex shape in registers for the whole task; a support query is 4 dot
+// products per lane and a DPP row all-reduce of (value, index, point) with "larger value, then lower
+// index" -- exactly the first maximum of the sequential scan, identical in every lane of the group.
+struct SupCoop16 {
+  f3 va[4], vb[4];
+  int c;
+  MS_DEV void load(int which, const shape_t& s) {
+    f3* dst = which == 0 ? va : vb;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      dst[k] = f3{0, 0, 0};
+      if (s.type == SH_CONVEX) {
+        const int i = c + 16 * k < s.nverts ? c + 16 * k : 0;
+        dst[k] = f3{s.verts[3 * i], s.verts[3 * i + 1], s.verts[3 * i + 2]};
+      }
+    }
+  }
+  template <int CTRL>
+  static MS_DEV void step(float& t, int& i, f3& p) {
+    const float ot = dpp_f<CTRL>(t);
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, false);
+    const f3 op = f3{dpp_f<CTRL>(p.x), dpp_f<CTRL>(p.y), dpp_f<CTRL>(p.z)};
+    const bool take = ot > t || (ot == t && oi < i);
+    t = take ? ot : t; i = take ? oi : i;
+    p.x = take ? op.x : p.x; p.y = take ? op.y : p.y; p.z = take ? op.z : p.z;
+  }
+  MS_DEV f3 operator()(int which, const shape_t& s, f3 d) const {
+    if (s.type != SH_CONVEX) return support(s, d);
+    const f3* v = which == 0 ? va : vb;
+    const f3 dl = mtmulv(s.rot, d);
+    float t = dot(v[0], dl);
+    int i = c;
+    f3 p = v[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const float tk = dot(v[k], dl);
+      const bool g = tk > t && c + 16 * k < s.nverts;
+      t = g ? tk : t; i = g ? c + 16 * k : i; p = g ? v[k] : p;
+    }
+    if (c >= s.nverts) { t = -3e38f; i = 1 << 20; }
+    step<0x128>(t, i, p); step<0x124>(t, i, p); step<0x122>(t, i, p); step<0x121>(t, i, p);
+    return s.c + mmulv(s.rot, p);
+  }
+};
+
 template <bool FUSED>
 __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S, int n_sub) {
   __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
@@ -356,7 +402,47 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       nh = nh < S16_MAX_HIT ? nh : S16_MAX_HIT;
       __syncthreads();
       PH(23);
-      // ---- manifolds: all surviving (env, pair) tasks of the wave spread over the 64 lanes
+      // ---- manifolds, part 1: generic convex pairs (MPR), one pair at a time per env with the 16 lanes
+      // of the group sharing the hull scans. The single contact of task number t of this env stays
+      // in the registers of lane t % 16 (slot t / 16) until the record offsets are known.
+      float mres[2][7];
+      int midx[2] = {-1, -1};
+      {
+        int nm = 0;
+        for (int idx = 0; idx < nh; idx++) {
+          const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
+          const float* ta_ = L + S16_NP_SHP + 16 * ((pk >> 16) & 0xFF);
+          const float* tb_ = L + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF);
+          const int ta = (int)(__float_as_uint(ta_[14]) & 7u), tb = (int)(__float_as_uint(tb_[14]) & 7u);
+          if (ta == SH_PLANE || (ta == SH_BOX && tb == SH_BOX)) continue;
+          const shape_t A = shape_from_table(M, ta_);
+          const shape_t B = shape_from_table(M, tb_);
+          SupCoop16 sup;
+          sup.c = c;
+          sup.load(0, A);
+          sup.load(1, B);
+          manifold_t m;
+          collide_mpr_t(A, B, M.contact_offset, m, sup);
+          if (c == 0) reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = m.count;
+          if (m.count > 0) {
+            if (nm >= 32) { if (live && c == 0) S.overflow[e] = 1; }
+            else if ((nm & 15) == c) {
+#pragma unroll
+              for (int sl = 0; sl < 2; sl++)
+                if ((nm >> 4) == sl) {
+                  mres[sl][0] = m.n.x; mres[sl][1] = m.n.y; mres[sl][2] = m.n.z;
+                  mres[sl][3] = m.x[0].x; mres[sl][4] = m.x[0].y; mres[sl][5] = m.x[0].z; mres[sl][6] = m.sep[0];
+                  midx[sl] = idx;
+                }
+            }
+            nm++;
+          }
+        }
+      }
+      __syncthreads();
+      PH(25);
+      // ---- manifolds, part 2: plane and box-box pairs, all such (env, pair) tasks of the wave spread
+      // over the 64 lanes
       int cum[S16_ENVS_PER_BLOCK + 1];
       cum[0] = 0;
 #pragma unroll
@@ -380,10 +466,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF));
           PH_ADD(27, __popcll(__ballot(A.type == SH_PLANE)));
           PH_ADD(28, __popcll(__ballot(A.type == SH_BOX && B.type == SH_BOX)));
-          if (A.type == SH_PLANE) collide_plane(A, B, M.contact_offset, m);
-          else if (A.type == SH_BOX && B.type == SH_BOX) collide_box_box<16>(A, B, M.contact_offset, m, sm + g * S16_ENV_FLOATS + S16_NP_SCR + c);
-          else collide_mpr(A, B, M.contact_offset, m);
-          reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
+          PH(10);
+          const bool is_plane = A.type == SH_PLANE, is_bb = A.type == SH_BOX && B.type == SH_BOX;
+          if (is_plane) collide_plane(A, B, M.contact_offset, m);
+          PH(11);
+          if (is_bb) collide_box_box<16>(A, B, M.contact_offset, m, sm + g * S16_ENV_FLOATS + S16_NP_SCR + c);
+          PH(12);
+          if (is_plane || is_bb) reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
         }
         __syncthreads();
         if (has && m.count > 0) {
@@ -407,6 +496,27 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
         __syncthreads();
       }
+      // the staged MPR contacts go to their slots (all manifold sizes are known now)
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        if (midx[sl] >= 0) {
+          int off = 0;
+          for (int j = 0; j < midx[sl]; j++) off += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
+          if (off < MAXC) {
+            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + midx[sl]];
+            const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
+            float* r = L + S16_REC + S16_REC_LEN * off;
+#pragma unroll
+            for (int k = 0; k < 6; k++) r[k] = mres[sl][k];
+            r[6] = mres[sl][6] - M.rest_offset;
+            r[7] = __int_as_float(pk & 0xFFFF);
+            r[8] = __int_as_float((int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) - 1, n) |
+                                        (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) - 1, n) << 16)));
+            r[9] = 0.5f * (L[S16_NP_SHP + 16 * sa + 15] + L[S16_NP_SHP + 16 * sb + 15]);
+          }
+        }
+      }
+      __syncthreads();
       PH(24);
       {
         int tot = 0;

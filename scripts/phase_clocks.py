@@ -24,7 +24,7 @@ env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
 buf = (ctypes.c_ulonglong * 32)()
 names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
-         "dyn: S stage", "dyn: V sum", "dyn: Ab sum", "dyn: inertia/force", "dyn: composite sum", "dyn: M columns",
+         "dyn: S stage", "dyn: V sum", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: MPR",
          "", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
          "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: manifolds", "np: count",
          "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
