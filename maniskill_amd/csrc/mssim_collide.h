@@ -35,6 +35,13 @@ struct manifold_t {
   float sep[4];
 };
 
+MS_DEV void manifold_clear(manifold_t& m) {
+  m.count = 0;
+  m.n = f3{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; k++) { m.x[k] = f3{0.f, 0.f, 0.f}; m.sep[k] = 0.f; }
+}
+
 MS_DEV f3 support(const shape_t& s, f3 d) {
   f3 dl = mtmulv(s.rot, d);
   f3 pl;
@@ -97,16 +104,20 @@ MS_DEV void keep4_insert(manifold_t& m, f3 p, float s) {
     if (k < m.count && s < m.sep[k]) pos = k;
   if (pos >= 4) return;
 #pragma unroll
-  for (int k = 3; k > 0; k--)
-    if (k > pos && k <= m.count) { m.x[k] = m.x[k - 1]; m.sep[k] = m.sep[k - 1]; }
+  for (int k = 3; k > 0; k--) {  // value selects: conditional struct stores would put `m` into scratch memory
+    const bool g = k > pos && k <= m.count;
+    m.x[k] = sel3(g, m.x[k - 1], m.x[k]); m.sep[k] = g ? m.sep[k - 1] : m.sep[k];
+  }
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (k == pos) { m.x[k] = p; m.sep[k] = s; }
+  for (int k = 0; k < 4; k++) {
+    const bool g = k == pos;
+    m.x[k] = sel3(g, p, m.x[k]); m.sep[k] = g ? s : m.sep[k];
+  }
   m.count = m.count < 4 ? m.count + 1 : 4;
 }
 
 MS_DEV void collide_plane(const shape_t& pl, const shape_t& b, float offset, manifold_t& m) {
-  m.count = 0;
+  manifold_clear(m);
   f3 np = mcol(pl.rot, 0);
   m.n = -np;
   auto add = [&](f3 p, float radius) {
@@ -163,7 +174,7 @@ MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
     if (i < n) {
       const bool wrap = !(i + 1 < n);
       const f3 a = P[i];
-      const f3 b = (i == 7 || wrap) ? P[0] : P[(i + 1) & 7];
+      const f3 b = sel3(i == 7 || wrap, P[0], P[(i + 1) & 7]);
       const float da = d[i], db = (i == 7 || wrap) ? d[0] : d[(i + 1) & 7];
       if (da <= 0.f && m < 8) out.put(m++, a);
       if (((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) && m < 8) {
@@ -177,7 +188,7 @@ MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
 
 template <int STRIDE = 64>
 MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, manifold_t& m, float* lds) {
-  m.count = 0;
+  manifold_clear(m);
   const float eps = 1e-6f;
   f3 a[3] = {mcol(A.rot, 0), mcol(A.rot, 1), mcol(A.rot, 2)};
   f3 b[3] = {mcol(B.rot, 0), mcol(B.rot, 1), mcol(B.rot, 2)};
@@ -312,8 +323,11 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   if (n <= 4) {
     m.count = n;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (k < n) { m.x[k] = Rb.get(k); m.sep[k] = seps[(size_t)k * STRIDE]; }
+    for (int k = 0; k < 4; k++) {
+      const f3 pk = Rb.get(k);
+      const float sk = seps[(size_t)k * STRIDE];
+      m.x[k] = sel3(k < n, pk, f3{0.f, 0.f, 0.f}); m.sep[k] = k < n ? sk : 0.f;
+    }
     return;
   }
   // more than 4 candidates: deepest, farthest from it, then the two of largest area on either side
@@ -326,15 +340,18 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   float s0 = sp[0];
   f3 p0 = R[0];
 #pragma unroll
-  for (int i = 1; i < 8; i++)
-    if (i < n && sp[i] < s0) { s0 = sp[i]; i0 = i; p0 = R[i]; }
+  for (int i = 1; i < 8; i++) {
+    const bool g = i < n && sp[i] < s0;
+    s0 = g ? sp[i] : s0; i0 = g ? i : i0; p0 = sel3(g, R[i], p0);
+  }
   int i1 = -1; float best = -1.f;
   f3 p1 = p0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    if (i < n && i != i0) {
+    {
       f3 d = R[i] - p0; float v = dot(d, d);
-      if (v > best) { best = v; i1 = i; p1 = R[i]; }
+      const bool g = i < n && i != i0 && v > best;
+      best = g ? v : best; i1 = g ? i : i1; p1 = sel3(g, R[i], p1);
     }
   }
   f3 e = p1 - p0;
@@ -363,8 +380,10 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
       f3 p = Rb.get(idx[k]);
       float s = seps[(size_t)idx[k] * STRIDE];
 #pragma unroll
-      for (int t = 0; t < 4; t++)
-        if (t == m.count) { m.x[t] = p; m.sep[t] = s; }
+      for (int t = 0; t < 4; t++) {
+        const bool g = t == m.count;
+        m.x[t] = sel3(g, p, m.x[t]); m.sep[t] = g ? s : m.sep[t];
+      }
       m.count++;
     }
 }
@@ -420,7 +439,7 @@ __device__ unsigned g_mpr_hist[2][16];  // [0]: portal discovery iterations, [1]
 #endif
 template <class SUP>
 MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, manifold_t& m, const SUP& sup) {
-  m.count = 0;
+  manifold_clear(m);
   const float margin = offset;
   const float tol = 1e-5f;
   mvert v0, v1, v2, v3, v4;

@@ -24,6 +24,9 @@ MS_DEV f3 normalized(f3 a) {
   return n > 0.f ? a * (1.f / n) : f3{1.f, 0.f, 0.f};
 }
 MS_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+// value select. `g ? a : b` on struct lvalues can be lowered to a select of ADDRESSES, which forces
+// register arrays into scratch memory; selecting component by component keeps everything in VGPRs.
+MS_DEV f3 sel3(bool g, f3 a, f3 b) { return f3{g ? a.x : b.x, g ? a.y : b.y, g ? a.z : b.z}; }
 
 struct q4 {
   float w, x, y, z;

@@ -1320,7 +1320,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   // cooperative 16-lanes-per-env kernel when every velocity component fits one DPP row
   S->coop = (n + 6 * d->n_free <= S16_LANES);
   // whole control step in one launch (in-kernel narrowphase) when the scene fits the LDS tables
-  S->fused = S->coop && d->n_free <= S16_MAX_FREE && d->n_kin <= S16_MAX_KIN && ns <= S16_MAX_SHAPE && d->n_pair < 65536 && d->n_pair > 0;
+  S->fused = S->coop && d->n_free <= S16_MAX_FREE && d->n_kin <= S16_MAX_KIN && ns <= S16_MAX_SHAPE && d->n_pair <= 56 * 16 && d->n_pair > 0;
   if (const char* ev = getenv("MSSIM_SOLVER")) {
     if (!strcmp(ev, "lane")) S->coop = S->fused = false;
     if (!strcmp(ev, "split")) S->fused = false;

@@ -59,7 +59,7 @@
 #define S16_NP_SHP (S16_U)        // [32][16] world shape table
 #define S16_NP_HIT (S16_U + 512)  // [64] surviving pairs: pair | sa << 16 | sb << 24
 #define S16_NP_CNT (S16_U + 576)  // [64] manifold sizes
-#define S16_NP_SCR (S16_U + 640)  // [56][16] box-box clip scratch of the group's 16 lanes
+#define S16_NP_SCR (S16_U + 640)  // [56][16] box-box clip scratch of the group's 16 lanes | pair table during the cull (<= 896 pairs)
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
@@ -153,8 +153,7 @@ MS_DEV shape_t shape_from_table(const DevModel& M, const float* t) {
 struct SupCoop16 {
   f3 va[4], vb[4];
   int c;
-  MS_DEV void load(int which, const shape_t& s) {
-    f3* dst = which == 0 ? va : vb;
+  static MS_DEV void load_one(f3 (&dst)[4], const shape_t& s, int c) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       dst[k] = f3{0, 0, 0};
@@ -173,9 +172,7 @@ struct SupCoop16 {
     t = take ? ot : t; i = take ? oi : i;
     p.x = take ? op.x : p.x; p.y = take ? op.y : p.y; p.z = take ? op.z : p.z;
   }
-  MS_DEV f3 operator()(int which, const shape_t& s, f3 d) const {
-    if (s.type != SH_CONVEX) return support(s, d);
-    const f3* v = which == 0 ? va : vb;
+  static MS_DEV f3 scan(const f3 (&v)[4], const shape_t& s, f3 d, int c) {
     const f3 dl = mtmulv(s.rot, d);
     float t = dot(v[0], dl);
     int i = c;
@@ -184,11 +181,17 @@ struct SupCoop16 {
     for (int k = 1; k < 4; k++) {
       const float tk = dot(v[k], dl);
       const bool g = tk > t && c + 16 * k < s.nverts;
-      t = g ? tk : t; i = g ? c + 16 * k : i; p = g ? v[k] : p;
+      t = g ? tk : t; i = g ? c + 16 * k : i; p = sel3(g, v[k], p);
     }
     if (c >= s.nverts) { t = -3e38f; i = 1 << 20; }
     step<0x128>(t, i, p); step<0x124>(t, i, p); step<0x122>(t, i, p); step<0x121>(t, i, p);
     return s.c + mmulv(s.rot, p);
+  }
+  // (no pointer select between the two arrays: that would force them out of registers)
+  MS_DEV f3 operator()(int which, const shape_t& s, f3 d) const {
+    if (s.type != SH_CONVEX) return support(s, d);
+    if (which == 0) return scan(va, s, d, c);
+    return scan(vb, s, d, c);
   }
 };
 
@@ -216,100 +219,33 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   if (!FUSED) n_sub = 1;
 
   PH_INIT
-  // ---------------------------------------------------------------- state (loaded once)
+  // ---------------------------------------------------------------- carried state (loaded once)
+  // Only what changes over the step stays in registers across the substeps (q, qd, body pose, joint
+  // axis / anchor, free-body velocity, applied force); per-env constants are (re)loaded inside the
+  // loop after the narrowphase so that they are not live -- and spilled -- while it runs.
   const pose_t root = pose_soa(S.root, 0, N, e);
   const f3 O = root.p;
-  float q_c = 0.f, qd_c = 0.f, qt_c = 0.f, qdt_c = 0.f, qf_c = 0.f;
+  float q_c = 0.f, qd_c = 0.f;
   pose_t bp_c = root;
   f3 aw_c = f3{0, 0, 0}, an_c = f3{0, 0, 0};
-  bool rev_c = false;
-  unsigned anc_c = 0u;
-  float kp0 = 0.f, kd0 = 0.f, fmax = 3e38f, arm = 0.f, lo_c = -3e38f, hi_c = 3e38f;
-  float inert[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  bool grav_c = false, accel_mode = false;
-  pose_t JF_c = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};  // joint frame in the parent body frame
-  f3 al_c = f3{0, 0, 0};                            // joint axis in the joint frame
-  int par_c = -1;
   if (art) {
-    JF_c = pose_from(M.dof_frame + 7 * c);
-    al_c = f3{M.dof_axis[3 * c], M.dof_axis[3 * c + 1], M.dof_axis[3 * c + 2]};
-    par_c = M.dof_parent[c];
-    q_c = SOA(S.q, c); qd_c = SOA(S.qd, c); qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
+    q_c = SOA(S.q, c); qd_c = SOA(S.qd, c);
     bp_c = pose_soa(S.bodypose, 7 * c, N, e);
     aw_c = f3{SOA(S.bodyaux, 6 * c), SOA(S.bodyaux, 6 * c + 1), SOA(S.bodyaux, 6 * c + 2)};
     an_c = f3{SOA(S.bodyaux, 6 * c + 3), SOA(S.bodyaux, 6 * c + 4), SOA(S.bodyaux, 6 * c + 5)};
-    rev_c = M.dof_type[c] == MSSIM_JOINT_REVOLUTE;
-    anc_c = M.dof_anc[c];
-    kp0 = M.dof_drive[4 * c]; kd0 = M.dof_drive[4 * c + 1]; fmax = M.dof_drive[4 * c + 2];
-    accel_mode = (int)M.dof_drive[4 * c + 3] == MSSIM_DRIVE_ACCELERATION;
-    arm = M.dof_armature[c];
-    lo_c = M.dof_limit[2 * c]; hi_c = M.dof_limit[2 * c + 1];
-#pragma unroll
-    for (int k = 0; k < 10; k++) inert[k] = M.body_inertial[10 * c + k];
-    grav_c = M.body_gravity[c] != 0;
   }
   const unsigned self_c = art ? (1u << c) : 0u;
   float qacc_c = 0.f;
   // free-body velocity component of this lane; pose and the external force live in the pose table / registers
   float vfree_c = freel ? SOA(S.free_s, 13 * fb_id + 7 + fk) : 0.f;
   float fforce_c = (freel && fk < 3) ? SOA(S.free_force, 3 * fb_id + fk) : 0.f;
-  float fin[S16_MAX_FREE][10];
-#pragma unroll
-  for (int b = 0; b < S16_MAX_FREE; b++) {
-#pragma unroll
-    for (int k = 0; k < 10; k++) fin[b][k] = 0.f;
-    if (b < nf) free_inertial_of(M, N, b, e, fin[b]);
-  }
   // pose table: root, links, free bodies, kinematic bodies
   {
-    reinterpret_cast<unsigned*>(L)[S16_ANC + c] = anc_c | self_c;
+    reinterpret_cast<unsigned*>(L)[S16_ANC + c] = (art ? M.dof_anc[c] : 0u) | self_c;
     if (c == 0) lds_pose_store(L + S16_PT, root);
     if (art) lds_pose_store(L + S16_BP + 7 * c, bp_c);
     if (c < nf) lds_pose_store(L + S16_PT + 7 * (S16_PT_FREE + c), pose_soa(S.free_s, 13 * c, N, e));
     if (FUSED && c < M.n_kin) lds_pose_store(L + S16_PT + 7 * (S16_PT_KIN + c), pose_soa(S.kin, 7 * c, N, e));
-  }
-  // FUSED: shape-local data of shapes c and c + 16 (constant over the step)
-  pose_t shF[2];
-  float shP[2][3], shBr[2], shMu[2];
-  f3 shBc[2];
-  unsigned shPk[2];
-  int shSlot[2];
-  if (FUSED) {
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int s = c + 16 * k;
-      shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
-      shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
-      if (s < M.n_shape) {
-        const int slot = M.shape_env_slot[s];
-        if (slot < 0) {
-          shF[k] = pose_from(M.shape_frame + 7 * s);
-          shP[k][0] = M.shape_param[4 * s]; shP[k][1] = M.shape_param[4 * s + 1]; shP[k][2] = M.shape_param[4 * s + 2];
-          shBc[k] = f3{M.shape_center[3 * s], M.shape_center[3 * s + 1], M.shape_center[3 * s + 2]};
-          shBr[k] = M.shape_bound[4 * s + 3];
-        } else {
-          shF[k] = pose_soa(M.env_shape_frame, 7 * slot, N, e);
-          const float* pp = M.env_shape_param + (size_t)(4 * slot) * N + e;
-          shP[k][0] = pp[0]; shP[k][1] = pp[(size_t)N]; shP[k][2] = pp[2 * (size_t)N];
-          const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
-          shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
-          shBr[k] = bb[3 * (size_t)N];
-        }
-        shMu[k] = M.shape_material[4 * s + 1];
-        shSlot[k] = pose_slot(M.shape_kind[s], M.shape_index[s]);
-        shPk[k] = (unsigned)M.shape_type[s] | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
-      }
-    }
-  }
-  // FUSED: the shape pair this lane tests in cull round r (pair 16 r + c), packed sa | sb << 8
-  constexpr int PR = 12;
-  int cullp[PR];
-  if (FUSED) {
-#pragma unroll
-    for (int r = 0; r < PR; r++) {
-      const int p = 16 * r + c;
-      cullp[r] = p < M.n_pair ? (M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8)) : -1;
-    }
   }
   __syncthreads();
   PH(0);
@@ -325,6 +261,46 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // ================================================================ contacts -> LDS records
     int nc = 0;
     if (FUSED) {
+      // shape-local data of shapes c and c + 16 and the cull pairs of this lane (model constants,
+      // fetched per substep rather than held in registers over the whole step)
+      pose_t shF[2];
+      float shP[2][3], shBr[2], shMu[2];
+      f3 shBc[2];
+      unsigned shPk[2];
+      int shSlot[2];
+      {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int s = c + 16 * k;
+          shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
+          shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
+          if (s < M.n_shape) {
+            const int slot = M.shape_env_slot[s];
+            if (slot < 0) {
+              shF[k] = pose_from(M.shape_frame + 7 * s);
+              shP[k][0] = M.shape_param[4 * s]; shP[k][1] = M.shape_param[4 * s + 1]; shP[k][2] = M.shape_param[4 * s + 2];
+              shBc[k] = f3{M.shape_center[3 * s], M.shape_center[3 * s + 1], M.shape_center[3 * s + 2]};
+              shBr[k] = M.shape_bound[4 * s + 3];
+            } else {
+              shF[k] = pose_soa(M.env_shape_frame, 7 * slot, N, e);
+              const float* pp = M.env_shape_param + (size_t)(4 * slot) * N + e;
+              shP[k][0] = pp[0]; shP[k][1] = pp[(size_t)N]; shP[k][2] = pp[2 * (size_t)N];
+              const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
+              shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
+              shBr[k] = bb[3 * (size_t)N];
+            }
+            shMu[k] = M.shape_material[4 * s + 1];
+            shSlot[k] = pose_slot(M.shape_kind[s], M.shape_index[s]);
+            shPk[k] = (unsigned)M.shape_type[s] | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
+          }
+        }
+      }
+      // the pair table (sa | sb << 8 per pair) is staged in this env's clip-scratch area for the cull
+      // rounds (the area is only needed again by the box-box manifolds afterwards)
+      {
+        int* const lp = reinterpret_cast<int*>(L + S16_NP_SCR);
+        for (int p = c; p < M.n_pair; p += 16) lp[p] = M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8);
+      }
       // ---- world shape table of this env
 #pragma unroll
       for (int k = 0; k < 2; k++) {
@@ -389,14 +365,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
         nh += __popc(m16);
       };
-#pragma unroll
-      for (int r = 0; r < PR; r++) {
-        if (16 * r >= M.n_pair) break;
-        cull_round(16 * r + c, cullp[r]);
-      }
-      for (int base = 16 * PR; base < M.n_pair; base += 16) {
+#pragma unroll 1
+      for (int base = 0; base < M.n_pair; base += 16) {
         const int p = base + c;
-        cull_round(p, p < M.n_pair ? (M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8)) : -1);
+        cull_round(p, p < M.n_pair ? reinterpret_cast<const int*>(L + S16_NP_SCR)[p] : -1);
       }
       if (__any(hit_over) && hit_over && live) S.overflow[e] = 1;
       nh = nh < S16_MAX_HIT ? nh : S16_MAX_HIT;
@@ -419,8 +391,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const shape_t B = shape_from_table(M, tb_);
           SupCoop16 sup;
           sup.c = c;
-          sup.load(0, A);
-          sup.load(1, B);
+          SupCoop16::load_one(sup.va, A, c);
+          SupCoop16::load_one(sup.vb, B, c);
           manifold_t m;
           collide_mpr_t(A, B, M.contact_offset, m, sup);
           if (c == 0) reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = m.count;
@@ -458,7 +430,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         const int idx = has ? t - cum[ge] : 0;
         float* Lg = sm + ge * S16_ENV_FLOATS;
         manifold_t m;
-        m.count = 0;
+        manifold_clear(m);
         int pk = 0;
         if (has) {
           pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
@@ -563,6 +535,39 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       __syncthreads();
     }
     PH(21);
+
+    // ================================================================ per-env constants of this lane
+    float qt_c = 0.f, qdt_c = 0.f, qf_c = 0.f;
+    bool rev_c = false;
+    unsigned anc_c = 0u;
+    float kp0 = 0.f, kd0 = 0.f, fmax = 3e38f, arm = 0.f, lo_c = -3e38f, hi_c = 3e38f;
+    float inert[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool grav_c = false, accel_mode = false;
+    pose_t JF_c = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};  // joint frame in the parent body frame
+    f3 al_c = f3{0, 0, 0};                            // joint axis in the joint frame
+    int par_c = -1;
+    if (art) {
+      JF_c = pose_from(M.dof_frame + 7 * c);
+      al_c = f3{M.dof_axis[3 * c], M.dof_axis[3 * c + 1], M.dof_axis[3 * c + 2]};
+      par_c = M.dof_parent[c];
+      qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
+      rev_c = M.dof_type[c] == MSSIM_JOINT_REVOLUTE;
+      anc_c = M.dof_anc[c];
+      kp0 = M.dof_drive[4 * c]; kd0 = M.dof_drive[4 * c + 1]; fmax = M.dof_drive[4 * c + 2];
+      accel_mode = (int)M.dof_drive[4 * c + 3] == MSSIM_DRIVE_ACCELERATION;
+      arm = M.dof_armature[c];
+      lo_c = M.dof_limit[2 * c]; hi_c = M.dof_limit[2 * c + 1];
+#pragma unroll
+      for (int k = 0; k < 10; k++) inert[k] = M.body_inertial[10 * c + k];
+      grav_c = M.body_gravity[c] != 0;
+    }
+    float fin[S16_MAX_FREE][10];
+#pragma unroll
+    for (int b = 0; b < S16_MAX_FREE; b++) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) fin[b][k] = 0.f;
+      if (b < nf) free_inertial_of(M, N, b, e, fin[b]);
+    }
 
     // ================================================================ dynamics: RNEA bias + CRBA
     sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
@@ -1109,45 +1114,47 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     vfree_c = freel ? v_c : 0.f;
     bp_c = nb; aw_c = naw; an_c = nan;
     PH(15);
+      // ================================================================ write back (last substep)
+    if (last) {
+      if (art && live) {
+        SOA(S.qacc, c) = qacc_c;
+        SOA(S.q, c) = q_c;
+        SOA(S.qd, c) = v_c;
+      }
+      if (freel && live) {
+        SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
+        if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
+      }
+      // body velocities about O with the new subspaces
+      sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+      if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
+      __syncthreads();
+      {
+        float* p = L + S16_S + 6 * c;
+        p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
+        L[S16_VEC + c] = art ? v_c : 0.f;
+      }
+      __syncthreads();
+      sv6 nV = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
+      for (int i = 0; i < n; i++) {
+        float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;
+        const float* p = L + S16_S + 6 * i;
+        nV.w += f3{p[0], p[1], p[2]} * m;
+        nV.v += f3{p[3], p[4], p[5]} * m;
+      }
+      PH(16);
+      if (art && live) {
+        pose_store_soa(S.bodypose, 7 * c, N, e, nb);
+        float* o = S.bodyvel + (size_t)(6 * c) * N + e;
+        o[0] = nV.w.x; o[(size_t)N] = nV.w.y; o[2 * (size_t)N] = nV.w.z;
+        o[3 * (size_t)N] = nV.v.x; o[4 * (size_t)N] = nV.v.y; o[5 * (size_t)N] = nV.v.z;
+        float* a = S.bodyaux + (size_t)(6 * c) * N + e;
+        a[0] = naw.x; a[(size_t)N] = naw.y; a[2 * (size_t)N] = naw.z;
+        a[3 * (size_t)N] = nan.x; a[4 * (size_t)N] = nan.y; a[5 * (size_t)N] = nan.z;
+      }
+    }
   }
 
-  // ---------------------------------------------------------------- write back
-  if (art && live) {
-    SOA(S.qacc, c) = qacc_c;
-    SOA(S.q, c) = q_c;
-    SOA(S.qd, c) = v_c;
-  }
-  if (freel && live) {
-    SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
-    if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
-  }
-  // body velocities about O with the new subspaces
-  sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
-  if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
-  __syncthreads();
-  {
-    float* p = L + S16_S + 6 * c;
-    p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
-    L[S16_VEC + c] = art ? v_c : 0.f;
-  }
-  __syncthreads();
-  sv6 nV = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
-  for (int i = 0; i < n; i++) {
-    float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;
-    const float* p = L + S16_S + 6 * i;
-    nV.w += f3{p[0], p[1], p[2]} * m;
-    nV.v += f3{p[3], p[4], p[5]} * m;
-  }
-  PH(16);
-  if (art && live) {
-    pose_store_soa(S.bodypose, 7 * c, N, e, nb);
-    float* o = S.bodyvel + (size_t)(6 * c) * N + e;
-    o[0] = nV.w.x; o[(size_t)N] = nV.w.y; o[2 * (size_t)N] = nV.w.z;
-    o[3 * (size_t)N] = nV.v.x; o[4 * (size_t)N] = nV.v.y; o[5 * (size_t)N] = nV.v.z;
-    float* a = S.bodyaux + (size_t)(6 * c) * N + e;
-    a[0] = naw.x; a[(size_t)N] = naw.y; a[2 * (size_t)N] = naw.z;
-    a[3 * (size_t)N] = nan.x; a[4 * (size_t)N] = nan.y; a[5 * (size_t)N] = nan.z;
-  }
   if (!FUSED && live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
   (void)nrow_con;
   PH(7);

@@ -26,7 +26,7 @@ buf = (ctypes.c_ulonglong * 32)()
 names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
          "dyn: S stage", "dyn: V sum", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: MPR",
          "", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
-         "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: manifolds", "np: count",
+         "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: plane/box-box rounds + record writes", "np: coop MPR",
          "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
 for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" % steps, steps)):
     torch.cuda.synchronize()
