@@ -141,6 +141,7 @@ def main():
     n = args.envs_per_gpu
     substeps = 100 // args.control_freq
     global_seeds = [2022 + i for i in range(n * world)]
+    torch.manual_seed(2022 + rank)  # reproducible action stream (A/B comparisons between builds)
     env = gym.make(args.env_id, num_envs=n, sim_backend=f"cuda:{local_rank}", sim_config=dict(control_freq=args.control_freq))
     base = env.unwrapped
     seeds = shard_seeds(global_seeds, rank, world)

@@ -60,6 +60,9 @@
 #define S16_NP_HIT (S16_U + 512)  // [64] surviving pairs: pair | sa << 16 | sb << 24
 #define S16_NP_CNT (S16_U + 576)  // [64] manifold sizes
 #define S16_NP_SCR (S16_U + 640)  // [56][16] box-box clip scratch of the group's 16 lanes | pair table during the cull (<= 896 pairs)
+#define S16_NP_ML (S16_U + 1536)  // [20] hit indices of this env's MPR (generic convex) pairs
+#define S16_NP_MS (S16_U + 1556)  // [20][7] their contacts n(3) x(3) sep, staged until the record offsets are known
+#define S16_MAX_MPR 20
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
@@ -163,28 +166,30 @@ struct SupCoop16 {
       }
     }
   }
-  template <int CTRL>
-  static MS_DEV void step(float& t, int& i, f3& p) {
-    const float ot = dpp_f<CTRL>(t);
-    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, false);
-    const f3 op = f3{dpp_f<CTRL>(p.x), dpp_f<CTRL>(p.y), dpp_f<CTRL>(p.z)};
-    const bool take = ot > t || (ot == t && oi < i);
-    t = take ? ot : t; i = take ? oi : i;
-    p.x = take ? op.x : p.x; p.y = take ? op.y : p.y; p.z = take ? op.z : p.z;
-  }
   static MS_DEV f3 scan(const f3 (&v)[4], const shape_t& s, f3 d, int c) {
     const f3 dl = mtmulv(s.rot, d);
+    // this lane's first maximum over its vertices c, c + 16, c + 32, c + 48
     float t = dot(v[0], dl);
     int i = c;
-    f3 p = v[0];
 #pragma unroll
     for (int k = 1; k < 4; k++) {
       const float tk = dot(v[k], dl);
       const bool g = tk > t && c + 16 * k < s.nverts;
-      t = g ? tk : t; i = g ? c + 16 * k : i; p = sel3(g, v[k], p);
+      t = g ? tk : t; i = g ? c + 16 * k : i;
     }
     if (c >= s.nverts) { t = -3e38f; i = 1 << 20; }
-    step<0x128>(t, i, p); step<0x124>(t, i, p); step<0x122>(t, i, p); step<0x121>(t, i, p);
+    // group maximum of the value, then the lowest index among the lanes that reach it (= the first
+    // maximum of the sequential scan), then the point from its owner lane
+    float tm = t;
+    tm = fmaxf(tm, dpp_f<0x128>(tm)); tm = fmaxf(tm, dpp_f<0x124>(tm)); tm = fmaxf(tm, dpp_f<0x122>(tm)); tm = fmaxf(tm, dpp_f<0x121>(tm));
+    int im = t == tm ? i : (1 << 20);
+    im = min(im, __builtin_amdgcn_update_dpp(0, im, 0x128, 0xF, 0xF, false));
+    im = min(im, __builtin_amdgcn_update_dpp(0, im, 0x124, 0xF, 0xF, false));
+    im = min(im, __builtin_amdgcn_update_dpp(0, im, 0x122, 0xF, 0xF, false));
+    im = min(im, __builtin_amdgcn_update_dpp(0, im, 0x121, 0xF, 0xF, false));
+    const int slot = im >> 4, owner = im & 15;
+    const f3 mine = sel3(slot == 0, v[0], sel3(slot == 1, v[1], sel3(slot == 2, v[2], v[3])));
+    const f3 p = f3{__shfl(mine.x, owner, 16), __shfl(mine.y, owner, 16), __shfl(mine.z, owner, 16)};
     return s.c + mmulv(s.rot, p);
   }
   // (no pointer select between the two arrays: that would force them out of registers)
@@ -374,40 +379,60 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       nh = nh < S16_MAX_HIT ? nh : S16_MAX_HIT;
       __syncthreads();
       PH(23);
-      // ---- manifolds, part 1: generic convex pairs (MPR), one pair at a time per env with the 16 lanes
-      // of the group sharing the hull scans. The single contact of task number t of this env stays
-      // in the registers of lane t % 16 (slot t / 16) until the record offsets are known.
-      float mres[2][7];
-      int midx[2] = {-1, -1};
+      // ---- manifolds, part 1: generic convex pairs (MPR). A pair is worked on by one 16-lane group
+      // (hull scans shared by its lanes); the MPR pairs of all 4 envs form one task list that the 4
+      // groups take round-robin, so an env with many such pairs does not serialise on its own group.
+      int nml = 0;  // MPR pairs of this env
       {
-        int nm = 0;
-        for (int idx = 0; idx < nh; idx++) {
-          const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
-          const float* ta_ = L + S16_NP_SHP + 16 * ((pk >> 16) & 0xFF);
-          const float* tb_ = L + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF);
-          const int ta = (int)(__float_as_uint(ta_[14]) & 7u), tb = (int)(__float_as_uint(tb_[14]) & 7u);
-          if (ta == SH_PLANE || (ta == SH_BOX && tb == SH_BOX)) continue;
-          const shape_t A = shape_from_table(M, ta_);
-          const shape_t B = shape_from_table(M, tb_);
+        bool over = false;
+        for (int base = 0; base < nh; base += 16) {
+          const int idx = base + c;
+          bool is_mpr = false;
+          if (idx < nh) {
+            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
+            const int ta = (int)(__float_as_uint(L[S16_NP_SHP + 16 * ((pk >> 16) & 0xFF) + 14]) & 7u);
+            const int tb = (int)(__float_as_uint(L[S16_NP_SHP + 16 * ((pk >> 24) & 0xFF) + 14]) & 7u);
+            is_mpr = !(ta == SH_PLANE || (ta == SH_BOX && tb == SH_BOX));
+          }
+          const unsigned m16 = (unsigned)(__ballot(is_mpr) >> (16 * g)) & 0xFFFFu;
+          const int rank = nml + __popc(m16 & ((1u << c) - 1u));
+          if (is_mpr) {
+            if (rank < S16_MAX_MPR) reinterpret_cast<int*>(L)[S16_NP_ML + rank] = idx;
+            else { over = true; reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = 0; }
+          }
+          nml += __popc(m16);
+        }
+        if (__any(over) && over && live) S.overflow[e] = 1;
+        nml = nml < S16_MAX_MPR ? nml : S16_MAX_MPR;
+      }
+      __syncthreads();
+      {
+        int mcum[S16_ENVS_PER_BLOCK + 1];
+        mcum[0] = 0;
+#pragma unroll
+        for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) mcum[j + 1] = mcum[j] + __shfl(nml, 16 * j);
+        const int TM = mcum[S16_ENVS_PER_BLOCK];
+        PH_ADD(14, (TM + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK);
+        for (int t = g; t < TM; t += S16_ENVS_PER_BLOCK) {
+          int ge = 0;
+#pragma unroll
+          for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= mcum[j] ? 1 : 0;
+          const int k = t - mcum[ge];
+          float* Lg = sm + ge * S16_ENV_FLOATS;
+          const int idx = reinterpret_cast<const int*>(Lg)[S16_NP_ML + k];
+          const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 16) & 0xFF));
+          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF));
           SupCoop16 sup;
           sup.c = c;
           SupCoop16::load_one(sup.va, A, c);
           SupCoop16::load_one(sup.vb, B, c);
           manifold_t m;
           collide_mpr_t(A, B, M.contact_offset, m, sup);
-          if (c == 0) reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = m.count;
-          if (m.count > 0) {
-            if (nm >= 32) { if (live && c == 0) S.overflow[e] = 1; }
-            else if ((nm & 15) == c) {
-#pragma unroll
-              for (int sl = 0; sl < 2; sl++)
-                if ((nm >> 4) == sl) {
-                  mres[sl][0] = m.n.x; mres[sl][1] = m.n.y; mres[sl][2] = m.n.z;
-                  mres[sl][3] = m.x[0].x; mres[sl][4] = m.x[0].y; mres[sl][5] = m.x[0].z; mres[sl][6] = m.sep[0];
-                  midx[sl] = idx;
-                }
-            }
-            nm++;
+          if (c == 0) {
+            reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
+            float* o = Lg + S16_NP_MS + 7 * k;
+            o[0] = m.n.x; o[1] = m.n.y; o[2] = m.n.z; o[3] = m.x[0].x; o[4] = m.x[0].y; o[5] = m.x[0].z; o[6] = m.sep[0];
           }
         }
       }
@@ -469,18 +494,19 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         __syncthreads();
       }
       // the staged MPR contacts go to their slots (all manifold sizes are known now)
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++) {
-        if (midx[sl] >= 0) {
+      for (int k = c; k < nml; k += 16) {
+        const int idx = reinterpret_cast<const int*>(L)[S16_NP_ML + k];
+        if (reinterpret_cast<const int*>(L)[S16_NP_CNT + idx] > 0) {
           int off = 0;
-          for (int j = 0; j < midx[sl]; j++) off += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
+          for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
           if (off < MAXC) {
-            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + midx[sl]];
+            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
             const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
+            const float* o = L + S16_NP_MS + 7 * k;
             float* r = L + S16_REC + S16_REC_LEN * off;
 #pragma unroll
-            for (int k = 0; k < 6; k++) r[k] = mres[sl][k];
-            r[6] = mres[sl][6] - M.rest_offset;
+            for (int q = 0; q < 6; q++) r[q] = o[q];
+            r[6] = o[6] - M.rest_offset;
             r[7] = __int_as_float(pk & 0xFFFF);
             r[8] = __int_as_float((int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) - 1, n) |
                                         (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) - 1, n) << 16)));
@@ -849,8 +875,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
       // zero rows are written for the padding slots too: the solver sweeps max over the wave's envs and
       // must read finite values there
-      if (i < S16_CON_LDS || live) {
-        float* row0 = i < S16_CON_LDS ? (L + S16_CROW + 3 * S16_ROWLEN * i) : (grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
+      // (LDS and global rows are written by separate code: one pointer for both would be a flat
+      // pointer, and flat stores are markedly slower than ds / global stores)
+      auto put_rows = [&](float* row0) __attribute__((always_inline)) {
 #pragma unroll
         for (int dk = 0; dk < 3; dk++) {
           float* row = row0 + S16_ROWLEN * dk;
@@ -869,7 +896,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             row[39] = dk == 2 ? g21 * invd : 0.f;
           }
         }
-      }
+      };
+      if (i < S16_CON_LDS) put_rows(L + S16_CROW + 3 * S16_ROWLEN * i);
+      else if (live) put_rows(grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
     }
     nrow_con = nc;
     PH_ADD(29, max_nc);
@@ -1039,13 +1068,20 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       };
       for (int i = 0; i < nc; i++) {
         // a contact's three rows never straddle the LDS / global boundary
-        const float* row = i < S16_CON_LDS ? (L + S16_CROW + 3 * S16_ROWLEN * i) : (grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
+        float l0, l1, l2;
+        if (i < S16_CON_LDS) {
+          const float* row = L + S16_CROW + 3 * S16_ROWLEN * i;
+          l0 = row[36]; l1 = row[S16_ROWLEN + 36]; l2 = row[2 * S16_ROWLEN + 36];
+        } else {
+          const float* row = grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS);
+          l0 = row[36]; l1 = row[S16_ROWLEN + 36]; l2 = row[2 * S16_ROWLEN + 36];
+        }
         const float* rec = L + S16_REC + S16_REC_LEN * i;
         const int p = __float_as_int(rec[7]);
         const f3 nrm = f3{rec[0], rec[1], rec[2]};
         const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
         const f3 t2 = cross(nrm, t1);
-        const f3 imp = nrm * row[36] + t1 * row[S16_ROWLEN + 36] + t2 * row[2 * S16_ROWLEN + 36];
+        const f3 imp = nrm * l0 + t1 * l1 + t2 * l2;
         if (p != prev_p) {
           flush();
           acc = f3{0, 0, 0};
