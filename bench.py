@@ -169,7 +169,14 @@ def main():
         solve_ms, solve_n = prof["solve"]
         narrow_ms, narrow_n = prof["narrow"]
         avg_solve_s = (solve_ms / max(solve_n, 1)) * 1e-3
-        alg_bytes_per_launch = ALG_BYTES_PER_ENV_STEP * n / substeps  # one launch = n envs x 1 substep
+        fused = narrow_n == 0 and solve_n == args.steps  # k_solve16<FUSED>: one launch = n envs x one control step
+        alg_bytes_per_launch = ALG_BYTES_PER_ENV_STEP * n / (1 if fused else substeps)
+        if fused:
+            kernel_name, kernel_key = f"k_solve16<FUSED> (whole control step: {substeps} substeps incl. narrowphase, 16 lanes/env)", "k_solve16<true>"
+        elif (px.model.n_dof + 6 * px.model.n_free) <= 16 and os.environ.get("MSSIM_SOLVER") != "lane":
+            kernel_name, kernel_key = "k_solve16 (one substep, 16 lanes/env; narrowphase in k_narrow)", "k_solve16<false>"
+        else:
+            kernel_name, kernel_key = "k_solve (one env per lane)", "k_solve"
         achieved = alg_bytes_per_launch / avg_solve_s / 1e9 if avg_solve_s > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), PickCube-v1 state-obs 4096 envs/GPU",
@@ -194,16 +201,16 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_solve16 (cooperative solve, 16 lanes/env)" if getattr(px._sim, "model", None) is not None and (px.model.n_dof + 6 * px.model.n_free) <= 16 and os.environ.get("MSSIM_SOLVER") != "lane" else "k_solve",
+                "kernel": kernel_name,
                 "achieved": round(achieved, 4),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic("k_solve16"),
+                "traffic": pmc_traffic(kernel_key),
                 "avg_kernel_ms": round(avg_solve_s * 1e3, 4),
                 "launches": solve_n,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "narrowphase_avg_kernel_ms": round(narrow_ms / max(narrow_n, 1), 4),
+                "narrowphase_avg_kernel_ms": None if fused else round(narrow_ms / max(narrow_n, 1), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
