@@ -881,20 +881,21 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #pragma unroll
         for (int dk = 0; dk < 3; dk++) {
           float* row = row0 + S16_ROWLEN * dk;
-          const float diag = dk == 0 ? d0 : (dk == 1 ? d1 : d2);
-          const float invd = diag > 1e-12f ? 1.f / diag : 0.f;
           row[c] = J3[dk];
           row[16 + c] = W3[dk];
-          if (c == 0) {
-            row[32] = invd;
-            row[33] = (dk == 0 && ck) ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
-            row[34] = (dk == 0 && ck) ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
-            row[35] = ck ? (dk == 0 ? -1.f : mu) : 0.f;
-            row[36] = 0.f;
-            row[37] = __int_as_float(p);
-            row[38] = dk == 0 ? 0.f : (dk == 1 ? g10 : g20) * invd;  // cross terms scaled by this row's 1/diag
-            row[39] = dk == 2 ? g21 * invd : 0.f;
-          }
+          if (c == 0) row[36] = 0.f;  // multiplier
+        }
+        if (c == 0) {
+          // scalars of the block: row0[32..35] = 1/d0, bias(pos), bias(vel), mu; row0[37] = pair;
+          // row1[32..35] = 1/d1, k10, 1/d2, k20; row2[32] = k21 (k = Delassus cross term x the row's 1/d)
+          const float i0 = d0 > 1e-12f ? 1.f / d0 : 0.f, i1 = d1 > 1e-12f ? 1.f / d1 : 0.f, i2 = d2 > 1e-12f ? 1.f / d2 : 0.f;
+          row0[32] = i0;
+          row0[33] = ck ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
+          row0[34] = ck ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
+          row0[35] = ck ? mu : 0.f;
+          row0[37] = __int_as_float(p);
+          row0[S16_ROWLEN + 32] = i1; row0[S16_ROWLEN + 33] = g10 * i1; row0[S16_ROWLEN + 34] = i2; row0[S16_ROWLEN + 35] = g20 * i2;
+          row0[2 * S16_ROWLEN + 32] = g21 * i2;
         }
       };
       if (i < S16_CON_LDS) put_rows(L + S16_CROW + 3 * S16_ROWLEN * i);
@@ -918,49 +919,62 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
     // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
     // the dependent reduction chains.
+    // The dependent chain per contact is jv0 -> nl0 -> nl1 -> nl2 -> v; everything that does not
+    // depend on the previous multiplier of the block (a1, a2, the first two W updates) is computed
+    // off the chain. Padding slots (up to the wave's longest env) hold all-zero rows: their updates
+    // reproduce the zero multipliers and move nothing.
     struct ConRec {
-      float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, k10, k20, k21;
-      float4 s0, s1, s2;
+      float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, k21;
+      float4 s0, sk;  // (1/d0, bias pos, bias vel, mu), (1/d1, k10, 1/d2, k20)
     };
-    // padding slots (up to the wave's longest env) hold all-zero rows: every update below then
-    // reproduces the zero multipliers and moves nothing
-    auto con_load = [&](const float* row, ConRec& R, bool active) __attribute__((always_inline)) {
+    auto con_solve = [&](float J0, float W0, float J1, float W1, float J2, float W2, float& lam0, float& lam1, float& lam2,
+                         float4 s0, float4 sk, float k21, bool use_bias) __attribute__((always_inline)) {
+      const float jv0 = gsum16(J0 * v_c);
+      const float jv1 = gsum16(J1 * v_c);
+      const float jv2 = gsum16(J2 * v_c);
+      const float a1 = fmaf(-jv1, sk.x, lam1);
+      const float a2 = fmaf(-jv2, sk.z, lam2);
+      const float nl0 = fmaxf(fmaf(-(jv0 + (use_bias ? s0.y : s0.z)), s0.x, lam0), 0.f);
+      const float dl0 = nl0 - lam0;
+      const float h = s0.w * nl0;
+      const float nl1 = fminf(fmaxf(fmaf(-sk.y, dl0, a1), -h), h);
+      const float dl1 = nl1 - lam1;
+      const float nl2 = fminf(fmaxf(fmaf(-k21, dl1, fmaf(-sk.w, dl0, a2)), -h), h);
+      const float dl2 = nl2 - lam2;
+      v_c = fmaf(W2, dl2, fmaf(W1, dl1, fmaf(W0, dl0, v_c)));
+      lam0 = nl0; lam1 = nl1; lam2 = nl2;
+    };
+    auto con_load = [&](const float* row, ConRec& R) __attribute__((always_inline)) {
       R.J0 = row[c]; R.W0 = row[16 + c];
       R.J1 = row[S16_ROWLEN + c]; R.W1 = row[S16_ROWLEN + 16 + c];
       R.J2 = row[2 * S16_ROWLEN + c]; R.W2 = row[2 * S16_ROWLEN + 16 + c];
       R.s0 = *reinterpret_cast<const float4*>(row + 32);
-      R.s1 = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
-      R.s2 = *reinterpret_cast<const float4*>(row + 2 * S16_ROWLEN + 32);
+      R.sk = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
+      R.k21 = row[2 * S16_ROWLEN + 32];
       R.lam0 = row[36]; R.lam1 = row[S16_ROWLEN + 36]; R.lam2 = row[2 * S16_ROWLEN + 36];
-      R.k10 = row[S16_ROWLEN + 38];
-      R.k20 = row[2 * S16_ROWLEN + 38]; R.k21 = row[2 * S16_ROWLEN + 39];
-      (void)active;  // padding slots hold zero rows (row build), nothing to mask here
     };
-    // The dependent chain per contact is jv0 -> nl0 -> nl1 -> nl2 -> v; everything that does not
-    // depend on the previous multiplier of the block (a1, a2, the first two W updates) is computed
-    // off the chain. k10 = g10 / d1, k20 = g20 / d2, k21 = g21 / d2 (Delassus cross terms).
-    auto con_apply = [&](const ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
-      const float jv0 = gsum16(R.J0 * v_c);
-      const float jv1 = gsum16(R.J1 * v_c);
-      const float jv2 = gsum16(R.J2 * v_c);
-      const float a1 = fmaf(-jv1, R.s1.x, R.lam1);
-      const float a2 = fmaf(-jv2, R.s2.x, R.lam2);
-      const float nl0 = fmaxf(fmaf(-(jv0 + (use_bias ? R.s0.y : R.s0.z)), R.s0.x, R.lam0), 0.f);
-      const float dl0 = nl0 - R.lam0;
-      const float h1 = R.s1.w * nl0, h2 = R.s2.w * nl0;
-      const float nl1 = fminf(fmaxf(fmaf(-R.k10, dl0, a1), -h1), h1);
-      const float dl1 = nl1 - R.lam1;
-      const float nl2 = fminf(fmaxf(fmaf(-R.k21, dl1, fmaf(-R.k20, dl0, a2)), -h2), h2);
-      const float dl2 = nl2 - R.lam2;
-      v_c = fmaf(R.W2, dl2, fmaf(R.W1, dl1, fmaf(R.W0, dl0, v_c)));
-      if (active && c == 0) { row[36] = nl0; row[S16_ROWLEN + 36] = nl1; row[2 * S16_ROWLEN + 36] = nl2; }
+    auto con_apply = [&](ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
+      con_solve(R.J0, R.W0, R.J1, R.W1, R.J2, R.W2, R.lam0, R.lam1, R.lam2, R.s0, R.sk, R.k21, use_bias);
+      if (active && c == 0) { row[36] = R.lam0; row[S16_ROWLEN + 36] = R.lam1; row[2 * S16_ROWLEN + 36] = R.lam2; }
     };
+    // contacts held in LDS: Jacobian / W entries of this lane and the multipliers stay in registers over
+    // all iterations (statically indexed, the sweep is unrolled over the 12 slots); only the 9 block
+    // scalars are re-read from LDS
+    float* const crow = L + S16_CROW;
+    float Jr[S16_CON_LDS][3], Wr[S16_CON_LDS][3], lamr[S16_CON_LDS][3];
+#pragma unroll
+    for (int k = 0; k < S16_CON_LDS; k++) {
+#pragma unroll
+      for (int dk = 0; dk < 3; dk++) {
+        Jr[k][dk] = 0.f; Wr[k][dk] = 0.f; lamr[k][dk] = 0.f;
+        if (k < max_clds) { Jr[k][dk] = crow[(3 * k + dk) * S16_ROWLEN + c]; Wr[k][dk] = crow[(3 * k + dk) * S16_ROWLEN + 16 + c]; }
+      }
+    }
 #ifdef EXP_ITERS
     const int n_iters = EXP_ITERS;
 #else
     const int n_iters = M.pos_iters + M.vel_iters;
 #endif
-    float* const crow = L + S16_CROW;
     for (int it = 0; it <= n_iters; it++) {
       if (it == M.pos_iters) {
         q_c += dt * v_c;
@@ -1011,37 +1025,43 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
       }
       PH(18);
-      if (max_clds > 0) {
-        ConRec A, B;
-        con_load(crow, A, 0 < nc_lds);
-        int k = 0;
-        while (true) {
-          // next block is loaded before the dependent chain of the current one (index clamped: in range)
-          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), B, k + 1 < nc_lds);
-          con_apply(A, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
-          if (++k >= max_clds) break;
-          con_load(crow + 3 * S16_ROWLEN * min(k + 1, max_clds - 1), A, k + 1 < nc_lds);
-          con_apply(B, crow + 3 * S16_ROWLEN * k, k < nc_lds, use_bias);
-          if (++k >= max_clds) break;
+#pragma unroll
+      for (int k = 0; k < S16_CON_LDS; k++) {
+        if (k < max_clds) {  // wave-uniform
+          const float* row = crow + 3 * S16_ROWLEN * k;
+          const float4 s0 = *reinterpret_cast<const float4*>(row + 32);
+          const float4 sk = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
+          const float k21 = row[2 * S16_ROWLEN + 32];
+          float l0 = lamr[k][0], l1 = lamr[k][1], l2 = lamr[k][2];
+          con_solve(Jr[k][0], Wr[k][0], Jr[k][1], Wr[k][1], Jr[k][2], Wr[k][2], l0, l1, l2, s0, sk, k21, use_bias);
+          lamr[k][0] = l0; lamr[k][1] = l1; lamr[k][2] = l2;
         }
       }
       PH(19);
       if (max_cglb > 0) {
         // contacts beyond the LDS capacity stream from the per-env global scratch, one block ahead
         ConRec A, B;
-        con_load(grow, A, 0 < nc_glb);
+        con_load(grow, A);
         int k = 0;
         while (true) {
-          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), B, k + 1 < nc_glb);
+          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), B);
           con_apply(A, grow + (size_t)(3 * S16_ROWLEN) * k, k < nc_glb && live, use_bias);
           if (++k >= max_cglb) break;
-          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), A, k + 1 < nc_glb);
+          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), A);
           con_apply(B, grow + (size_t)(3 * S16_ROWLEN) * k, k < nc_glb && live, use_bias);
           if (++k >= max_cglb) break;
         }
       }
       PH(20);
     }
+    if (c == 0) {
+#pragma unroll
+      for (int k = 0; k < S16_CON_LDS; k++)
+        if (k < nc_lds) {
+          crow[3 * S16_ROWLEN * k + 36] = lamr[k][0]; crow[(3 * k + 1) * S16_ROWLEN + 36] = lamr[k][1]; crow[(3 * k + 2) * S16_ROWLEN + 36] = lamr[k][2];
+        }
+    }
+    __syncthreads();
     PH(5);
 
     // ================================================================ contact impulses per pair (last substep)
