@@ -251,6 +251,14 @@ typedef struct mssim_pick_task {
  * obj_to_goal3), reward [N] f32, flags [N][4] u8 = success, is_obj_placed, is_robot_static, is_grasped */
 int MSSIM_FN(task_pick_outputs)(mssim_handle h, const mssim_pick_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
 
+/* Geometric Jacobian of an articulation link at the CURRENT simulation state, for the end-effector
+ * controllers (agents/controllers/pd_ee_pose.py:96-121, controllers/utils/kinematics.py:156-171, where
+ * the reference calls pytorch_kinematics' `chain.jacobian`): out [N][6][n_dof] f32, rows 0-2 linear
+ * and 3-5 angular velocity of the link frame origin per unit joint velocity, expressed in the
+ * articulation ROOT frame; columns of joints that do not move the link are zero. It falls out of the
+ * step's own FK state (world joint axes / anchors), no separate kinematics pass. */
+int MSSIM_FN(link_jacobian)(mssim_handle h, int32_t link_index, float* out, void* stream);
+
 /* Measurement aid (bench.py roofline block): when enabled, every k_solve / k_narrow launch inside
  * mssim_step is bracketed by HIP events on the SAME stream it is launched on. profile_read
  * synchronises, returns the accumulated milliseconds and launch counts since the last read

@@ -1,19 +1,106 @@
-"""End-effector space controllers: configs are accepted so robot definitions import unchanged, but
-constructing one raises -- batched IK on device is the next widening step (SURVEY.md 8f rank 3;
-reference: mani_skill/agents/controllers/pd_ee_pose.py, controllers/utils/kinematics.py:124-186)."""
+"""End-effector space controllers (counterpart of mani_skill/agents/controllers/pd_ee_pose.py:23-262):
+the action is a (delta) position / pose of the end-effector link in the robot's root frame, turned into
+joint position targets by `Kinematics.compute_ik`."""
 from dataclasses import dataclass
 from typing import Sequence, Union
 
-from .base_controller import BaseController, ControllerConfig
+import numpy as np
+import torch
+from gymnasium import spaces
+
+from maniskill_amd.utils import gym_utils
+from maniskill_amd.utils.geometry.rotation_conversions import (
+    euler_angles_to_matrix,
+    matrix_to_quaternion,
+    quaternion_apply,
+    quaternion_multiply,
+)
+from maniskill_amd.utils.structs.pose import Pose
+
+from .base_controller import ControllerConfig
+from .pd_joint_pos import PDJointPosController
+from .utils.kinematics import Kinematics
 
 
-class PDEEPosController(BaseController):
-    def __init__(self, *a, **kw):
-        raise NotImplementedError("pd_ee_* control modes need batched IK, which this build does not implement yet (SURVEY.md 8f)")
+class PDEEPosController(PDJointPosController):
+    config: "PDEEPosControllerConfig"
+    _target_pose = None
 
+    def _check_gpu_sim_works(self):
+        assert self.config.frame == "root_translation", "only translation in the root frame is supported for EE control in the GPU sim"
 
-class PDEEPoseController(PDEEPosController):
-    pass
+    def _initialize_joints(self):
+        self.initial_qpos = None
+        super()._initialize_joints()
+        self._check_gpu_sim_works()
+        self.kinematics = Kinematics(self.config.urdf_path, self.config.ee_link, self.articulation, self.active_joint_indices)
+        self.ee_link = self.kinematics.end_link
+
+    def _initialize_action_space(self):
+        low = np.float32(np.broadcast_to(self.config.pos_lower, 3))
+        high = np.float32(np.broadcast_to(self.config.pos_upper, 3))
+        self.single_action_space = spaces.Box(low, high, dtype=np.float32)
+
+    def fused_action_spec(self):
+        return None  # IK sits between the action and the joint targets
+
+    @property
+    def ee_pos(self):
+        return self.ee_link.pose.p
+
+    @property
+    def ee_pose(self):
+        return self.ee_link.pose
+
+    @property
+    def ee_pose_at_base(self):
+        return self.articulation.pose.inv() * self.ee_pose
+
+    def reset(self):
+        super().reset()
+        cur = self.ee_pose_at_base
+        if self._target_pose is None or self.scene._reset_mask_all:
+            self._target_pose = Pose.create(cur.raw_pose.clone())
+        else:
+            m = self.scene._reset_mask
+            self._target_pose.raw_pose[m] = cur.raw_pose[m]
+
+    def compute_target_pose(self, prev_ee_pose_at_base, action):
+        if self.config.use_delta:
+            delta_pose = Pose.create_from_pq(p=action)
+            if self.config.frame == "root_translation":
+                return delta_pose * prev_ee_pose_at_base
+            if self.config.frame == "body_translation":
+                return prev_ee_pose_at_base * delta_pose
+            raise NotImplementedError(self.config.frame)
+        assert self.config.frame == "root_translation", self.config.frame
+        return Pose.create_from_pq(p=action)
+
+    def set_action(self, action):
+        action = self._preprocess_action(action)
+        self._step = 0
+        self._start_qpos = self.qpos.clone()
+        prev = self._target_pose if self.config.use_target else self.ee_pose_at_base
+        self._target_pose = self.compute_target_pose(prev, action)
+        pos_only = type(self.config) == PDEEPosControllerConfig
+        self._target_qpos = self.kinematics.compute_ik(
+            self._target_pose, self.articulation.get_qpos(), pos_only=pos_only, action=action,
+            use_delta_ik_solver=self.config.use_delta and not self.config.use_target,
+        )
+        if self._target_qpos is None:
+            self._target_qpos = self._start_qpos
+        if self.config.interpolate:
+            self._step_size = (self._target_qpos - self._start_qpos) / self._sim_steps
+        else:
+            self.set_drive_targets(self._target_qpos)
+
+    def get_state(self) -> dict:
+        return {"target_pose": self._target_pose.raw_pose} if self.config.use_target else {}
+
+    def set_state(self, state: dict):
+        if self.config.use_target:
+            t = state["target_pose"]
+            self._target_pose = Pose.create_from_pq(t[:, :3], t[:, 3:])
 
 
 @dataclass
@@ -35,22 +122,48 @@ class PDEEPosControllerConfig(ControllerConfig):
     controller_cls = PDEEPosController
 
 
+class PDEEPoseController(PDEEPosController):
+    config: "PDEEPoseControllerConfig"
+
+    def _check_gpu_sim_works(self):
+        assert self.config.frame == "root_translation:root_aligned_body_rotation", (
+            "only root-frame translation with root-aligned rotation is supported for EE control in the GPU sim"
+        )
+
+    def _initialize_action_space(self):
+        low = np.float32(np.hstack([np.broadcast_to(self.config.pos_lower, 3), np.broadcast_to(self.config.rot_lower, 3)]))
+        high = np.float32(np.hstack([np.broadcast_to(self.config.pos_upper, 3), np.broadcast_to(self.config.rot_upper, 3)]))
+        self.single_action_space = spaces.Box(low, high, dtype=np.float32)
+
+    def _clip_and_scale_action(self, action):
+        # translation per axis, rotation clipped by its norm (pd_ee_pose.py:197-210)
+        pos = gym_utils.clip_and_scale_action(action[:, :3], self.action_space_low[:3], self.action_space_high[:3])
+        rot = action[:, 3:]
+        norm = torch.linalg.norm(rot, dim=1, keepdim=True)
+        rot = torch.where(norm > 1, rot / norm.clamp_min(1e-12), rot) * self.config.rot_lower
+        return torch.hstack([pos, rot])
+
+    def compute_target_pose(self, prev_ee_pose_at_base, action):
+        if self.config.use_delta:
+            delta_pos, delta_rot = action[:, 0:3], action[:, 3:6]
+            delta_quat = matrix_to_quaternion(euler_angles_to_matrix(delta_rot, "XYZ"))
+            if "root_aligned_body_rotation" in self.config.frame:
+                q = quaternion_multiply(delta_quat, prev_ee_pose_at_base.q)
+            else:
+                q = quaternion_multiply(prev_ee_pose_at_base.q, delta_quat)
+            if "root_translation" in self.config.frame:
+                p = prev_ee_pose_at_base.p + delta_pos
+            else:
+                p = prev_ee_pose_at_base.p + quaternion_apply(prev_ee_pose_at_base.q, delta_pos)
+            return Pose.create_from_pq(p, q)
+        assert self.config.frame == "root_translation:root_aligned_body_rotation", self.config.frame
+        target_pos, target_rot = action[:, 0:3], action[:, 3:6]
+        return Pose.create_from_pq(target_pos, matrix_to_quaternion(euler_angles_to_matrix(target_rot, "XYZ")))
+
+
 @dataclass
-class PDEEPoseControllerConfig(ControllerConfig):
-    pos_lower: Union[float, Sequence[float]] = None
-    pos_upper: Union[float, Sequence[float]] = None
+class PDEEPoseControllerConfig(PDEEPosControllerConfig):
     rot_lower: Union[float, Sequence[float]] = None
     rot_upper: Union[float, Sequence[float]] = None
-    stiffness: Union[float, Sequence[float]] = None
-    damping: Union[float, Sequence[float]] = None
-    force_limit: Union[float, Sequence[float]] = 1e10
-    friction: Union[float, Sequence[float]] = 0.0
-    ee_link: str = None
-    urdf_path: str = None
     frame: str = "root_translation:root_aligned_body_rotation"
-    use_delta: bool = True
-    use_target: bool = False
-    interpolate: bool = False
-    normalize_action: bool = True
-    drive_mode: str = "force"
     controller_cls = PDEEPoseController

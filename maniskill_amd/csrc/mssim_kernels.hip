@@ -1124,6 +1124,34 @@ __global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_
   f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
 }
 
+// geometric Jacobian of link `link` in the root frame: out [N][6][n_dof] (see include/mssim.h)
+__global__ void k_link_jacobian(DevModel M, DevState S, int link, float* __restrict__ out) {
+  const int N = S.N;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  const pose_t root = pose_soa(S.root, 0, N, e);
+  const m3 Rr = qmat(root.q);
+  const int b = M.link_body[link];
+  const pose_t Pb = b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e);
+  const f3 pe = pmul(Pb, pose_from(M.link_frame + 7 * link)).p;
+  const unsigned path = b < 0 ? 0u : (M.dof_anc[b] | (1u << b));
+  float* o = out + (size_t)e * 6 * n;
+  for (int j = 0; j < n; j++) {
+    f3 jv = f3{0, 0, 0}, jw = f3{0, 0, 0};
+    if ((path >> j) & 1u) {
+      const f3 a = f3{SOA(S.bodyaux, 6 * j), SOA(S.bodyaux, 6 * j + 1), SOA(S.bodyaux, 6 * j + 2)};
+      const f3 an = f3{SOA(S.bodyaux, 6 * j + 3), SOA(S.bodyaux, 6 * j + 4), SOA(S.bodyaux, 6 * j + 5)};
+      if (M.dof_type[j] == MSSIM_JOINT_REVOLUTE) { jv = cross(a, pe - an); jw = a; }
+      else jv = a;
+      jv = mtmulv(Rr, jv);
+      jw = mtmulv(Rr, jw);
+    }
+    o[0 * n + j] = jv.x; o[1 * n + j] = jv.y; o[2 * n + j] = jv.z;
+    o[3 * n + j] = jw.x; o[4 * n + j] = jw.y; o[5 * n + j] = jw.z;
+  }
+}
+
 __global__ void k_i2f(const int* src, float* dst, size_t count) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < count) dst[i] = (float)src[i];
@@ -1424,6 +1452,15 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
     else hipLaunchKernelGGL(k_solve<TopoDyn>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);
   }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_link_jacobian(mssim_handle h, int32_t link_index, float* out, void* stream) {
+  if (link_index < 0 || link_index >= h->M.n_link || !out) { h->err = "link_jacobian: bad link index / output"; return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+  hipLaunchKernelGGL(k_link_jacobian, env_grid(h->N, 256), dim3(256), 0, st, h->M, h->S, (int)link_index, out);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

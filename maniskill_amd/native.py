@@ -170,6 +170,7 @@ class NativeLib:
         f("query_body_impulses", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
         f("set_drive_properties", C.c_int, [H, _F32P])
         f("read_internal", C.c_int, [H, C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p])
+        f("link_jacobian", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
         f("overflow_count", C.c_int, [H, C.c_void_p])
         f("set_action_map", C.c_int, [H, _I32P, _F32P, _F32P, _I32P])
         f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
@@ -184,7 +185,7 @@ class NativeLib:
     EXPORTS = [
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
-        "query_body_impulses", "set_drive_properties", "read_internal", "overflow_count", "set_action_map",
+        "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map",
         "apply_action", "task_pick_outputs", "profile_enable",
         "profile_read", "last_error",
         "abi_version",
@@ -286,6 +287,9 @@ class NativeSim:
         if n < 0:
             self._check(n, f"read_internal({name})")
         return n
+
+    def link_jacobian(self, link_index, out_ptr, stream=None):
+        self._check(self.lib.link_jacobian(self.h, int(link_index), out_ptr, stream), "link_jacobian")
 
     def set_action_map(self, column, low, high, flags):
         col = np.ascontiguousarray(column, dtype=np.int32)

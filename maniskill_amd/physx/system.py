@@ -282,6 +282,13 @@ class MssimSystem:
         n = self._sim.read_internal(name, out.data_ptr(), max_items, self._stream())
         return out[:n]
 
+    def link_jacobian(self, link_index: int) -> torch.Tensor:
+        """[N, 6, n_dof] geometric Jacobian (linear; angular) of articulation link `link_index` in the root
+        frame at the current simulation state (include/mssim.h `link_jacobian`)"""
+        out = torch.empty((self.num_envs, 6, self.model.n_dof), dtype=torch.float32, device=self.device)
+        self._sim.link_jacobian(link_index, out.data_ptr(), self._stream())
+        return out
+
     # ------------------------------------------------------------------ fused callers (HIP only)
     @property
     def supports_fused_callers(self) -> bool:

@@ -824,6 +824,36 @@ int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_
 
 // fused callers are an optimisation of the HIP product; the oracle keeps the plain (torch) path
 int mssim_ref_set_action_map(mssim_handle h, const int32_t*, const float*, const float*, const int32_t*) { h->err = "not available in the oracle"; return 1; }
+// geometric Jacobian of a link in the root frame, from the oracle's own FK (include/mssim.h)
+int mssim_ref_link_jacobian(mssim_handle h, int32_t link, float* out, void*) {
+  const Model& M = h->M;
+  if (link < 0 || link >= M.n_link || !out) { h->err = "link_jacobian: bad link index / output"; return 1; }
+  const int n = M.n_dof;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < h->N; e++) {
+    EnvState& E = h->env[e];
+    std::vector<Vec> axis_w, anchor;
+    fk(M, E, &axis_w, &anchor);
+    const int b = M.link_body[link];
+    const Pose<Real> Pb = b < 0 ? E.root : E.body_pose[b];
+    const Vec pe = pmul(Pb, pose7(&M.link_frame[7 * link])).p;
+    std::vector<char> on_path(n, 0);
+    for (int i = b; i >= 0; i = M.dof_parent[i]) on_path[i] = 1;
+    float* o = out + (size_t)e * 6 * n;
+    for (int j = 0; j < n; j++) {
+      Vec jv, jw;
+      if (on_path[j]) {
+        if (M.dof_type[j] == MSSIM_JOINT_REVOLUTE) { jv = cross(axis_w[j], pe - anchor[j]); jw = axis_w[j]; }
+        else jv = axis_w[j];
+        jv = qrot(qconj(E.root.q), jv);
+        jw = qrot(qconj(E.root.q), jw);
+      }
+      o[0 * n + j] = (float)jv.x; o[1 * n + j] = (float)jv.y; o[2 * n + j] = (float)jv.z;
+      o[3 * n + j] = (float)jw.x; o[4 * n + j] = (float)jw.y; o[5 * n + j] = (float)jw.z;
+    }
+  }
+  return 0;
+}
 int mssim_ref_apply_action(mssim_handle h, const float*, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_task_pick_outputs(mssim_handle h, const mssim_pick_task*, float*, float*, uint8_t*, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_profile_enable(mssim_handle, int32_t) { return 0; }

@@ -277,3 +277,64 @@ def check_peg_insertion(sim_backend, device_type):
     sd = base.get_state_dict()
     assert set(sd["actors"].keys()) >= {"peg", "box_with_hole"} and not any(k.startswith("peg_") for k in sd["actors"])
     env.close()
+
+
+def check_ee_controllers(sim_backend):
+    """pd_ee_* control modes (reference: agents/controllers/pd_ee_pose.py; its tests only step the modes,
+    tests/utils.py:21-28 + tests/test_envs.py): the TCP moves the way the root-frame command says."""
+    N = 4
+    # delta position: +x command moves the TCP along +x of the root frame
+    env = make("PickCube-v1", N, sim_backend, control_mode="pd_ee_delta_pos")
+    base = env.unwrapped
+    env.reset(seed=0)
+    assert base.single_action_space.shape == (4,)
+    p0 = base.agent.tcp.pose.p.clone()
+    a = torch.zeros(N, 4, device=base.device)
+    a[:, 0] = 0.5  # 5 cm per control step
+    for _ in range(6):
+        env.step(a)
+    d = base.agent.tcp.pose.p - p0
+    assert torch.all(d[:, 0] > 0.08) and torch.all(d[:, 0] < 0.32), d  # (the delta is relative to the lagging current pose)
+    assert torch.all(d[:, 1:].abs() < 0.03), d
+    env.close()
+    # delta pose: a pure rotation command about root z turns the TCP and leaves its position in place
+    env = make("PickCube-v1", N, sim_backend, control_mode="pd_ee_delta_pose")
+    base = env.unwrapped
+    env.reset(seed=0)
+    assert base.single_action_space.shape == (7,)
+    P0 = base.agent.tcp.pose.raw_pose.clone()
+    a = torch.zeros(N, 7, device=base.device)
+    a[:, 5] = 1.0
+    for _ in range(6):
+        env.step(a)
+    P1 = base.agent.tcp.pose.raw_pose
+    assert torch.all((P1[:, :3] - P0[:, :3]).norm(dim=1) < 0.02)
+    dot = (P1[:, 3:] * P0[:, 3:]).sum(1).abs().clamp(max=1)
+    ang = 2 * torch.acos(dot)
+    assert torch.all(ang > 0.15) and torch.all(ang < 0.7), ang  # 6 steps x 0.1 rad commanded, relative to the lagging pose
+    env.close()
+    # target-delta position and absolute pose: the iterative IK reaches the commanded pose
+    env = make("PickCube-v1", N, sim_backend, control_mode="pd_ee_target_delta_pos")
+    base = env.unwrapped
+    env.reset(seed=0)
+    p0 = base.agent.tcp.pose.p.clone()
+    a = torch.zeros(N, 4, device=base.device)
+    a[:, 2] = 1.0
+    env.step(a)  # target = start + 10 cm up, then hold
+    for _ in range(15):
+        env.step(torch.zeros(N, 4, device=base.device))
+    d = base.agent.tcp.pose.p - p0
+    assert torch.allclose(d[:, 2], torch.full_like(d[:, 2], 0.1), atol=0.01), d
+    assert torch.all(d[:, :2].abs() < 0.01), d
+    env.close()
+    env = make("PickCube-v1", N, sim_backend, control_mode="pd_ee_pose")
+    base = env.unwrapped
+    env.reset(seed=0)
+    tgt = torch.zeros(N, 7, device=base.device)
+    tgt[:, :3] = torch.tensor([0.45, 0.10, 0.35], device=base.device)  # reachable with the tool pointing down
+    tgt[:, 3:6] = torch.tensor([np.pi, 0.0, 0.0], device=base.device)  # tool pointing down
+    for _ in range(25):
+        env.step(tgt)
+    now = base.agent.robot.pose.inv() * base.agent.tcp.pose
+    assert torch.allclose(now.p, tgt[:, :3], atol=0.01), (now.p - tgt[:, :3])
+    env.close()

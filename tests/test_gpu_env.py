@@ -42,6 +42,10 @@ def test_scripted_pick_and_lift():
     ec.check_scripted_pick_and_lift(BACKEND)
 
 
+def test_ee_controllers():
+    ec.check_ee_controllers(BACKEND)
+
+
 def test_peg_insertion_per_env_geometry():
     ec.check_peg_insertion(BACKEND, "cuda")
 

@@ -230,3 +230,20 @@ def test_pair_impulse_query_matches():
     assert torch.allclose(res[0][0, :, 2], torch.full((N,), w), rtol=2e-2)
     assert torch.allclose(res[0], res[1], atol=2e-5)
     assert torch.allclose(res[0][0], -res[0][1])
+
+
+def test_link_jacobian_matches_oracle():
+    """`mssim_link_jacobian` (HIP) against the oracle's, which tests/test_link_jacobian.py pins by finite differences"""
+    model = panda_tabletop_model()
+    N = 128
+    gpu, cpu = make_pair(model, N)
+    q, qd, tq, cube = random_tabletop_state(N, 7, spread=1.0)
+    for px in (gpu, cpu):
+        set_state(px, model, N, q, qd, tq, cube)
+        px.gpu_update_articulation_kinematics()
+    for name in ("panda_hand_tcp", "panda_link3", "panda_rightfinger"):
+        link = model.link_names.index(name)
+        a, b = gpu.link_jacobian(link).cpu(), cpu.link_jacobian(link)
+        assert a.shape == (N, 6, model.n_dof)
+        assert torch.max(torch.abs(a - b)) < 5e-6
+
