@@ -113,3 +113,18 @@ def test_fused_callers_match_torch_path(monkeypatch):
         assert i1.keys() == i2.keys()
         for k in i1:
             assert torch.equal(i1[k], i2[k]), k
+
+
+def test_trajectory_recorded_on_oracle_replays_on_hip(tmp_path):
+    """cross-backend replay by env states (reference: replay_trajectory.py --use-env-states -b ...): a
+    trajectory recorded on the CPU oracle, replayed step by step on the HIP backend"""
+    import os
+
+    from maniskill_amd.trajectory.replay_trajectory import replay
+    from tests.test_trajectory import _record
+
+    ob.register("f64", "oracle_f64_env")
+    path = _record(tmp_path, "oracle_f64_env")
+    res = replay(path, sim_backend=BACKEND, use_env_states=True)
+    assert len(res) == 2 and all(r["max_state_deviation"] < 2e-3 for r in res), res
+
