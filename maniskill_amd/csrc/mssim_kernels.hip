@@ -38,6 +38,7 @@ struct DevModel {
   const int *shape_type, *shape_kind, *shape_index, *shape_row, *shape_hull, *pair_shape;
   const float *shape_frame, *shape_param, *shape_material, *shape_bound, *hull_verts;
   const float* shape_center;  // [n_shape][3] bounding-sphere centre in the BODY frame (shape_frame applied)
+  const float* shape_half;    // [n_shape][3] half extents of a box in the SHAPE frame, centred at the bound centre, that contains the shape
   // per-env overrides ([items][N], env fastest); slot < 0 = shared value
   const int *shape_env_slot, *free_env_slot;
   const float *env_shape_frame, *env_shape_param, *env_shape_bound, *env_free_inertial;
@@ -1339,6 +1340,30 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       for (int i = 0; i < 3; i++) ctr[3 * s2 + i] = f[i] + R[i][0] * b[0] + R[i][1] * b[1] + R[i][2] * b[2];
     }
     if ((rc = upload(S, ctr.data(), (size_t)3 * ns, &M.shape_center))) { mssim_destroy(S); return rc; }
+    // oriented bounding boxes for the cull (shape frame axes, centred at the bound centre)
+    std::vector<float> half(3 * (ns > 0 ? ns : 1), 0.f);
+    for (int s2 = 0; s2 < ns; s2++) {
+      const float* pp = d->shape_param + 4 * s2;
+      const float* b = d->shape_bound + 4 * s2;
+      float* h = &half[3 * s2];
+      switch (d->shape_type[s2]) {
+        case MSSIM_SHAPE_BOX: h[0] = pp[0]; h[1] = pp[1]; h[2] = pp[2]; break;
+        case MSSIM_SHAPE_SPHERE: h[0] = h[1] = h[2] = pp[0]; break;
+        case MSSIM_SHAPE_CAPSULE: h[0] = pp[1] + pp[0]; h[1] = h[2] = pp[0]; break;
+        case MSSIM_SHAPE_CYLINDER: h[0] = pp[1]; h[1] = h[2] = pp[0]; break;
+        case MSSIM_SHAPE_CONVEX:
+          for (int i = 0; i < d->shape_hull[2 * s2 + 1]; i++) {
+            const float* v = d->hull_verts + 3 * (size_t)(d->shape_hull[2 * s2] + i);
+            for (int k = 0; k < 3; k++) h[k] = std::max(h[k], std::fabs(v[k] - b[k]));
+          }
+          break;
+        default: h[0] = h[1] = h[2] = 3e30f;  // plane: never used
+      }
+      // primitive shapes are centred on their frame; keep the box valid if the bound centre is offset
+      if (d->shape_type[s2] != MSSIM_SHAPE_CONVEX && d->shape_type[s2] != MSSIM_SHAPE_PLANE)
+        for (int k = 0; k < 3; k++) h[k] += std::fabs(b[k]);
+    }
+    if ((rc = upload(S, half.data(), (size_t)3 * ns, &M.shape_half))) { mssim_destroy(S); return rc; }
   }
   {
     const bool has_es = d->n_env_shape > 0, has_ef = d->n_env_free > 0;

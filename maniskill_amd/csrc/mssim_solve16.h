@@ -36,7 +36,7 @@
 #define S16_PT_KIN 19
 #define S16_MAX_FREE 2
 #define S16_MAX_KIN 6
-#define S16_MAX_SHAPE 32
+#define S16_MAX_SHAPE 28
 #define S16_MAX_HIT 64
 #define S16_BP (S16_PT + 7 * S16_PT_LINK)  // link poses
 #define S16_U 272      // union: dynamics staging | solver rows | narrowphase scratch
@@ -59,13 +59,14 @@
 #define S16_ROWLEN 32
 #define S16_ROWS_GLB (3 * (MAXC - S16_REGC - S16_LDSC))  // global scratch rows per env (x S16_ROWLEN floats)
 // narrowphase scratch (FUSED), overlays the union below the contact records
-#define S16_NP_SHP (S16_U)        // [32][16] world shape table
-#define S16_NP_HIT (S16_U + 512)  // [64] surviving pairs: pair | sa << 16 | sb << 24
-#define S16_NP_CNT (S16_U + 576)  // [64] manifold sizes
-#define S16_NP_SCR (S16_U + 640)  // [56][16] box-box clip scratch of the group's 16 lanes | pair table during the cull (<= 896 pairs)
-#define S16_NP_ML (S16_U + 1536)  // [20] hit indices of this env's MPR (generic convex) pairs
-#define S16_NP_MS (S16_U + 1556)  // [20][7] their contacts n(3) x(3) sep, staged until the record offsets are known
-#define S16_MAX_MPR 20
+#define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 pad
+#define S16_NP_SHP (S16_U)        // [28][20] world shape table
+#define S16_NP_HIT (S16_U + 560)  // [64] surviving pairs: pair | sa << 16 | sb << 24
+#define S16_NP_CNT (S16_U + 624)  // [64] manifold sizes
+#define S16_NP_SCR (S16_U + 688)  // [56][16] box-box clip scratch of the group's 16 lanes | pair table during the cull (<= 896 pairs)
+#define S16_NP_ML (S16_U + 1584)  // [14] hit indices of this env's MPR (generic convex) pairs
+#define S16_NP_MS (S16_U + 1598)  // [14][7] their contacts n(3) x(3) sep, staged until the record offsets are known
+#define S16_MAX_MPR 14
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
@@ -138,6 +139,33 @@ MS_DEV unsigned slot_lane_mask(const float* L, int sl, int n) {
   if (sl >= S16_PT_LINK && sl < S16_PT_FREE) return reinterpret_cast<const unsigned*>(L)[S16_ANC + sl - S16_PT_LINK];
   if (sl >= S16_PT_FREE && sl < S16_PT_KIN) return 0x3Fu << (n + 6 * (sl - S16_PT_FREE));
   return 0u;
+}
+// separating-axis test of two oriented boxes (rotations RA / RB, half extents ha / hb, d = centre B -
+// centre A), radii enlarged by `margin`; true = certainly apart (Gottschalk et al., OBBTree)
+MS_DEV bool obb_separated(const m3& RA, f3 ha, const m3& RB, f3 hb, f3 d, float margin) {
+  float R[3][3], AR[3][3];
+  const float t[3] = {dot(mcol(RA, 0), d), dot(mcol(RA, 1), d), dot(mcol(RA, 2), d)};
+  const float a[3] = {ha.x, ha.y, ha.z}, b[3] = {hb.x, hb.y, hb.z};
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { R[i][j] = dot(mcol(RA, i), mcol(RB, j)); AR[i][j] = fabsf(R[i][j]) + 1e-6f; }
+  bool sep = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) sep = sep || fabsf(t[i]) > a[i] + b[0] * AR[i][0] + b[1] * AR[i][1] + b[2] * AR[i][2] + margin;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    sep = sep || fabsf(t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j]) > b[j] + a[0] * AR[0][j] + a[1] * AR[1][j] + a[2] * AR[2][j] + margin;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float ra = a[i1] * AR[i2][j] + a[i2] * AR[i1][j];
+      const float rb = b[j1] * AR[i][j2] + b[j2] * AR[i][j1];
+      sep = sep || fabsf(t[i2] * R[i1][j] - t[i1] * R[i2][j]) > ra + rb + margin;
+    }
+  return sep;
 }
 // world shape from the LDS shape table of one env
 MS_DEV shape_t shape_from_table(const DevModel& M, const float* t) {
@@ -273,7 +301,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // fetched per substep rather than held in registers over the whole step)
       pose_t shF[2];
       float shP[2][3], shBr[2], shMu[2];
-      f3 shBc[2];
+      f3 shBc[2], shH[2];
       unsigned shPk[2];
       int shSlot[2];
       {
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         for (int k = 0; k < 2; k++) {
           const int s = c + 16 * k;
           shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
-          shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
+          shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shH[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
           if (s < M.n_shape) {
             const int slot = M.shape_env_slot[s];
             if (slot < 0) {
@@ -289,6 +317,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
               shP[k][0] = M.shape_param[4 * s]; shP[k][1] = M.shape_param[4 * s + 1]; shP[k][2] = M.shape_param[4 * s + 2];
               shBc[k] = f3{M.shape_center[3 * s], M.shape_center[3 * s + 1], M.shape_center[3 * s + 2]};
               shBr[k] = M.shape_bound[4 * s + 3];
+              shH[k] = f3{M.shape_half[3 * s], M.shape_half[3 * s + 1], M.shape_half[3 * s + 2]};
             } else {
               shF[k] = pose_soa(M.env_shape_frame, 7 * slot, N, e);
               const float* pp = M.env_shape_param + (size_t)(4 * slot) * N + e;
@@ -296,6 +325,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
               const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
               shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
               shBr[k] = bb[3 * (size_t)N];
+              // per-env shapes are primitives centred on their frame: box of the type's extents
+              const int ty = M.shape_type[s];
+              shH[k] = ty == SH_BOX ? f3{shP[k][0], shP[k][1], shP[k][2]}
+                     : ty == SH_SPHERE ? f3{shP[k][0], shP[k][0], shP[k][0]}
+                     : ty == SH_CAPSULE ? f3{shP[k][1] + shP[k][0], shP[k][0], shP[k][0]}
+                     : f3{shP[k][1], shP[k][0], shP[k][0]};
             }
             shMu[k] = M.shape_material[4 * s + 1];
             shSlot[k] = pose_slot(M.shape_kind[s], M.shape_index[s]);
@@ -318,12 +353,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           if (shSlot[k] >= 0) P = lds_pose(L + S16_PT + 7 * shSlot[k]);
           const pose_t W = pmul(P, shF[k]);
           const f3 bcw = P.p + qrot(P.q, shBc[k]);
-          float* o = L + S16_NP_SHP + 16 * s;
+          float* o = L + S16_NP_SHP + S16_SHP * s;
           lds_pose_store(o, W);
           o[7] = shP[k][0]; o[8] = shP[k][1]; o[9] = shP[k][2];
           o[10] = bcw.x; o[11] = bcw.y; o[12] = bcw.z; o[13] = shBr[k];
           o[14] = __uint_as_float(shPk[k]);
           o[15] = shMu[k];
+          o[16] = shH[k].x; o[17] = shH[k].y; o[18] = shH[k].z; o[19] = 0.f;
         }
       }
       __syncthreads();
@@ -335,32 +371,27 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         bool surv = false;
         const int sa = sab & 0xFF, sb = (sab >> 8) & 0xFF;
         if (sab >= 0) {
-          const float* ta_ = L + S16_NP_SHP + 16 * sa;
-          const float* tb_ = L + S16_NP_SHP + 16 * sb;
-          const int ta = (int)(__float_as_uint(ta_[14]) & 7u), tb = (int)(__float_as_uint(tb_[14]) & 7u);
+          const float* ta_ = L + S16_NP_SHP + S16_SHP * sa;
+          const float* tb_ = L + S16_NP_SHP + S16_SHP * sb;
+          const int ta = (int)(__float_as_uint(ta_[14]) & 7u);
           const f3 cb = f3{tb_[10], tb_[11], tb_[12]};
           const float ra = ta_[13], rb = tb_[13];
-          f3 ca = f3{0, 0, 0};
           bool cull;
           if (ta == SH_PLANE) {
             const m3 R = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]});
             cull = dot(mcol(R, 0), cb - f3{ta_[0], ta_[1], ta_[2]}) > rb + M.contact_offset;
           } else {
-            ca = f3{ta_[10], ta_[11], ta_[12]};
+            const f3 ca = f3{ta_[10], ta_[11], ta_[12]};
             const f3 d = cb - ca;
             const float rr = ra + rb + M.contact_offset;
             cull = dot(d, d) > rr * rr;
-          }
-          // tighter, still conservative: the other shape's bounding sphere against an oriented box
-          if (!cull && ta == SH_BOX) {
-            const shape_t A = shape_from_table(M, ta_);
-            const float rr = rb + M.contact_offset;
-            cull = point_box_dist2(A, cb) > rr * rr;
-          }
-          if (!cull && tb == SH_BOX && ta != SH_PLANE) {
-            const shape_t B = shape_from_table(M, tb_);
-            const float rr = ra + M.contact_offset;
-            cull = point_box_dist2(B, ca) > rr * rr;
+            // oriented boxes of both shapes (15-axis separating-axis test, contact offset added to the
+            // radii): discards the pairs whose bounding spheres overlap but whose shapes are apart --
+            // most of the hull pairs that would otherwise run a full MPR only to find no contact
+            if (!cull) {
+              const m3 RA = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]}), RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
+              cull = obb_separated(RA, f3{ta_[16], ta_[17], ta_[18]}, RB, f3{tb_[16], tb_[17], tb_[18]}, d, M.contact_offset);
+            }
           }
           surv = !cull;
         }
@@ -393,8 +424,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           bool is_mpr = false;
           if (idx < nh) {
             const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
-            const int ta = (int)(__float_as_uint(L[S16_NP_SHP + 16 * ((pk >> 16) & 0xFF) + 14]) & 7u);
-            const int tb = (int)(__float_as_uint(L[S16_NP_SHP + 16 * ((pk >> 24) & 0xFF) + 14]) & 7u);
+            const int ta = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 14]) & 7u);
+            const int tb = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]) & 7u);
             is_mpr = !(ta == SH_PLANE || (ta == SH_BOX && tb == SH_BOX));
           }
           const unsigned m16 = (unsigned)(__ballot(is_mpr) >> (16 * g)) & 0xFFFFu;
@@ -424,8 +455,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           float* Lg = sm + ge * S16_ENV_FLOATS;
           const int idx = reinterpret_cast<const int*>(Lg)[S16_NP_ML + k];
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
-          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 16) & 0xFF));
-          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF));
+          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
+          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
           SupCoop16 sup;
           sup.c = c;
           SupCoop16::load_one(sup.va, A, c);
@@ -462,8 +493,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         int pk = 0;
         if (has) {
           pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
-          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 16) & 0xFF));
-          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + 16 * ((pk >> 24) & 0xFF));
+          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
+          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
           PH_ADD(27, __popcll(__ballot(A.type == SH_PLANE)));
           PH_ADD(28, __popcll(__ballot(A.type == SH_BOX && B.type == SH_BOX)));
           PH(10);
@@ -479,9 +510,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           int off = 0;
           for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(Lg)[S16_NP_CNT + j];
           const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
-          const float mu = 0.5f * (Lg[S16_NP_SHP + 16 * sa + 15] + Lg[S16_NP_SHP + 16 * sb + 15]);
-          const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) - 1, n) |
-                                   (slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) - 1, n) << 16));
+          const float mu = 0.5f * (Lg[S16_NP_SHP + S16_SHP * sa + 15] + Lg[S16_NP_SHP + S16_SHP * sb + 15]);
+          const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
+                                   (slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16));
 #pragma unroll
           for (int k = 0; k < 4; k++)
             if (k < m.count && off + k < MAXC) {
@@ -511,9 +542,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             for (int q = 0; q < 6; q++) r[q] = o[q];
             r[6] = o[6] - M.rest_offset;
             r[7] = __int_as_float(pk & 0xFFFF);
-            r[8] = __int_as_float((int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + 16 * sa + 14]) >> 10) & 31u) - 1, n) |
-                                        (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + 16 * sb + 14]) >> 10) & 31u) - 1, n) << 16)));
-            r[9] = 0.5f * (L[S16_NP_SHP + 16 * sa + 15] + L[S16_NP_SHP + 16 * sb + 15]);
+            r[8] = __int_as_float((int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
+                                        (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16)));
+            r[9] = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
           }
         }
       }
