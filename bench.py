@@ -65,7 +65,9 @@ def timed_steps(env, steps, gather, barrier):
         a = 2 * torch.rand((N, 8), device=dev) - 1
         obs, rew, term, trunc, info = env.step(a)
         if gather is not None:
-            gather(obs, rew, term | trunc)
+            gather.start(obs, rew, term | trunc)  # one packed RCCL all-gather per step, overlapping the next step
+    if gather is not None:
+        gather.result()  # the last collective has to be complete inside the timed region
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     barrier()
@@ -150,7 +152,7 @@ def main():
     for _ in range(args.warmup):
         o, r, te, tr, _ = env.step(2 * torch.rand((n, 8), device=dev) - 1)
         if gather is not None:
-            gather(o, r, te | tr)
+            gather.start(o, r, te | tr)
     env.reset(seed=seeds)
     px = base.scene.px
     px.profile_enable(True)
@@ -196,7 +198,7 @@ def main():
                 "15+1 solver iterations, random actions 2*U-1, no resets inside the timed region",
                 "envs_per_gpu": n,
                 "substeps": substeps,
-                "parallelism": f"env-sharded x{world}, no in-step collective" + (", RCCL all-gather of obs/reward/done per step" if gather is not None else ""),
+                "parallelism": f"env-sharded x{world}, no in-step collective" + (", one packed RCCL all-gather of obs/reward/done per step (asynchronous, overlaps the next step)" if gather is not None else ""),
                 "solver_overflow_envs": overflow,
             },
             "roofline": {

@@ -27,9 +27,18 @@ obs, _ = env.reset(seed=seeds)
 g = torch.Generator().manual_seed(0)
 acts = [2 * torch.rand(n * world, 8, generator=g) - 1 for _ in range(3)]
 gather = StepGather(n, obs.shape[1], "cpu")
-for a in acts:
+pending = None
+for i, a in enumerate(acts):
     obs, rew, te, tr, _ = env.step(a[rank * n:(rank + 1) * n])
-    O, R, D = gather(obs, rew, te | tr)
+    if i == 0:
+        O, R, D = gather(obs, rew, te | tr)          # synchronous form
+    else:
+        b = gather.start(obs, rew, te | tr)          # pipelined form: the collective of step i is only
+        if pending is not None:                      # collected after step i + 1 has been issued
+            gather.result(pending)
+        pending = b
+O, R, D = gather.result(pending)
+assert D.dtype == torch.bool and D.shape == (n * world,)
 if rank == 0:
     torch.save(dict(obs=O.clone(), rew=R.clone()), os.environ["MS_OUT"])
 dist.barrier()
