@@ -49,7 +49,7 @@
 #define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
 #define S16_LIMW (S16_U)       // [16][16] W = A^-1 J^T of the joint-limit rows
 #define S16_CS (S16_U + 256)   // [MAXC][16] block scalars of every contact: 1/d0 bias+ bias- mu | 1/d1 k10 1/d2 k20 | k21 lam0 lam1 lam2 | pair
-#define S16_REGC 16            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
+#define S16_REGC 12            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
 #define S16_LDSC 7             // next contacts: J | W rows in LDS; the rest stream from the per-env global scratch
 #define S16_JWLEN 96           // 3 x (J[16] W[16]) of one contact
 #define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][96]
@@ -282,6 +282,16 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     if (art) lds_pose_store(L + S16_BP + 7 * c, bp_c);
     if (c < nf) lds_pose_store(L + S16_PT + 7 * (S16_PT_FREE + c), pose_soa(S.free_s, 13 * c, N, e));
     if (FUSED && c < M.n_kin) lds_pose_store(L + S16_PT + 7 * (S16_PT_KIN + c), pose_soa(S.kin, 7 * c, N, e));
+  }
+  // previous step's hit list (pairs whose dense pair_cnt entry must be cleared if they are no longer
+  // in contact after this step): lane c holds entries c, c + 16, c + 32. Read here, at the start, so
+  // that the two dependent global loads are long done when the impulse phase needs them.
+  int nold = 0, oldp[3] = {-1, -1, -1};
+  if (FUSED) {
+    nold = S.hit_list[e];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (c + 16 * k < nold) oldp[k] = S.hit_list[(size_t)(1 + c + 16 * k) * N + e];
   }
   __syncthreads();
   PH(0);
@@ -1112,13 +1122,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // previous step's hit list that are no longer in contact are zeroed, the new list is written
       int* const newl = reinterpret_cast<int*>(L + S16_VEC);  // up to MAXC pair ids
       int nnew = 0;
-      int nold = 0, oldp[3] = {-1, -1, -1};  // previous list, lane c holds entries c, c + 16, c + 32
-      if (FUSED) {
-        nold = S.hit_list[e];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-          if (c + 16 * k < nold) oldp[k] = S.hit_list[(size_t)(1 + c + 16 * k) * N + e];
-      }
       int prev_p = -1, run = 0;
       f3 acc = f3{0, 0, 0};
       auto flush = [&]() __attribute__((always_inline)) {
