@@ -1492,7 +1492,8 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
   if (h->fused && n_substeps > 0) {
     prof_mark(h, 0, st);
-    hipLaunchKernelGGL(k_solve16<true>, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, (int)n_substeps);
+    if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<true, 9>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, (int)n_substeps);
+    else hipLaunchKernelGGL((k_solve16<true, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, (int)n_substeps);
     prof_mark(h, 0, st);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1504,7 +1505,7 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
       prof_mark(h, 1, st);
     }
     prof_mark(h, 0, st);
-    if (h->coop) hipLaunchKernelGGL(k_solve16<false>, env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, 1);
+    if (h->coop) hipLaunchKernelGGL((k_solve16<false, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, 1);
     else if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     else hipLaunchKernelGGL(k_solve<TopoDyn>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);

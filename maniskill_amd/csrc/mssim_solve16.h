@@ -231,7 +231,9 @@ struct SupCoop16 {
   }
 };
 
-template <bool FUSED>
+// NDOF > 0: the number of joints is a compile-time constant (9 for the Panda), so the loops over the
+// joints are unrolled and their masks folded; NDOF = 0 reads it from the model.
+template <bool FUSED, int NDOF = 0>
 __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S, int n_sub) {
   __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   const int N = S.N;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   const bool live = e_raw < N;
   const int e = live ? e_raw : N - 1;  // dead groups shadow the last env and never store
   float* L = sm + g * S16_ENV_FLOATS;
-  const int n = M.n_dof, nf = M.n_free;
+  const int n = NDOF > 0 ? NDOF : M.n_dof, nf = M.n_free;
   const float dt = M.dt;
   const f3 g3 = f3{M.gx, M.gy, M.gz};
   const bool art = c < n;
