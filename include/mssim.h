@@ -246,6 +246,8 @@ typedef struct mssim_pick_task {
   float min_force;            /* 0.5 N */
   float max_angle_deg;        /* 85    */
   float reward_scale;         /* 1 (dense) or 1/5 (normalized_dense) */
+  int32_t* elapsed_steps;     /* optional device [N]: incremented in place (BaseEnv.step, sapien_env.py:951) ... */
+  int32_t* elapsed_out;       /* ... and the new value copied here (info["elapsed_steps"], sapien_env.py:739)      */
 } mssim_pick_task;
 /* obs [N][2*n_dof+24] f32 (qpos, qvel, is_grasped, tcp_pose7, goal_pos3, obj_pose7, tcp_to_obj3,
  * obj_to_goal3), reward [N] f32, flags [N][4] u8 = success, is_obj_placed, is_robot_static, is_grasped */
@@ -259,6 +261,8 @@ typedef struct mssim_push_task {
   float goal_radius;                  /* 0.1  */
   float cube_half_size;               /* 0.02 */
   float reward_scale;                 /* 1 (dense) or 1/3 (normalized_dense) */
+  int32_t* elapsed_steps;             /* optional, as in mssim_pick_task */
+  int32_t* elapsed_out;
 } mssim_push_task;
 int MSSIM_FN(task_push_outputs)(mssim_handle h, const mssim_push_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
 

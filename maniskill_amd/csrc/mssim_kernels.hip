@@ -1057,8 +1057,8 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
 }
 
 // PickCube-style evaluate / obs / reward
-__global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_task T, float* __restrict__ obs, float* __restrict__ reward,
-                            uint8_t* __restrict__ flags) {
+__global__ __launch_bounds__(64) void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_task T, const int* __restrict__ pairs, int npairs,
+                                                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags) {
   const int N = S.N;
   int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= N) return;
@@ -1077,18 +1077,16 @@ __global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_
   const float* ob = rowp(T.obj_row);
   const float* gl = rowp(T.goal_row);
   const f3 ptcp = f3{tcp[0], tcp[1], tcp[2]}, pobj = f3{ob[0], ob[1], ob[2]}, pgoal = f3{gl[0], gl[1], gl[2]};
-  // pairwise contact impulses finger <-> object during the last substep (scene.py:736-796)
+  // pairwise contact impulses finger <-> object during the last substep (scene.py:736-796); the few
+  // candidate pairs are listed by the host: entry = pair | finger (bit 30: 0 left, 1 right) | object is shape A (bit 31)
   f3 lf = f3{0, 0, 0}, rf = f3{0, 0, 0};
-  for (int p = 0; p < M.n_pair; p++) {
-    const int ra = M.shape_row[M.pair_shape[2 * p]], rb = M.shape_row[M.pair_shape[2 * p + 1]];
-    const bool a_obj = ra == T.obj_row, b_obj = rb == T.obj_row;
-    if (!(a_obj || b_obj)) continue;
-    const int other = a_obj ? rb : ra;
-    if (other != T.finger1_row && other != T.finger2_row) continue;
+  for (int k = 0; k < npairs; k++) {
+    const unsigned ent = (unsigned)pairs[k];
+    const int p = (int)(ent & 0x3FFFFFFFu);
     if (S.pair_cnt[(size_t)p * N + e] <= 0) continue;
     // impulse on the finger from the object: +imp if the finger is shape A, -imp otherwise
-    f3 imp = f3{SOA(S.pair_imp, 3 * p), SOA(S.pair_imp, 3 * p + 1), SOA(S.pair_imp, 3 * p + 2)} * (a_obj ? -1.f : 1.f);
-    if (other == T.finger1_row) lf += imp; else rf += imp;
+    f3 imp = f3{SOA(S.pair_imp, 3 * p), SOA(S.pair_imp, 3 * p + 1), SOA(S.pair_imp, 3 * p + 2)} * ((ent >> 31) ? -1.f : 1.f);
+    if ((ent >> 30) & 1u) rf += imp; else lf += imp;
   }
   const float inv_dt = 1.f / M.dt;
   lf = lf * inv_dt; rf = rf * inv_dt;
@@ -1123,6 +1121,7 @@ __global__ void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_
   reward[e] = r * T.reward_scale;
   uint8_t* f = flags + 4 * (size_t)e;
   f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
+  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
 
 __global__ void k_task_push(DevModel M, DevState S, mssim_buffers B, mssim_push_task T, float* __restrict__ obs, float* __restrict__ reward,
@@ -1155,6 +1154,7 @@ __global__ void k_task_push(DevModel M, DevState S, mssim_buffers B, mssim_push_
   if (success) r = 3.f;
   reward[e] = r * T.reward_scale;
   flags[e] = success;
+  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
 
 // geometric Jacobian of link `link` in the root frame: out [N][6][n_dof] (see include/mssim.h)
@@ -1203,6 +1203,8 @@ struct mssim_sim {
   float* d_drive = nullptr;
   bool panda = false;
   bool dirty = true;
+  std::vector<int32_t> h_shape_row, h_pair_shape;  // host copies (contact-pair lists of the task epilogues)
+  int* d_pick_pairs = nullptr; int n_pick_pairs = 0; int pick_rows[3] = {-1, -1, -1};
   std::vector<int*> queries;
   std::vector<int> query_n;
   std::vector<int> query_kind;
@@ -1295,6 +1297,8 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   UP(dof_frame, 7 * n) UP(dof_axis, 3 * n) UP(dof_limit, 2 * n) UP(dof_drive, 4 * n) UP(dof_armature, n) UP(body_inertial, 10 * n)
   UP(tendon_param, 5 * d->n_tendon) UP(link_frame, 7 * d->n_link) UP(free_inertial, 10 * d->n_free) UP(free_damping, 2 * d->n_free)
   UP(shape_type, ns) UP(shape_row, ns) UP(pair_shape, 2 * d->n_pair)
+  S->h_shape_row.assign(d->shape_row, d->shape_row + ns);
+  S->h_pair_shape.assign(d->pair_shape, d->pair_shape + 2 * (size_t)d->n_pair);
   UP(shape_frame, 7 * ns) UP(shape_param, 4 * ns) UP(shape_material, 4 * ns) UP(shape_bound, 4 * ns)
 #undef UP
   {
@@ -1582,7 +1586,24 @@ int mssim_task_pick_outputs(mssim_handle h, const mssim_pick_task* task, float* 
   for (int r : rows)
     if (r < 0 || r >= R) { h->err = "task_pick_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
-  hipLaunchKernelGGL(k_task_pick, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, obs, reward, flags);
+  if (h->pick_rows[0] != task->obj_row || h->pick_rows[1] != task->finger1_row || h->pick_rows[2] != task->finger2_row || !h->d_pick_pairs) {
+    // candidate finger <-> object pairs (a handful of the ~100 pairs of the scene)
+    std::vector<int32_t> lst;
+    for (int p = 0; p < h->M.n_pair; p++) {
+      const int ra = h->h_shape_row[h->h_pair_shape[2 * p]], rb = h->h_shape_row[h->h_pair_shape[2 * p + 1]];
+      const bool a_obj = ra == task->obj_row, b_obj = rb == task->obj_row;
+      if (!(a_obj || b_obj)) continue;
+      const int other = a_obj ? rb : ra;
+      if (other != task->finger1_row && other != task->finger2_row) continue;
+      lst.push_back((int32_t)((unsigned)p | (other == task->finger2_row ? 1u << 30 : 0u) | (a_obj ? 1u << 31 : 0u)));
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->d_pick_pairs) { HIPCHK(h, hipMalloc((void**)&h->d_pick_pairs, sizeof(int32_t) * (h->M.n_pair > 0 ? h->M.n_pair : 1))); h->allocs.push_back(h->d_pick_pairs); }
+    if (!lst.empty()) HIPCHK(h, hipMemcpy(h->d_pick_pairs, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
+    h->n_pick_pairs = (int)lst.size();
+    h->pick_rows[0] = task->obj_row; h->pick_rows[1] = task->finger1_row; h->pick_rows[2] = task->finger2_row;
+  }
+  hipLaunchKernelGGL(k_task_pick, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

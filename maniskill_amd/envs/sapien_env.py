@@ -452,14 +452,16 @@ class BaseEnv(gym.Env):
     # ------------------------------------------------------------------ step
     def step(self, action: Union[None, np.ndarray, torch.Tensor, Dict]):
         action = self._step_action(action)
-        self._elapsed_steps += 1
+        # the fused task epilogue also advances `_elapsed_steps` (one launch instead of add + copy)
         fused = self._fused_step_outputs(action) if self._use_fused_callers else None
         if fused is not None:
             obs, reward, info = fused
-        else:
-            info = self.get_info()
-            obs = self.get_obs(info)
-            reward = self.get_reward(obs=obs, action=action, info=info)
+            # `success` is a fresh tensor of this step and there is no `fail`: no copies needed
+            return obs, reward, info["success"], self._no_truncation(), info
+        self._elapsed_steps += 1
+        info = self.get_info()
+        obs = self.get_obs(info)
+        reward = self.get_reward(obs=obs, action=action, info=info)
         if "success" in info:
             terminated = torch.logical_or(info["success"], info["fail"]) if "fail" in info else info["success"].clone()
         elif "fail" in info:
@@ -467,6 +469,14 @@ class BaseEnv(gym.Env):
         else:
             terminated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         return obs, reward, terminated, torch.zeros(self.num_envs, dtype=torch.bool, device=self.device), info
+
+    def _no_truncation(self) -> torch.Tensor:
+        """all-False `truncated` of the fused step path (time limits are applied by TimeLimitWrapper);
+        one cached tensor instead of a fill kernel per step -- treat it as read-only"""
+        t = getattr(self, "_false_flags", None)
+        if t is None or t.shape[0] != self.num_envs or t.device != self.device:
+            t = self._false_flags = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        return t
 
     def _substep_hooks_overridden(self) -> bool:
         cls = type(self)

@@ -149,7 +149,9 @@ class PickCubeEnv(BaseEnv):
         obs = torch.empty((N, D), dtype=torch.float32, device=self.device)
         reward = torch.empty((N,), dtype=torch.float32, device=self.device)
         flags = torch.empty((N, 4), dtype=torch.uint8, device=self.device)
+        es = torch.empty_like(self._elapsed_steps)
+        st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
         px.task_pick_outputs(st["task"], obs, reward, flags)
         fb = flags.view(torch.bool)
-        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fb[:, 0], is_obj_placed=fb[:, 1], is_robot_static=fb[:, 2], is_grasped=fb[:, 3])
+        info = dict(elapsed_steps=es, success=fb[:, 0], is_obj_placed=fb[:, 1], is_robot_static=fb[:, 2], is_grasped=fb[:, 3])
         return obs, reward, info

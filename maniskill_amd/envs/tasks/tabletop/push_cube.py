@@ -119,5 +119,7 @@ class PushCubeEnv(BaseEnv):
         obs = torch.empty((N, D), dtype=torch.float32, device=self.device)
         reward = torch.empty((N,), dtype=torch.float32, device=self.device)
         flags = torch.empty((N, 1), dtype=torch.uint8, device=self.device)
+        es = torch.empty_like(self._elapsed_steps)
+        st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
         px.task_push_outputs(st["task"], obs, reward, flags)
-        return obs, reward, dict(elapsed_steps=self._elapsed_steps.clone(), success=flags.view(torch.bool)[:, 0])
+        return obs, reward, dict(elapsed_steps=es, success=flags.view(torch.bool)[:, 0])

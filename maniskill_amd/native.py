@@ -131,13 +131,13 @@ class PickTask(C.Structure):
     _fields_ = [
         ("tcp_row", C.c_int32), ("obj_row", C.c_int32), ("goal_row", C.c_int32), ("finger1_row", C.c_int32), ("finger2_row", C.c_int32),
         ("n_static_dofs", C.c_int32), ("goal_thresh", C.c_float), ("static_thresh", C.c_float), ("min_force", C.c_float),
-        ("max_angle_deg", C.c_float), ("reward_scale", C.c_float),
+        ("max_angle_deg", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p),
     ]
 
 
 class PushTask(C.Structure):
     _fields_ = [("tcp_row", C.c_int32), ("obj_row", C.c_int32), ("goal_row", C.c_int32), ("goal_radius", C.c_float),
-                ("cube_half_size", C.c_float), ("reward_scale", C.c_float)]
+                ("cube_half_size", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p)]
 
 
 class NativeError(RuntimeError):
