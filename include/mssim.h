@@ -266,6 +266,24 @@ typedef struct mssim_push_task {
 } mssim_push_task;
 int MSSIM_FN(task_push_outputs)(mssim_handle h, const mssim_push_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
 
+/* PegInsertionSide-style evaluate + state observation + dense reward in one launch
+ * (envs/tasks/tabletop/peg_insertion_side.py:247-355). Per-env geometry comes as device arrays.
+ * obs [N][2*n_dof+25] f32 (qpos, qvel, tcp_pose7, peg_pose7, peg_half_size3, box_hole_pose7,
+ * box_hole_radius), reward [N] f32, flags [N][1] u8 = success, head_at_hole [N][3] f32 = peg head in the
+ * hole frame (info["peg_head_pos_at_hole"]) */
+typedef struct mssim_peg_task {
+  int32_t tcp_row, peg_row, box_row, finger1_row, finger2_row; /* rigid_body_data body rows */
+  float min_force;            /* 0.5 N */
+  float max_angle_deg;        /* 20    */
+  float reward_scale;         /* 1 (dense) or 1/10 (normalized_dense) */
+  const float* peg_half_sizes;   /* device [N][3] */
+  const float* box_hole_offsets; /* device [N][3]: hole centre in the box frame */
+  const float* box_hole_radii;   /* device [N]    */
+  int32_t* elapsed_steps;     /* optional, as in mssim_pick_task */
+  int32_t* elapsed_out;
+} mssim_peg_task;
+int MSSIM_FN(task_peg_outputs)(mssim_handle h, const mssim_peg_task* task, float* obs, float* reward, uint8_t* flags, float* head_at_hole, void* stream);
+
 /* Geometric Jacobian of an articulation link at the CURRENT simulation state, for the end-effector
  * controllers (agents/controllers/pd_ee_pose.py:96-121, controllers/utils/kinematics.py:156-171, where
  * the reference calls pytorch_kinematics' `chain.jacobian`): out [N][6][n_dof] f32, rows 0-2 linear

@@ -1157,6 +1157,91 @@ __global__ void k_task_push(DevModel M, DevState S, mssim_buffers B, mssim_push_
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
 
+// Pose algebra exactly as the Python `Pose` class does it (utils/structs/pose.py, rotation_conversions.py:
+// no re-normalisation, rotation as p + w t + v x t with t = 2 v x p, product standardised to w >= 0), so
+// that the fused task outputs equal the torch path also for the slightly non-unit quaternions users set
+MS_DEV f3 tq_apply(q4 q, f3 p) {
+  const f3 v = f3{q.x, q.y, q.z};
+  const f3 t = cross(v, p) * 2.f;
+  return p + t * q.w + cross(v, t);
+}
+MS_DEV pose_t tq_mul(pose_t a, pose_t b) {
+  q4 q = qmul(a.q, b.q);
+  if (q.w < 0.f) q = q4{-q.w, -q.x, -q.y, -q.z};
+  return pose_t{a.p + tq_apply(a.q, b.p), q};
+}
+MS_DEV pose_t tq_inv(pose_t a) {
+  const q4 qc = q4{a.q.w, -a.q.x, -a.q.y, -a.q.z};
+  return pose_t{tq_apply(qc, -a.p), qc};
+}
+// PegInsertionSide evaluate / obs / reward (peg_insertion_side.py:247-355)
+__global__ __launch_bounds__(64) void k_task_peg(DevModel M, DevState S, mssim_buffers B, mssim_peg_task T, const int* __restrict__ pairs, int npairs,
+                                                  float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, float* __restrict__ head_out) {
+  const int N = S.N;
+  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const int n = M.n_dof;
+  float* o = obs + (size_t)e * (2 * n + 25);
+  auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
+  auto rowpose = [&](int row) { const float* r = rowp(row); return pose_t{f3{r[0], r[1], r[2]}, q4{r[3], r[4], r[5], r[6]}}; };
+  for (int j = 0; j < n; j++) {
+    o[j] = B.art_qpos[(size_t)e * n + j];
+    o[n + j] = B.art_qvel[(size_t)e * n + j];
+  }
+  const float* tcp = rowp(T.tcp_row);
+  const float* pg = rowp(T.peg_row);
+  const pose_t Ptcp = rowpose(T.tcp_row), Ppeg = rowpose(T.peg_row), Pbox = rowpose(T.box_row);
+  const f3 hs = f3{T.peg_half_sizes[3 * e], T.peg_half_sizes[3 * e + 1], T.peg_half_sizes[3 * e + 2]};
+  const f3 hoff = f3{T.box_hole_offsets[3 * e], T.box_hole_offsets[3 * e + 1], T.box_hole_offsets[3 * e + 2]};
+  const float rad = T.box_hole_radii[e];
+  const q4 qi = q4{1, 0, 0, 0};
+  const pose_t head = tq_mul(Ppeg, pose_t{f3{hs.x, 0, 0}, qi});      // peg head (orange end)
+  const pose_t hole = tq_mul(Pbox, pose_t{hoff, qi});                 // hole centre frame
+  const f3 hah = tq_mul(tq_inv(hole), head).p;                          // head in the hole frame
+  const bool success = hah.x >= -0.015f && fabsf(hah.y) <= rad && fabsf(hah.z) <= rad;
+  // finger <-> peg contact forces of the last substep (Panda.is_grasping, panda.py:236-264)
+  f3 lf = f3{0, 0, 0}, rf = f3{0, 0, 0};
+  for (int k = 0; k < npairs; k++) {
+    const unsigned ent = (unsigned)pairs[k];
+    const int p = (int)(ent & 0x3FFFFFFFu);
+    if (S.pair_cnt[(size_t)p * N + e] <= 0) continue;
+    f3 imp = f3{SOA(S.pair_imp, 3 * p), SOA(S.pair_imp, 3 * p + 1), SOA(S.pair_imp, 3 * p + 2)} * ((ent >> 31) ? -1.f : 1.f);
+    if ((ent >> 30) & 1u) rf += imp; else lf += imp;
+  }
+  const float inv_dt = 1.f / M.dt;
+  lf = lf * inv_dt; rf = rf * inv_dt;
+  auto yaxis = [&](int row) { return mcol(qmat(qnormalized(rowpose(row).q)), 1); };
+  auto angle_deg = [&](f3 a, f3 b) {
+    const float na = norm(a), nb = norm(b);
+    a = a * (1.f / (na < 1e-6f ? 1.f : na));
+    b = b * (1.f / (nb < 1e-6f ? 1.f : nb));
+    return acosf(fminf(fmaxf(dot(a, b), -1.f), 1.f)) * 57.29577951308232f;
+  };
+  const f3 ldir = yaxis(T.finger1_row), rdir = -yaxis(T.finger2_row);
+  const bool grasped = norm(lf) >= T.min_force && angle_deg(ldir, lf) <= T.max_angle_deg && norm(rf) >= T.min_force && angle_deg(rdir, rf) <= T.max_angle_deg;
+  // observation
+  int k = 2 * n;
+  for (int i = 0; i < 7; i++) o[k++] = tcp[i];
+  for (int i = 0; i < 7; i++) o[k++] = pg[i];
+  o[k++] = hs.x; o[k++] = hs.y; o[k++] = hs.z;
+  o[k++] = hole.p.x; o[k++] = hole.p.y; o[k++] = hole.p.z; o[k++] = hole.q.w; o[k++] = hole.q.x; o[k++] = hole.q.y; o[k++] = hole.q.z;
+  o[k++] = rad;
+  // dense reward
+  const f3 grasp_target = tq_mul(Ppeg, pose_t{f3{-0.06f, 0, 0}, qi}).p;
+  float r = 1.f - tanhf(4.f * norm(Ptcp.p - grasp_target));
+  if (grasped) r += 1.f;
+  const pose_t goal_inv = tq_inv(tq_mul(hole, pose_t{f3{-hs.x, 0, 0}, qi}));   // goal = box * hole_offset * head_offset^-1
+  const f3 hg = tq_mul(goal_inv, head).p, bg = tq_mul(goal_inv, Ppeg).p;
+  const float head_yz = sqrtf(hg.y * hg.y + hg.z * hg.z), body_yz = sqrtf(bg.y * bg.y + bg.z * bg.z);
+  if (grasped) r += 3.f * (1.f - tanhf(0.5f * (head_yz + body_yz) + 4.5f * fmaxf(head_yz, body_yz)));
+  if (grasped && head_yz < 0.01f && body_yz < 0.01f) r += 5.f * (1.f - tanhf(5.f * norm(hah)));
+  if (success) r = 10.f;
+  reward[e] = r * T.reward_scale;
+  flags[e] = success;
+  head_out[3 * (size_t)e] = hah.x; head_out[3 * (size_t)e + 1] = hah.y; head_out[3 * (size_t)e + 2] = hah.z;
+  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
+}
+
 // geometric Jacobian of link `link` in the root frame: out [N][6][n_dof] (see include/mssim.h)
 __global__ void k_link_jacobian(DevModel M, DevState S, int link, float* __restrict__ out) {
   const int N = S.N;
@@ -1580,29 +1665,47 @@ int mssim_apply_action(mssim_handle h, const float* action, int32_t action_dim, 
   return 0;
 }
 
+// candidate finger <-> object pairs (a handful of the ~100 pairs of the scene) for the task epilogues:
+// entry = pair | finger (bit 30: 0 left, 1 right) | object is shape A (bit 31); cached per (object, fingers)
+static int finger_pair_list(mssim_handle h, int obj_row, int f1_row, int f2_row) {
+  if (h->pick_rows[0] == obj_row && h->pick_rows[1] == f1_row && h->pick_rows[2] == f2_row && h->d_pick_pairs) return 0;
+  std::vector<int32_t> lst;
+  for (int p = 0; p < h->M.n_pair; p++) {
+    const int ra = h->h_shape_row[h->h_pair_shape[2 * p]], rb = h->h_shape_row[h->h_pair_shape[2 * p + 1]];
+    const bool a_obj = ra == obj_row, b_obj = rb == obj_row;
+    if (!(a_obj || b_obj)) continue;
+    const int other = a_obj ? rb : ra;
+    if (other != f1_row && other != f2_row) continue;
+    lst.push_back((int32_t)((unsigned)p | (other == f2_row ? 1u << 30 : 0u) | (a_obj ? 1u << 31 : 0u)));
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_pick_pairs) { HIPCHK(h, hipMalloc((void**)&h->d_pick_pairs, sizeof(int32_t) * (h->M.n_pair > 0 ? h->M.n_pair : 1))); h->allocs.push_back(h->d_pick_pairs); }
+  if (!lst.empty()) HIPCHK(h, hipMemcpy(h->d_pick_pairs, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
+  h->n_pick_pairs = (int)lst.size();
+  h->pick_rows[0] = obj_row; h->pick_rows[1] = f1_row; h->pick_rows[2] = f2_row;
+  return 0;
+}
+
+int mssim_task_peg_outputs(mssim_handle h, const mssim_peg_task* task, float* obs, float* reward, uint8_t* flags, float* head_at_hole, void* stream) {
+  const int R = h->M.n_link + h->M.n_free + h->M.n_kin;
+  const int rows[5] = {task->tcp_row, task->peg_row, task->box_row, task->finger1_row, task->finger2_row};
+  for (int r : rows)
+    if (r < 0 || r >= R) { h->err = "task_peg_outputs: body row out of range"; return 1; }
+  if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
+  if (!task->peg_half_sizes || !task->box_hole_offsets || !task->box_hole_radii || !head_at_hole) { h->err = "task_peg_outputs: missing per-env geometry / output"; return 3; }
+  { int rc = finger_pair_list(h, task->peg_row, task->finger1_row, task->finger2_row); if (rc) return rc; }
+  hipLaunchKernelGGL(k_task_peg, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags, head_at_hole);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int mssim_task_pick_outputs(mssim_handle h, const mssim_pick_task* task, float* obs, float* reward, uint8_t* flags, void* stream) {
   const int R = h->M.n_link + h->M.n_free + h->M.n_kin;
   const int rows[5] = {task->tcp_row, task->obj_row, task->goal_row, task->finger1_row, task->finger2_row};
   for (int r : rows)
     if (r < 0 || r >= R) { h->err = "task_pick_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
-  if (h->pick_rows[0] != task->obj_row || h->pick_rows[1] != task->finger1_row || h->pick_rows[2] != task->finger2_row || !h->d_pick_pairs) {
-    // candidate finger <-> object pairs (a handful of the ~100 pairs of the scene)
-    std::vector<int32_t> lst;
-    for (int p = 0; p < h->M.n_pair; p++) {
-      const int ra = h->h_shape_row[h->h_pair_shape[2 * p]], rb = h->h_shape_row[h->h_pair_shape[2 * p + 1]];
-      const bool a_obj = ra == task->obj_row, b_obj = rb == task->obj_row;
-      if (!(a_obj || b_obj)) continue;
-      const int other = a_obj ? rb : ra;
-      if (other != task->finger1_row && other != task->finger2_row) continue;
-      lst.push_back((int32_t)((unsigned)p | (other == task->finger2_row ? 1u << 30 : 0u) | (a_obj ? 1u << 31 : 0u)));
-    }
-    HIPCHK(h, hipSetDevice(h->device));
-    if (!h->d_pick_pairs) { HIPCHK(h, hipMalloc((void**)&h->d_pick_pairs, sizeof(int32_t) * (h->M.n_pair > 0 ? h->M.n_pair : 1))); h->allocs.push_back(h->d_pick_pairs); }
-    if (!lst.empty()) HIPCHK(h, hipMemcpy(h->d_pick_pairs, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
-    h->n_pick_pairs = (int)lst.size();
-    h->pick_rows[0] = task->obj_row; h->pick_rows[1] = task->finger1_row; h->pick_rows[2] = task->finger2_row;
-  }
+  { int rc = finger_pair_list(h, task->obj_row, task->finger1_row, task->finger2_row); if (rc) return rc; }
   hipLaunchKernelGGL(k_task_pick, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags);
   HIPCHK(h, hipGetLastError());
   return 0;

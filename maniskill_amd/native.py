@@ -140,6 +140,13 @@ class PushTask(C.Structure):
                 ("cube_half_size", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p)]
 
 
+class PegTask(C.Structure):
+    _fields_ = [("tcp_row", C.c_int32), ("peg_row", C.c_int32), ("box_row", C.c_int32), ("finger1_row", C.c_int32), ("finger2_row", C.c_int32),
+                ("min_force", C.c_float), ("max_angle_deg", C.c_float), ("reward_scale", C.c_float),
+                ("peg_half_sizes", C.c_void_p), ("box_hole_offsets", C.c_void_p), ("box_hole_radii", C.c_void_p),
+                ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -180,6 +187,7 @@ class NativeLib:
         f("set_action_map", C.c_int, [H, _I32P, _F32P, _F32P, _I32P])
         f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
         f("task_pick_outputs", C.c_int, [H, C.POINTER(PickTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+        f("task_peg_outputs", C.c_int, [H, C.POINTER(PegTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("task_push_outputs", C.c_int, [H, C.POINTER(PushTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("profile_enable", C.c_int, [H, C.c_int32])
         f("profile_read", C.c_int, [H, _F32P, _I32P])
@@ -192,7 +200,7 @@ class NativeLib:
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
         "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map",
-        "apply_action", "task_pick_outputs", "task_push_outputs", "profile_enable",
+        "apply_action", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
         "profile_read", "last_error",
         "abi_version",
     ]
@@ -307,6 +315,9 @@ class NativeSim:
 
     def apply_action(self, action_ptr, action_dim, stream=None):
         self._check(self.lib.apply_action(self.h, action_ptr, action_dim, stream), "apply_action")
+
+    def task_peg_outputs(self, task: "PegTask", obs_ptr, reward_ptr, flags_ptr, head_ptr, stream=None):
+        self._check(self.lib.task_peg_outputs(self.h, C.byref(task), obs_ptr, reward_ptr, flags_ptr, head_ptr, stream), "task_peg_outputs")
 
     def task_push_outputs(self, task: "PushTask", obs_ptr, reward_ptr, flags_ptr, stream=None):
         self._check(self.lib.task_push_outputs(self.h, C.byref(task), obs_ptr, reward_ptr, flags_ptr, stream), "task_push_outputs")

@@ -302,6 +302,9 @@ class MssimSystem:
         assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs
         self._sim.apply_action(action.data_ptr(), action.shape[1], self._stream())
 
+    def task_peg_outputs(self, task, obs: torch.Tensor, reward: torch.Tensor, flags: torch.Tensor, head: torch.Tensor):
+        self._sim.task_peg_outputs(task, obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), head.data_ptr(), self._stream())
+
     def task_push_outputs(self, task, obs: torch.Tensor, reward: torch.Tensor, flags: torch.Tensor):
         self._sim.task_push_outputs(task, obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), self._stream())
 

@@ -14,7 +14,7 @@ DECLARED = sorted(set(re.findall(r"MSSIM_FN\((\w+)\)\(", HEADER)))
 def test_header_declares_the_expected_surface():
     for name in ("create", "destroy", "bind_buffers", "apply", "fetch", "step", "update_kinematics", "create_pair_query",
                  "query_pair_impulses", "create_body_query", "query_body_impulses", "set_timestep", "get_timestep",
-                 "apply_action", "task_pick_outputs", "task_push_outputs", "link_jacobian", "last_error", "abi_version"):
+                 "apply_action", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "link_jacobian", "last_error", "abi_version"):
         assert name in DECLARED
 
 

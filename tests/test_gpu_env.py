@@ -87,7 +87,7 @@ def test_env_rollout_matches_oracle_backend(env_id):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
 
 
-@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1"])
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1"])
 def test_fused_callers_match_torch_path(monkeypatch, env_id):
     """the fused native action map + task epilogue give the same step outputs as the torch path"""
     import gymnasium as gym
@@ -107,13 +107,19 @@ def test_fused_callers_match_torch_path(monkeypatch, env_id):
             traj.append((obs.cpu().clone(), rew.cpu().clone(), term.cpu().clone(), {k: v.cpu().clone() for k, v in info.items()}))
         outs.append(traj)
         env.close()
+    # (the native action map rounds `low + 0.5 (a + 1)(high - low)` differently from the torch expression by
+    # an ulp, so the two 12-step trajectories drift apart at the 1e-5 level; contact-rich Peg a bit more)
+    tol = 5e-5 if env_id == "PegInsertionSide-v1" else 1e-5
     for (o1, r1, t1, i1), (o2, r2, t2, i2) in zip(*outs):
-        assert torch.allclose(o1, o2, atol=1e-5), (o1 - o2).abs().max()
-        assert torch.allclose(r1, r2, atol=1e-5)
+        assert torch.allclose(o1, o2, atol=tol), (o1 - o2).abs().max()
+        assert torch.allclose(r1, r2, atol=tol)
         assert torch.equal(t1, t2)
         assert i1.keys() == i2.keys()
         for k in i1:
-            assert torch.equal(i1[k], i2[k]), k
+            if i1[k].dtype.is_floating_point:
+                assert torch.allclose(i1[k], i2[k], atol=tol), k
+            else:
+                assert torch.equal(i1[k], i2[k]), k
 
 
 def test_trajectory_recorded_on_oracle_replays_on_hip(tmp_path):
