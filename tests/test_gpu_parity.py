@@ -271,3 +271,20 @@ def test_fused_and_split_kernels_agree(monkeypatch):
     r = model.row_of("cube")
     assert torch.max(torch.abs(a["rb"][r, :, :7] - b["rb"][r, :, :7])[same]) < 2e-5
 
+
+@pytest.mark.parametrize("N", [1, 5, 67])
+def test_env_counts_that_do_not_fill_a_wave(N):
+    """4 envs share a wavefront (16 lanes each) and grids are padded to 8 blocks: env counts that are not
+    multiples of 4 / 32 exercise the shadow groups and the padding blocks"""
+    model = panda_tabletop_model()
+    gpu, cpu = make_pair(model, N)
+    q, qd, tq, cube = random_tabletop_state(N, 13)
+    for px in (gpu, cpu):
+        set_state(px, model, N, q, qd, tq, cube)
+        px.step(5)
+    a, b = get_state(gpu, model, N), get_state(cpu, model, N)
+    ok = (a["cnt"] == b["cnt"]).all(0) & (b["cnt"].sum(0) <= 8)
+    assert ok.float().mean() > 0.5
+    assert torch.max(torch.abs(a["q"] - b["q"])[ok]) < 2e-4
+    assert torch.isfinite(a["rb"]).all() and torch.isfinite(a["q"]).all()
+
