@@ -4,6 +4,6 @@ set -e
 cd "$(dirname "$0")/.."
 for v in "base:" "nostore:-DEXP_NO_FINAL_STORES" "nofk:-DEXP_NO_FK" "it1:-DEXP_ITERS=1" "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-pass-failed $flags \
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-pass-failed -fno-hip-fp32-correctly-rounded-divide-sqrt $flags \
     -o maniskill_amd/_native/libmssim_exp_$name.so maniskill_amd/csrc/mssim_kernels.hip
 done

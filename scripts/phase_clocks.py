@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "maniskill_amd", "_native", "libmssim_clk.so")
 src = os.path.join(ROOT, "maniskill_amd", "csrc", "mssim_kernels.hip")
 if "--build" in sys.argv or not os.path.exists(lib):
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
                     "-DMSSIM_PHASE_CLOCKS", "-o", lib, src], check=True)
     if "--build" in sys.argv:
         sys.exit(0)
