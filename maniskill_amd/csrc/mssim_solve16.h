@@ -848,6 +848,11 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
       }
     }
+    // this lane's velocity component as an axis (+ origin for rotation-like components), see the row build
+    f3 jaxis_c = f3{0, 0, 0}, jorigin_c = f3{0, 0, 0};
+    bool jrot_c = false;
+    if (art) { jaxis_c = aw_c; jorigin_c = an_c; jrot_c = rev_c; }
+    else if (freel) { jaxis_c = f3{(fk % 3) == 0 ? 1.f : 0.f, (fk % 3) == 1 ? 1.f : 0.f, (fk % 3) == 2 ? 1.f : 0.f}; jorigin_c = mycom; jrot_c = fk >= 3; }
     fforce_c = 0.f;  // an applied force acts during one substep only
     __syncthreads();  // the dynamics staging area is dead from here on: rows overlay it
     PH(3);
@@ -889,20 +894,20 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       const int p = __float_as_int(rec[7]);
       const int bodies = __float_as_int(rec[8]);
       const float mu = rec[9];
-      const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
+      // (one cross product and one normalisation: the helper axis is selected, not the result)
+      const bool use_x = fabsf(nrm.x) < 0.57735f;
+      const f3 t1 = normalized(cross(nrm, f3{use_x ? 1.f : 0.f, use_x ? 0.f : 1.f, 0.f}));
       const f3 t2 = cross(nrm, t1);
       // does this lane's component move with side A / side B of the pair? (lane masks in the record)
       const float sgn = (float)((bodies >> c) & 1) - (float)((bodies >> (16 + c)) & 1);
-      // per-lane geometric factor of this contact point
-      f3 col = f3{0, 0, 0};  // articulation lanes: d . col ; free angular lanes: (r x d)_k
-      if (art) col = rev_c ? cross(aw_c, x - an_c) : aw_c;
-      const f3 r = x - mycom;
+      // Every lane's Jacobian entry is axis . d (translation-like: prismatic joint, free linear) or
+      // axis . ((x - origin) x d) (rotation-like: revolute joint about its anchor, free angular about the
+      // centre of mass): one code path for articulation and free-body lanes
+      const f3 rx = x - jorigin_c;
 #pragma unroll
       for (int dk = 0; dk < 3; dk++) {
         const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
-        float J = 0.f;
-        if (art) J = sgn * dot(d, col);
-        else if (freel) J = sgn * (fk < 3 ? comp(d, fk) : comp(cross(r, d), fk - 3));
+        const float J = sgn * dot(jaxis_c, sel3(jrot_c, cross(rx, d), d));
         J3[dk] = ck ? J : 0.f;
       }
       // the three directions at once: one LDS round trip for J -> W = A^-1 J^T
