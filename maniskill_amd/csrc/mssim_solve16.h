@@ -111,6 +111,30 @@ MS_DEV float gsum16(float x) {
   x += dpp_f<0x121>(x);
   return x;
 }
+// three independent 16-lane all-reduces, interleaved, each step ONE v_add_f32_dpp (x += row_ror(x)).
+// Written as inline asm because the compiler pairs the independent adds into v_pk_add_f32, which cannot
+// take a DPP operand, and then needs a separate v_mov_b32_dpp (+ a mov for its `old` operand) per
+// step. Hazard: a VGPR written by a VALU op may be read by a DPP op only 2 wait states later -- inside the
+// block two other instructions always sit between a write and the next read of the same register; the
+// leading s_nop covers the producers of the inputs.
+MS_DEV void gsum16x3(float& a, float& b, float& c) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(a), "+v"(b), "+v"(c));
+}
 MS_DEV float gbc(float x, int j) { return __shfl(x, j, 16); }
 MS_DEV int gbci(int x, int j) { return __shfl(x, j, 16); }
 
@@ -924,8 +948,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         W3[dk] = W;
       }
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
-      const float d0 = gsum16(J3[0] * W3[0]), d1 = gsum16(J3[1] * W3[1]), d2 = gsum16(J3[2] * W3[2]);
-      const float g10 = gsum16(J3[1] * W3[0]), g20 = gsum16(J3[2] * W3[0]), g21 = gsum16(J3[2] * W3[1]);
+      float d0 = J3[0] * W3[0], d1 = J3[1] * W3[1], d2 = J3[2] * W3[2];
+      float g10 = J3[1] * W3[0], g20 = J3[2] * W3[0], g21 = J3[2] * W3[1];
+      gsum16x3(d0, d1, d2);
+      gsum16x3(g10, g20, g21);
       if (c == 0) {
         const float i0 = d0 > 1e-12f ? 1.f / d0 : 0.f, i1 = d1 > 1e-12f ? 1.f / d1 : 0.f, i2 = d2 > 1e-12f ? 1.f / d2 : 0.f;
         float4* cs = reinterpret_cast<float4*>(L + S16_CS + 16 * i);
@@ -986,9 +1012,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // multiplier of the block (a1, a2, the first two W updates) is computed off the chain.
     auto con_solve = [&](float J0, float W0, float J1, float W1, float J2, float W2, float& lam0, float& lam1, float& lam2,
                          float4 s0, float4 sk, float k21, bool use_bias) __attribute__((always_inline)) {
-      const float jv0 = gsum16(J0 * v_c);
-      const float jv1 = gsum16(J1 * v_c);
-      const float jv2 = gsum16(J2 * v_c);
+      float jv0 = J0 * v_c, jv1 = J1 * v_c, jv2 = J2 * v_c;
+      gsum16x3(jv0, jv1, jv2);
       const float a1 = fmaf(-jv1, sk.x, lam1);
       const float a2 = fmaf(-jv2, sk.z, lam2);
       const float nl0 = fmaxf(fmaf(-(jv0 + (use_bias ? s0.y : s0.z)), s0.x, lam0), 0.f);
