@@ -47,7 +47,11 @@ def pmc_traffic(kernel_key):
     same command (counters cannot be collected from inside the process); None if not collected"""
     try:
         with open(PMC_SUMMARY) as f:
-            return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch_raw"]
+            kernels = json.load(f)["kernels"]
+        for name, v in kernels.items():  # template arguments vary (k_solve16<true, 9>): match by prefix
+            if name.startswith(kernel_key):
+                return v["hbm_bytes_per_launch_raw"]
+        return None
     except Exception:
         return None
 
@@ -174,9 +178,9 @@ def main():
         fused = narrow_n == 0 and solve_n == args.steps  # k_solve16<FUSED>: one launch = n envs x one control step
         alg_bytes_per_launch = ALG_BYTES_PER_ENV_STEP * n / (1 if fused else substeps)
         if fused:
-            kernel_name, kernel_key = f"k_solve16<FUSED> (whole control step: {substeps} substeps incl. narrowphase, 16 lanes/env)", "k_solve16<true>"
+            kernel_name, kernel_key = f"k_solve16<FUSED> (whole control step: {substeps} substeps incl. narrowphase, 16 lanes/env)", "k_solve16<true"
         elif (px.model.n_dof + 6 * px.model.n_free) <= 16 and os.environ.get("MSSIM_SOLVER") != "lane":
-            kernel_name, kernel_key = "k_solve16 (one substep, 16 lanes/env; narrowphase in k_narrow)", "k_solve16<false>"
+            kernel_name, kernel_key = "k_solve16 (one substep, 16 lanes/env; narrowphase in k_narrow)", "k_solve16<false"
         else:
             kernel_name, kernel_key = "k_solve (one env per lane)", "k_solve"
         achieved = alg_bytes_per_launch / avg_solve_s / 1e9 if avg_solve_s > 0 else 0.0

@@ -907,6 +907,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     int max_nc = nc;
 #pragma unroll
     for (int o = 8 * S16_ENVS_PER_BLOCK; o >= 16; o >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, o));
+    max_nc = __builtin_amdgcn_readfirstlane(max_nc);  // wave-uniform: scalar branches instead of exec masks
     // J3 / W3: this lane's Jacobian and A^-1 J^T entries of the three rows; block scalars go to the LDS
     // table. Padding slots (this env has fewer contacts than the wave's longest) become all-zero blocks:
     // the solver sweeps the maximum over the wave's envs and their updates then move nothing.
@@ -1005,6 +1006,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       max_clds = max(max_clds, __shfl_xor(max_clds, o));
       max_cglb = max(max_cglb, __shfl_xor(max_cglb, o));
     }
+    max_creg = __builtin_amdgcn_readfirstlane(max_creg);
+    max_clds = __builtin_amdgcn_readfirstlane(max_clds);
+    max_cglb = __builtin_amdgcn_readfirstlane(max_cglb);
     // one contact = block of 3 rows. The three J.v reductions are independent (issued back to back);
     // the sequential Gauss-Seidel dependence inside the block is carried by the Delassus cross terms
     // (k10 = J1.W0 / d1, k20 = J2.W0 / d2, k21 = J2.W1 / d2) in scalar arithmetic. The dependent chain
