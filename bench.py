@@ -127,6 +127,17 @@ def main():
     import gymnasium as gym
     import torch.distributed as dist
 
+    from maniskill_amd import native
+
+    if not os.path.exists(native.NATIVE_LIB_PATH) and int(os.environ.get("LOCAL_RANK", 0)) == 0:
+        import __graft_entry__
+
+        __graft_entry__.build()  # fresh checkout: hipcc is on the GPU box too
+    for _ in range(600):  # other ranks wait for rank 0's build
+        if os.path.exists(native.NATIVE_LIB_PATH):
+            break
+        time.sleep(0.5)
+
     from maniskill_amd.distributed import StepGather, shard_seeds, world_info
 
     rank, local_rank, world = world_info()
@@ -221,7 +232,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             env.close()
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as ex:  # the GPU measurement must not be lost if the CPU checker cannot be built / loaded
+                out["cpu_baseline"] = dict(value=None, unit="env-steps/s", cores=0, kind="port", sample=f"unavailable: {type(ex).__name__}: {ex}")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
