@@ -135,3 +135,28 @@ def test_trajectory_recorded_on_oracle_replays_on_hip(tmp_path):
     res = replay(path, sim_backend=BACKEND, use_env_states=True)
     assert len(res) == 2 and all(r["max_state_deviation"] < 2e-3 for r in res), res
 
+
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1"])
+def test_long_random_rollout_stays_sane(env_id):
+    """300 control steps of uniform random actions without a reset (the benchmark protocol, 3x as long):
+    everything stays finite, joints stay inside their limits, nothing tunnels through the table"""
+    import gymnasium as gym
+
+    N = 1024
+    env = gym.make(env_id, num_envs=N, sim_backend=BACKEND)
+    base = env.unwrapped
+    env.reset(seed=0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(300):
+        obs, rew, term, trunc, info = env.step(2 * torch.rand(N, 8, device="cuda", generator=g) - 1)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    q = base.agent.robot.get_qpos()
+    lim = base.agent.robot.get_qlimits()[0].to(q.device)
+    assert torch.all(q >= lim[:, 0] - 0.05) and torch.all(q <= lim[:, 1] + 0.05)
+    assert torch.all(base.agent.robot.get_qvel().abs() < 50)
+    cube = base.scene.actors["cube"].pose.p
+    assert torch.all(cube[:, 2] > -0.01), cube[:, 2].min()  # on (or above) the table top, never through it
+    assert torch.all(cube.abs() < 5)
+    assert base.scene.px.overflow_count() <= N // 50
+    env.close()
+
