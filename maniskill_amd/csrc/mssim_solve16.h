@@ -1129,16 +1129,30 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
       }
       if (max_cglb > 0) {
-        // contacts beyond the LDS capacity: J | W rows stream from the per-env global scratch, one block ahead
-        ConRec A, B;
-        con_load(grow, S16_REGC + S16_LDSC, A);
+        // contacts beyond the LDS capacity: their J | W rows stream (read-only) from the per-env global
+        // scratch, three blocks ahead -- an L2 round trip is ~3 block solves long
+        auto gload = [&](int k, ConRec& R) __attribute__((always_inline)) {
+          const int kk = min(k, max_cglb - 1);
+          const float* row = grow + (size_t)S16_JWLEN * kk;
+          R.J0 = row[c]; R.W0 = row[16 + c];
+          R.J1 = row[32 + c]; R.W1 = row[48 + c];
+          R.J2 = row[64 + c]; R.W2 = row[80 + c];
+        };
+        auto gapply = [&](ConRec& R, int k) __attribute__((always_inline)) {
+          const int ci = S16_REGC + S16_LDSC + k;
+          const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * ci);
+          R.s0 = cs[0]; R.sk = cs[1]; R.kl = cs[2];
+          con_apply(R, ci, use_bias);
+        };
+        ConRec A, B, C;
+        gload(0, A); gload(1, B); gload(2, C);
         int k = 0;
         while (true) {
-          con_load(grow + (size_t)S16_JWLEN * min(k + 1, max_cglb - 1), S16_REGC + S16_LDSC + min(k + 1, max_cglb - 1), B);
-          con_apply(A, S16_REGC + S16_LDSC + k, use_bias);
+          gapply(A, k); gload(k + 3, A);
           if (++k >= max_cglb) break;
-          con_load(grow + (size_t)S16_JWLEN * min(k + 1, max_cglb - 1), S16_REGC + S16_LDSC + min(k + 1, max_cglb - 1), A);
-          con_apply(B, S16_REGC + S16_LDSC + k, use_bias);
+          gapply(B, k); gload(k + 3, B);
+          if (++k >= max_cglb) break;
+          gapply(C, k); gload(k + 3, C);
           if (++k >= max_cglb) break;
         }
       }
