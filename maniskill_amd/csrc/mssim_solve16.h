@@ -403,6 +403,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // ---- cull: 16 pairs of this env per round, survivors appended in pair order
       int nh = 0;
       bool hit_over = false;
+      // stage 1: bounding spheres / plane distance, all pairs (16 per round); survivors appended in pair order
       auto cull_round = [&](int p, int sab) __attribute__((always_inline)) {
         bool surv = false;
         const int sa = sab & 0xFF, sb = (sab >> 8) & 0xFF;
@@ -417,37 +418,59 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             const m3 R = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]});
             cull = dot(mcol(R, 0), cb - f3{ta_[0], ta_[1], ta_[2]}) > rb + M.contact_offset;
           } else {
-            const f3 ca = f3{ta_[10], ta_[11], ta_[12]};
-            const f3 d = cb - ca;
+            const f3 d = cb - f3{ta_[10], ta_[11], ta_[12]};
             const float rr = ra + rb + M.contact_offset;
             cull = dot(d, d) > rr * rr;
-            // oriented boxes of both shapes (15-axis separating-axis test, contact offset added to the
-            // radii): discards the pairs whose bounding spheres overlap but whose shapes are apart --
-            // most of the hull pairs that would otherwise run a full MPR only to find no contact
-            if (!cull) {
-              const m3 RA = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]}), RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
-              cull = obb_separated(RA, f3{ta_[16], ta_[17], ta_[18]}, RB, f3{tb_[16], tb_[17], tb_[18]}, d, M.contact_offset);
-            }
           }
           surv = !cull;
         }
+        // survivors are compacted in place into the staged pair table (write index <= read index)
+        __syncthreads();  // all reads of this round before its writes
         const unsigned long long bal = __ballot(surv);
         const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
-        const int rank = nh + __popc(m16 & ((1u << c) - 1u));
-        if (surv) {
-          if (rank < S16_MAX_HIT) reinterpret_cast<int*>(L)[S16_NP_HIT + rank] = p | (sa << 16) | (sb << 24);
-          else hit_over = true;
-        }
+        if (surv) reinterpret_cast<int*>(L)[S16_NP_SCR + nh + __popc(m16 & ((1u << c) - 1u))] = p | (sa << 16) | (sb << 24);
         nh += __popc(m16);
+        __syncthreads();
       };
 #pragma unroll 1
       for (int base = 0; base < M.n_pair; base += 16) {
         const int p = base + c;
         cull_round(p, p < M.n_pair ? reinterpret_cast<const int*>(L + S16_NP_SCR)[p] : -1);
       }
-      if (__any(hit_over) && hit_over && live) S.overflow[e] = 1;
-      nh = nh < S16_MAX_HIT ? nh : S16_MAX_HIT;
+      // stage 2, on the survivors only (usually one or two rounds): 15-axis separating-axis test of the two
+      // shapes' oriented boxes, contact offset added to the radii. It discards the pairs whose bounding
+      // spheres overlap but whose shapes are apart -- most of the hull pairs that would otherwise run a
+      // full MPR only to find no contact. Survivors go to the hit list, order preserved.
+      {
+        int nh2 = 0;
+#pragma unroll 1
+        for (int base = 0; base < nh; base += 16) {
+          const int idx = base + c;
+          bool keep = false;
+          int pk = 0;
+          if (idx < nh) {
+            pk = reinterpret_cast<const int*>(L)[S16_NP_SCR + idx];
+            const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
+            const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
+            keep = true;
+            if ((int)(__float_as_uint(ta_[14]) & 7u) != SH_PLANE) {
+              const m3 RA = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]}), RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
+              const f3 d = f3{tb_[10], tb_[11], tb_[12]} - f3{ta_[10], ta_[11], ta_[12]};
+              keep = !obb_separated(RA, f3{ta_[16], ta_[17], ta_[18]}, RB, f3{tb_[16], tb_[17], tb_[18]}, d, M.contact_offset);
+            }
+          }
+          const unsigned m16 = (unsigned)(__ballot(keep) >> (16 * g)) & 0xFFFFu;
+          const int rank = nh2 + __popc(m16 & ((1u << c) - 1u));
+          if (keep) {
+            if (rank < S16_MAX_HIT) reinterpret_cast<int*>(L)[S16_NP_HIT + rank] = pk;
+            else hit_over = true;
+          }
+          nh2 += __popc(m16);
+        }
+        nh = nh2 < S16_MAX_HIT ? nh2 : S16_MAX_HIT;
+      }
       __syncthreads();
+      if (__any(hit_over) && hit_over && live) S.overflow[e] = 1;
       PH(23);
       // ---- manifolds, part 1: generic convex pairs (MPR). A pair is worked on by one 16-lane group
       // (hull scans shared by its lanes); the MPR pairs of all 4 envs form one task list that the 4
