@@ -38,6 +38,8 @@ struct DevModel {
   const int *shape_type, *shape_kind, *shape_index, *shape_row, *shape_hull, *pair_shape;
   const float *shape_frame, *shape_param, *shape_material, *shape_bound, *hull_verts;
   const float* shape_center;  // [n_shape][3] bounding-sphere centre in the BODY frame (shape_frame applied)
+  const float* dof_pack;      // [n_dof][32]  all per-joint constants of the cooperative kernel in one 128-byte record
+  const float* shape_pack;    // [n_shape][24] all per-shape constants of its narrowphase in one 96-byte record
   const float* shape_half;    // [n_shape][3] half extents of a box in the SHAPE frame, centred at the bound centre, that contains the shape
   // per-env overrides ([items][N], env fastest); slot < 0 = shared value
   const int *shape_env_slot, *free_env_slot;
@@ -1288,6 +1290,7 @@ struct mssim_sim {
   float* d_drive = nullptr;
   bool panda = false;
   bool dirty = true;
+  std::vector<float> h_dof_pack; float* d_dof_pack = nullptr;  // (drive gains are patched by set_drive_properties)
   std::vector<int32_t> h_shape_row, h_pair_shape;  // host copies (contact-pair lists of the task epilogues)
   int* d_pick_pairs = nullptr; int n_pick_pairs = 0; int pick_rows[3] = {-1, -1, -1};
   std::vector<int*> queries;
@@ -1453,6 +1456,34 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
         for (int k = 0; k < 3; k++) h[k] += std::fabs(b[k]);
     }
     if ((rc = upload(S, half.data(), (size_t)3 * ns, &M.shape_half))) { mssim_destroy(S); return rc; }
+    // packed constant records (one or two cache lines per joint / shape instead of ~10 arrays)
+    auto fbits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    std::vector<float> sp(24 * (size_t)(ns > 0 ? ns : 1), 0.f);
+    for (int s2 = 0; s2 < ns; s2++) {
+      float* r = &sp[24 * (size_t)s2];
+      for (int k = 0; k < 7; k++) r[k] = d->shape_frame[7 * s2 + k];
+      for (int k = 0; k < 3; k++) { r[7 + k] = d->shape_param[4 * s2 + k]; r[10 + k] = ctr[3 * s2 + k]; r[14 + k] = half[3 * s2 + k]; }
+      r[13] = d->shape_bound[4 * s2 + 3];
+      r[17] = d->shape_material[4 * s2 + 1];
+      r[18] = fbits(d->shape_type[s2]);
+      r[19] = fbits(d->shape_body_kind[s2]);
+      r[20] = fbits(d->shape_body_index[s2]);
+      r[21] = fbits((d->n_env_shape > 0) ? d->shape_env_slot[s2] : -1);
+    }
+    if ((rc = upload(S, sp.data(), sp.size(), &M.shape_pack))) { mssim_destroy(S); return rc; }
+    S->h_dof_pack.assign(32 * (size_t)(n > 0 ? n : 1), 0.f);
+    for (int j = 0; j < n; j++) {
+      float* r = &S->h_dof_pack[32 * (size_t)j];
+      for (int k = 0; k < 7; k++) r[k] = d->dof_frame[7 * j + k];
+      for (int k = 0; k < 3; k++) r[7 + k] = d->dof_axis[3 * j + k];
+      r[10] = fbits(d->dof_parent[j]); r[11] = fbits(d->dof_type[j]); r[12] = fbits((int32_t)anc[j]);
+      for (int k = 0; k < 4; k++) r[13 + k] = d->dof_drive[4 * j + k];
+      r[17] = d->dof_armature[j]; r[18] = d->dof_limit[2 * j]; r[19] = d->dof_limit[2 * j + 1];
+      for (int k = 0; k < 10; k++) r[20 + k] = d->body_inertial[10 * j + k];
+      r[30] = fbits(d->body_gravity[j]);
+    }
+    if ((rc = upload(S, S->h_dof_pack.data(), S->h_dof_pack.size(), &M.dof_pack))) { mssim_destroy(S); return rc; }
+    S->d_dof_pack = const_cast<float*>(M.dof_pack);
   }
   {
     const bool has_es = d->n_env_shape > 0, has_ef = d->n_env_free > 0;
@@ -1540,6 +1571,9 @@ float mssim_get_timestep(mssim_handle h) { return h->M.dt; }
 int mssim_set_drive_properties(mssim_handle h, const float* drive) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpy(h->d_drive, drive, sizeof(float) * 4 * h->M.n_dof, hipMemcpyHostToDevice));
+  for (int j = 0; j < h->M.n_dof; j++)
+    for (int k = 0; k < 4; k++) h->h_dof_pack[32 * (size_t)j + 13 + k] = drive[4 * j + k];
+  HIPCHK(h, hipMemcpy(h->d_dof_pack, h->h_dof_pack.data(), sizeof(float) * h->h_dof_pack.size(), hipMemcpyHostToDevice));
   return 0;
 }
 

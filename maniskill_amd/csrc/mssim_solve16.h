@@ -347,13 +347,18 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
           shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shH[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
           if (s < M.n_shape) {
-            const int slot = M.shape_env_slot[s];
+            float r[24];  // the shape's 96-byte constant record
+            const float4* rp = reinterpret_cast<const float4*>(M.shape_pack + 24 * s);
+#pragma unroll
+            for (int k2 = 0; k2 < 6; k2++) { const float4 t = rp[k2]; r[4 * k2] = t.x; r[4 * k2 + 1] = t.y; r[4 * k2 + 2] = t.z; r[4 * k2 + 3] = t.w; }
+            const int ty = __float_as_int(r[18]);
+            const int slot = __float_as_int(r[21]);
             if (slot < 0) {
-              shF[k] = pose_from(M.shape_frame + 7 * s);
-              shP[k][0] = M.shape_param[4 * s]; shP[k][1] = M.shape_param[4 * s + 1]; shP[k][2] = M.shape_param[4 * s + 2];
-              shBc[k] = f3{M.shape_center[3 * s], M.shape_center[3 * s + 1], M.shape_center[3 * s + 2]};
-              shBr[k] = M.shape_bound[4 * s + 3];
-              shH[k] = f3{M.shape_half[3 * s], M.shape_half[3 * s + 1], M.shape_half[3 * s + 2]};
+              shF[k] = pose_t{f3{r[0], r[1], r[2]}, qnormalized(q4{r[3], r[4], r[5], r[6]})};
+              shP[k][0] = r[7]; shP[k][1] = r[8]; shP[k][2] = r[9];
+              shBc[k] = f3{r[10], r[11], r[12]};
+              shBr[k] = r[13];
+              shH[k] = f3{r[14], r[15], r[16]};
             } else {
               shF[k] = pose_soa(M.env_shape_frame, 7 * slot, N, e);
               const float* pp = M.env_shape_param + (size_t)(4 * slot) * N + e;
@@ -362,15 +367,14 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
               shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
               shBr[k] = bb[3 * (size_t)N];
               // per-env shapes are primitives centred on their frame: box of the type's extents
-              const int ty = M.shape_type[s];
               shH[k] = ty == SH_BOX ? f3{shP[k][0], shP[k][1], shP[k][2]}
                      : ty == SH_SPHERE ? f3{shP[k][0], shP[k][0], shP[k][0]}
                      : ty == SH_CAPSULE ? f3{shP[k][1] + shP[k][0], shP[k][0], shP[k][0]}
                      : f3{shP[k][1], shP[k][0], shP[k][0]};
             }
-            shMu[k] = M.shape_material[4 * s + 1];
-            shSlot[k] = pose_slot(M.shape_kind[s], M.shape_index[s]);
-            shPk[k] = (unsigned)M.shape_type[s] | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
+            shMu[k] = r[17];
+            shSlot[k] = pose_slot(__float_as_int(r[19]), __float_as_int(r[20]));
+            shPk[k] = (unsigned)ty | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
           }
         }
       }
@@ -666,19 +670,23 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     f3 al_c = f3{0, 0, 0};                            // joint axis in the joint frame
     int par_c = -1;
     if (art) {
-      JF_c = pose_from(M.dof_frame + 7 * c);
-      al_c = f3{M.dof_axis[3 * c], M.dof_axis[3 * c + 1], M.dof_axis[3 * c + 2]};
-      par_c = M.dof_parent[c];
-      qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
-      rev_c = M.dof_type[c] == MSSIM_JOINT_REVOLUTE;
-      anc_c = M.dof_anc[c];
-      kp0 = M.dof_drive[4 * c]; kd0 = M.dof_drive[4 * c + 1]; fmax = M.dof_drive[4 * c + 2];
-      accel_mode = (int)M.dof_drive[4 * c + 3] == MSSIM_DRIVE_ACCELERATION;
-      arm = M.dof_armature[c];
-      lo_c = M.dof_limit[2 * c]; hi_c = M.dof_limit[2 * c + 1];
+      float r[32];  // the joint's 128-byte constant record: 8 x 16-byte loads from one place
+      const float4* rp = reinterpret_cast<const float4*>(M.dof_pack + 32 * c);
 #pragma unroll
-      for (int k = 0; k < 10; k++) inert[k] = M.body_inertial[10 * c + k];
-      grav_c = M.body_gravity[c] != 0;
+      for (int k = 0; k < 8; k++) { const float4 t = rp[k]; r[4 * k] = t.x; r[4 * k + 1] = t.y; r[4 * k + 2] = t.z; r[4 * k + 3] = t.w; }
+      JF_c = pose_t{f3{r[0], r[1], r[2]}, qnormalized(q4{r[3], r[4], r[5], r[6]})};
+      al_c = f3{r[7], r[8], r[9]};
+      par_c = __float_as_int(r[10]);
+      rev_c = __float_as_int(r[11]) == MSSIM_JOINT_REVOLUTE;
+      anc_c = __float_as_uint(r[12]);
+      kp0 = r[13]; kd0 = r[14]; fmax = r[15];
+      accel_mode = (int)r[16] == MSSIM_DRIVE_ACCELERATION;
+      arm = r[17];
+      lo_c = r[18]; hi_c = r[19];
+#pragma unroll
+      for (int k = 0; k < 10; k++) inert[k] = r[20 + k];
+      grav_c = __float_as_int(r[30]) != 0;
+      qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
     }
     float fin[S16_MAX_FREE][10];
 #pragma unroll
