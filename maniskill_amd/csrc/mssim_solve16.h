@@ -49,7 +49,7 @@
 #define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
 #define S16_LIMW (S16_U)       // [16][16] W = A^-1 J^T of the joint-limit rows
 #define S16_CS (S16_U + 256)   // [MAXC][16] block scalars of every contact: 1/d0 bias+ bias- mu | 1/d1 k10 1/d2 k20 | k21 lam0 lam1 lam2 | pair
-#define S16_REGC 12            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
+#define S16_REGC 16            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
 #define S16_LDSC 7             // next contacts: J | W rows in LDS; the rest stream from the per-env global scratch
 #define S16_JWLEN 96           // 3 x (J[16] W[16]) of one contact
 #define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][96]
