@@ -135,6 +135,73 @@ MS_DEV void gsum16x3(float& a, float& b, float& c) {
       "s_nop 1\n"
       : "+v"(a), "+v"(b), "+v"(c));
 }
+// W = A^-1 row (pre-rotated, see the row build) * J of the lane a row rotation by k reads from, for the
+// three rows of a contact at once: one v_fmac_f32 with a DPP operand per term, no LDS round trip.
+// Inline asm: the compiler keeps v_mov_b32_dpp + v_fma pairs otherwise. The leading s_nop covers the
+// VALU-write -> DPP-read hazard for the producers of J; nothing inside the block writes a DPP source.
+MS_DEV void rot_fma3(const float (&I)[16], const float (&J3)[3], float (&W3)[3]) {
+  float w0 = I[0] * J3[0], w1 = I[0] * J3[1], w2 = I[0] * J3[2];
+  asm("s_nop 1\n"
+      "v_fmac_f32_dpp %0, %3, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %8 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %8 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %8 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %9 row_ror:3 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %9 row_ror:3 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %9 row_ror:3 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %11 row_ror:5 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %11 row_ror:5 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %11 row_ror:5 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %12 row_ror:6 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %12 row_ror:6 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %12 row_ror:6 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %13 row_ror:7 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %13 row_ror:7 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %13 row_ror:7 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %15 row_ror:9 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %15 row_ror:9 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %15 row_ror:9 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %16 row_ror:10 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %16 row_ror:10 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %16 row_ror:10 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %17 row_ror:11 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %17 row_ror:11 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %17 row_ror:11 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %18 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %18 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %18 row_ror:12 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %19 row_ror:13 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %19 row_ror:13 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %19 row_ror:13 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %20 row_ror:14 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %20 row_ror:14 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %20 row_ror:14 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %3, %21 row_ror:15 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %4, %21 row_ror:15 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %5, %21 row_ror:15 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(w0), "+v"(w1), "+v"(w2)
+      : "v"(J3[0]), "v"(J3[1]), "v"(J3[2]), "v"(I[0]), "v"(I[1]), "v"(I[2]), "v"(I[3]), "v"(I[4]), "v"(I[5]), "v"(I[6]), "v"(I[7]),
+        "v"(I[8]), "v"(I[9]), "v"(I[10]), "v"(I[11]), "v"(I[12]), "v"(I[13]), "v"(I[14]), "v"(I[15]));
+  W3[0] = w0; W3[1] = w1; W3[2] = w2;
+}
+template <int K>
+MS_DEV void rot_gather(const float* row, int c, float (&Irot)[16]) {
+  if constexpr (K == 0) {
+    Irot[0] = row[c];
+    rot_gather<1>(row, c, Irot);
+  } else if constexpr (K < 16) {
+    Irot[K] = row[__builtin_amdgcn_update_dpp(0, c, 0x120 + K, 0xF, 0xF, false)];
+    rot_gather<K + 1>(row, c, Irot);
+  }
+}
 MS_DEV float gbc(float x, int j) { return __shfl(x, j, 16); }
 MS_DEV int gbci(int x, int j) { return __shfl(x, j, 16); }
 
@@ -814,10 +881,15 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     float vstar = 0.f;
     // (a Sherman-Morrison downdate per saturated joint instead of the second elimination was tried:
     // 1 - D_j a_jj is ~0.01..0.1 for these drives and the cancellation costs ~3 digits in f32)
-    for (int pass = 0; pass < 2; pass++) {
-      float Arow[16];
+    // (joint count known at compile time: the elimination only touches the articulation's NA columns,
+    // rounded up to whole 16-byte LDS words; A^-1 is block diagonal, the rest of the row stays zero)
+    constexpr int NA = NDOF ? ((NDOF + 3) & ~3) : 16;
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 16; k++) Irow[k] = 0.f;
+    for (int pass = 0; pass < 2; pass++) {
+      float Arow[NA];
+#pragma unroll
+      for (int k = 0; k < NA; k++) {
         Arow[k] = art ? (Mrow[k] + Trow[k] + (k == c ? Dj + arm : 0.f)) : (k == c ? 1.f : 0.f);
         Irow[k] = k == c ? 1.f : 0.f;
       }
@@ -827,17 +899,22 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         __syncthreads();
         if (c == k) {
 #pragma unroll
-          for (int j = 0; j < 16; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + 16 + j] = Irow[j]; }
+          for (int j = 0; j < NA; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + NA + j] = Irow[j]; }
         }
         __syncthreads();
-        float PA[16], PI[16];
-        ld16(L + S16_PIV, PA);
-        ld16(L + S16_PIV + 16, PI);
-        const float inv = 1.f / PA[k];
-        const float fac = Arow[k] * inv;
+        float PA[NA], PI[NA];
+#pragma unroll
+        for (int j = 0; j < NA; j += 4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(L + S16_PIV + j);
+          const float4 i4 = *reinterpret_cast<const float4*>(L + S16_PIV + NA + j);
+          PA[j] = a4.x; PA[j + 1] = a4.y; PA[j + 2] = a4.z; PA[j + 3] = a4.w;
+          PI[j] = i4.x; PI[j + 1] = i4.y; PI[j + 2] = i4.z; PI[j + 3] = i4.w;
+        }
+        const float inv = 1.f / PA[k < NA ? k : 0];
+        const float fac = Arow[k < NA ? k : 0] * inv;
         const bool piv = c == k;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < NA; j++) {
           Arow[j] = piv ? PA[j] * inv : Arow[j] - fac * PA[j];
           Irow[j] = piv ? PI[j] * inv : Irow[j] - fac * PI[j];
         }
@@ -849,7 +926,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       ld16(L + S16_VEC + 16, rv);
       vstar = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; k++) vstar += Irow[k] * rv[k];
+      for (int k = 0; k < NA; k++) vstar += Irow[k] * rv[k];
       if (pass == 1) break;
       // drive force limit: saturated joints get the constant limit torque, lose their implicit terms
       const float td = kp * (qt_c - q_c - dt * vstar) + kd * (qdt_c - vstar);
@@ -934,6 +1011,16 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       lim_bpos = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
       lim_bvel = C >= 0.f ? C / dt : 0.f;
     }
+    // A^-1 row in rotated order for W = A^-1 J^T of the contact rows: Irot[k] = Ainv[c][src_k], src_k = the
+    // lane a DPP row rotation by k delivers to lane c (taken from the rotation itself, so no convention
+    // about its direction enters). Per-lane dynamic indexing goes through 16 private LDS words.
+    float Irot[16];
+    {
+      float* tmp = L + S16_JW + 16 * c;
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(tmp + j) = float4{Irow[j], Irow[j + 1], Irow[j + 2], Irow[j + 3]};
+      rot_gather<0>(tmp, c, Irot);
+    }
     // contacts: a block of 3 rows each (normal, t1, t2), built from the LDS records
     int max_nc = nc;
 #pragma unroll
@@ -966,19 +1053,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         const float J = sgn * dot(jaxis_c, sel3(jrot_c, cross(rx, d), d));
         J3[dk] = ck ? J : 0.f;
       }
-      // the three directions at once: one LDS round trip for J -> W = A^-1 J^T
-      __syncthreads();
-      L[S16_VEC + 16 + c] = J3[0]; L[S16_VEC + 32 + c] = J3[1]; L[S16_VEC + 48 + c] = J3[2];
-      __syncthreads();
-#pragma unroll
-      for (int dk = 0; dk < 3; dk++) {
-        float Jv[16];
-        ld16(L + S16_VEC + 16 + 16 * dk, Jv);
-        float W = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; j++) W += Irow[j] * Jv[j];
-        W3[dk] = W;
-      }
+      // W = A^-1 J^T for the three directions: 16 DPP row rotations of J against the pre-rotated row
+      rot_fma3(Irot, J3, W3);
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
       float d0 = J3[0] * W3[0], d1 = J3[1] * W3[1], d2 = J3[2] * W3[2];
       float g10 = J3[1] * W3[0], g20 = J3[2] * W3[0], g21 = J3[2] * W3[1];
@@ -1132,12 +1208,20 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
       }
       PH(18);
+      // block scalars of contact k + 1 are read from the LDS table before the dependent chain of contact k
+      // (one wave per SIMD: nothing else hides the LDS latency); slot k + 1 always exists in the table
+      float4 ns0 = *reinterpret_cast<const float4*>(L + S16_CS), nsk = *reinterpret_cast<const float4*>(L + S16_CS + 4);
+      float nk21 = L[S16_CS + 8];
 #pragma unroll
       for (int k = 0; k < S16_REGC; k++) {
         if (k < max_creg) {  // wave-uniform
-          const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * k);
-          const float4 s0 = cs[0], sk = cs[1];
-          const float k21 = L[S16_CS + 16 * k + 8];
+          const float4 s0 = ns0, sk = nsk;
+          const float k21 = nk21;
+          if (k + 1 < S16_REGC) {
+            const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * (k + 1));
+            ns0 = cs[0]; nsk = cs[1];
+            nk21 = L[S16_CS + 16 * (k + 1) + 8];
+          }
           float l0 = lamr[k][0], l1 = lamr[k][1], l2 = lamr[k][2];
           con_solve(Jr[k][0], Wr[k][0], Jr[k][1], Wr[k][1], Jr[k][2], Wr[k][2], l0, l1, l2, s0, sk, k21, use_bias);
           lamr[k][0] = l0; lamr[k][1] = l1; lamr[k][2] = l2;
