@@ -186,8 +186,15 @@ MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
   return m;
 }
 
-template <int STRIDE = 64>
-MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, manifold_t& m, float* lds) {
+// separating-axis search + the single-point edge-edge case + the choice of reference / incident face.
+// Returns 0 = apart, 1 = edge-edge contact (manifold filled), 2 = face contact (F filled, clipping is
+// the caller's: one lane per pair in collide_box_box, 16 lanes per pair in collide_box_box_coop)
+struct bb_face_t {
+  f3 nref, Xc, x1, x2, fc, y1, y2;
+  float hXr, hX1, hX2, hY1, hY2;
+  bool refA;
+};
+MS_DEV int bb_setup(const shape_t& A, const shape_t& B, float offset, manifold_t& m, bb_face_t& F) {
   manifold_clear(m);
   const float eps = 1e-6f;
   f3 a[3] = {mcol(A.rot, 0), mcol(A.rot, 1), mcol(A.rot, 2)};
@@ -227,13 +234,13 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
     }
   float sF = sA > sB ? sA : sB;
   float smax = sF > sE ? sF : sE;
-  if (smax > offset) return;
+  if (smax > offset) return 0;
 
   if (eI >= 0 && sE > sF + 1e-3f) {
-    f3 aE = eI == 0 ? a[0] : (eI == 1 ? a[1] : a[2]);
-    f3 bE = eJ == 0 ? b[0] : (eJ == 1 ? b[1] : b[2]);
+    f3 aE = sel3(eI == 0, a[0], sel3(eI == 1, a[1], a[2]));
+    f3 bE = sel3(eJ == 0, b[0], sel3(eJ == 1, b[1], b[2]));
     f3 ax = normalized(cross(aE, bE));
-    if (dot(ax, tw) < 0.f) ax = -ax;
+    ax = sel3(dot(ax, tw) < 0.f, -ax, ax);
     f3 pa = A.c, pb = B.c;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -254,7 +261,7 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
     m.n = -ax;
     m.sep[0] = dot(qb - qa, ax);
     m.x[0] = (qa + qb) * 0.5f;
-    return;
+    return 1;
   }
   bool refA = sA >= sB - 1e-5f;
   // select reference (X) / incident (Y) data without dynamic register indexing
@@ -262,16 +269,16 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
   float hX[3], hY[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    xa[k] = refA ? a[k] : b[k];
-    ya[k] = refA ? b[k] : a[k];
+    xa[k] = sel3(refA, a[k], b[k]);
+    ya[k] = sel3(refA, b[k], a[k]);
     hX[k] = refA ? hA[k] : hB[k];
     hY[k] = refA ? hB[k] : hA[k];
   }
-  f3 Xc = refA ? A.c : B.c, Yc = refA ? B.c : A.c;
+  f3 Xc = sel3(refA, A.c, B.c), Yc = sel3(refA, B.c, A.c);
   int ir = refA ? iA : iB;
-  f3 xr = ir == 0 ? xa[0] : (ir == 1 ? xa[1] : xa[2]);
+  f3 xr = sel3(ir == 0, xa[0], sel3(ir == 1, xa[1], xa[2]));
   float hXr = ir == 0 ? hX[0] : (ir == 1 ? hX[1] : hX[2]);
-  f3 nref = dot(xr, Yc - Xc) >= 0.f ? xr : -xr;
+  f3 nref = sel3(dot(xr, Yc - Xc) >= 0.f, xr, -xr);
   int jinc = 0;
   float bestd = -1.f;
 #pragma unroll
@@ -279,23 +286,37 @@ MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, ma
     float d = fabsf(dot(nref, ya[j]));
     if (d > bestd) { bestd = d; jinc = j; }
   }
-  f3 yi = jinc == 0 ? ya[0] : (jinc == 1 ? ya[1] : ya[2]);
-  f3 y1 = jinc == 0 ? ya[1] : (jinc == 1 ? ya[2] : ya[0]);
-  f3 y2 = jinc == 0 ? ya[2] : (jinc == 1 ? ya[0] : ya[1]);
+  f3 yi = sel3(jinc == 0, ya[0], sel3(jinc == 1, ya[1], ya[2]));
+  f3 y1 = sel3(jinc == 0, ya[1], sel3(jinc == 1, ya[2], ya[0]));
+  f3 y2 = sel3(jinc == 0, ya[2], sel3(jinc == 1, ya[0], ya[1]));
   float hYi = jinc == 0 ? hY[0] : (jinc == 1 ? hY[1] : hY[2]);
   float hY1 = jinc == 0 ? hY[1] : (jinc == 1 ? hY[2] : hY[0]);
   float hY2 = jinc == 0 ? hY[2] : (jinc == 1 ? hY[0] : hY[1]);
-  f3 ninc = dot(nref, yi) > 0.f ? -yi : yi;
+  f3 ninc = sel3(dot(nref, yi) > 0.f, -yi, yi);
   f3 fc = Yc + ninc * hYi;
+  F.x1 = sel3(ir == 0, xa[1], sel3(ir == 1, xa[2], xa[0]));
+  F.x2 = sel3(ir == 0, xa[2], sel3(ir == 1, xa[0], xa[1]));
+  F.hX1 = ir == 0 ? hX[1] : (ir == 1 ? hX[2] : hX[0]);
+  F.hX2 = ir == 0 ? hX[2] : (ir == 1 ? hX[0] : hX[1]);
+  F.nref = nref; F.Xc = Xc; F.fc = fc; F.y1 = y1; F.y2 = y2;
+  F.hXr = hXr; F.hY1 = hY1; F.hY2 = hY2; F.refA = refA;
+  return 2;
+}
+
+template <int STRIDE = 64>
+MS_DEV void collide_box_box(const shape_t& A, const shape_t& B, float offset, manifold_t& m, float* lds) {
+  bb_face_t F;
+  if (bb_setup(A, B, offset, m, F) != 2) return;
+  const f3 nref = F.nref, Xc = F.Xc, fc = F.fc, y1 = F.y1, y2 = F.y2;
+  const float hXr = F.hXr, hY1 = F.hY1, hY2 = F.hY2;
+  const bool refA = F.refA;
   lds_poly<STRIDE> P{lds, 0};
   P.put(0, fc + y1 * hY1 + y2 * hY2);
   P.put(1, fc - y1 * hY1 + y2 * hY2);
   P.put(2, fc - y1 * hY1 - y2 * hY2);
   P.put(3, fc + y1 * hY1 - y2 * hY2);
-  f3 x1 = ir == 0 ? xa[1] : (ir == 1 ? xa[2] : xa[0]);
-  f3 x2 = ir == 0 ? xa[2] : (ir == 1 ? xa[0] : xa[1]);
-  float hX1 = ir == 0 ? hX[1] : (ir == 1 ? hX[2] : hX[0]);
-  float hX2 = ir == 0 ? hX[2] : (ir == 1 ? hX[0] : hX[1]);
+  const f3 x1 = F.x1, x2 = F.x2;
+  const float hX1 = F.hX1, hX2 = F.hX2;
   int np = 4;
   np = clip_poly<STRIDE>(lds, 0, np, x1, dot(x1, Xc) + hX1);
   np = clip_poly<STRIDE>(lds, 1, np, -x1, -dot(x1, Xc) + hX1);
@@ -434,12 +455,23 @@ MS_DEV void closest_on_triangle(f3 a, f3 b, f3 c, float w[3]) {
 #ifdef MSSIM_PHASE_CLOCKS
 __device__ unsigned g_mpr_hist[2][16];  // [0]: portal discovery iterations, [1]: refinement iterations (bins of 4)
 #define MPR_COUNT(k, it) atomicAdd(&g_mpr_hist[k][(it) / 4 < 15 ? (it) / 4 : 15], 1u)
+// cycles of thread 0 of a wave between the marks (other groups' divergent paths included): 0 entry ->
+// portal found, 1 refinement, 2 contact point; 3 / 4 = refinement iterations / calls seen by thread 0
+__device__ unsigned long long g_mpr_clk[8];
+#define MPR_T0 unsigned long long mpr_t_ = clock64()
+#define MPR_T(i) do { if (threadIdx.x == 0) { atomicAdd(&g_mpr_clk[i], clock64() - mpr_t_); } mpr_t_ = clock64(); } while (0)
+#define MPR_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_mpr_clk[i], (unsigned long long)(v)); } while (0)
 #else
 #define MPR_COUNT(k, it)
+#define MPR_T0
+#define MPR_T(i)
+#define MPR_ADD(i, v)
 #endif
 template <class SUP>
 MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, manifold_t& m, const SUP& sup) {
   manifold_clear(m);
+  MPR_T0;
+  MPR_ADD(4, 1);
   const float margin = offset;
   const float tol = 1e-5f;
   mvert v0, v1, v2, v3, v4;
@@ -472,8 +504,10 @@ MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, mani
     break;
   }
   if (!found) return;
+  MPR_T(0);
   bool hit = false;
   for (int it = 0; it < 48; it++) {
+    MPR_ADD(3, 1);
     dir = cross(v2.v - v1.v, v3.v - v1.v);
     float dl = norm(dir);
     if (dl < 1e-14f) break;
@@ -495,6 +529,7 @@ MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, mani
     }
   }
   if (!hit) return;
+  MPR_T(1);
   float w[3];
   closest_on_triangle(v1.v, v2.v, v3.v, w);
   f3 wp = v1.v * w[0] + v2.v * w[1] + v3.v * w[2];

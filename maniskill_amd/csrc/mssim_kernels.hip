@@ -1842,6 +1842,14 @@ extern "C" int mssim_debug_phase_clocks(unsigned long long* out32, int reset) {
 extern "C" int mssim_debug_mpr_hist(unsigned* out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mpr_hist), 32 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
 }
+extern "C" int mssim_debug_mpr_clocks(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mpr_clk), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mpr_clk), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" int mssim_debug_phase_blocks(unsigned* out, int nblocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_blk), (size_t)nblocks * 32 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
 }

@@ -64,6 +64,10 @@
 #define S16_NP_HIT (S16_U + 560)  // [64] surviving pairs: pair | sa << 16 | sb << 24
 #define S16_NP_CNT (S16_U + 624)  // [64] manifold sizes
 #define S16_NP_SCR (S16_U + 688)  // [56][16] box-box clip scratch of the group's 16 lanes | pair table during the cull (<= 896 pairs)
+#define S16_MAX_BBC 16             // box-box pairs per wave (and per env) worked on by 16-lane groups
+#define S16_NP_BL (S16_NP_SCR)          // [16] hit indices of this env's box-box pairs       } inside the clip scratch,
+#define S16_NP_BS (S16_NP_SCR + 16)     // [16][20] their staged manifolds                    } which the one-lane-
+#define S16_NP_BSCR (S16_NP_SCR + 336)  // [24] polygon scatter / gather words of the group   } per-pair path owns otherwise
 #define S16_NP_ML (S16_U + 1584)  // [14] hit indices of this env's MPR (generic convex) pairs
 #define S16_NP_MS (S16_U + 1598)  // [14][7] their contacts n(3) x(3) sep, staged until the record offsets are known
 #define S16_MAX_MPR 14
@@ -216,6 +220,103 @@ MS_DEV void ld16(const float* p, float* out) {  // 16 consecutive floats (16-B a
 MS_DEV pose_t lds_pose(const float* b) { return pose_t{f3{b[0], b[1], b[2]}, q4{b[3], b[4], b[5], b[6]}}; }
 MS_DEV void lds_pose_store(float* b, pose_t P) {
   b[0] = P.p.x; b[1] = P.p.y; b[2] = P.p.z; b[3] = P.q.w; b[4] = P.q.x; b[5] = P.q.y; b[6] = P.q.z;
+}
+MS_DEV float gmax16(float x) {
+  x = fmaxf(x, dpp_f<0x128>(x));
+  x = fmaxf(x, dpp_f<0x124>(x));
+  x = fmaxf(x, dpp_f<0x122>(x));
+  x = fmaxf(x, dpp_f<0x121>(x));
+  return x;
+}
+// Box-box manifold by the 16 lanes of a group (same result as collide_box_box, which spends ~3400
+// instructions of one lane on it): the separating-axis search is evaluated redundantly, then lane
+// i < 8 owns polygon vertex i. A Sutherland-Hodgman pass is one step for all vertices: distance of
+// the own and the next vertex, output slots from two ballots (vertex order preserved), scatter /
+// gather through 8 x 3 LDS words. The 4-point reduction ("first extremum wins" scans) becomes
+// max-reductions + ballots. Result -> out[20]: count | n | 4 x (x y z sep); written by the owning lanes.
+// `scr`: 24 floats of the group. The group's lanes must be converged; no barrier is used (one wave:
+// LDS operations complete in order), so other groups of the wave may be inactive.
+MS_DEV void collide_box_box_coop(const shape_t& A, const shape_t& B, float offset, float* scr, float* out, int c, int g) {
+  manifold_t m;
+  bb_face_t F;
+  const int mode = bb_setup(A, B, offset, m, F);
+  if (mode != 2) {
+    if (c == 0) {
+      out[0] = __int_as_float(m.count);
+      out[1] = m.n.x; out[2] = m.n.y; out[3] = m.n.z;
+      out[4] = m.x[0].x; out[5] = m.x[0].y; out[6] = m.x[0].z; out[7] = m.sep[0];
+    }
+    return;
+  }
+  auto ballot16 = [&](bool b) __attribute__((always_inline)) { return (unsigned)(__ballot(b) >> (16 * g)) & 0xFFFFu; };
+  const unsigned below = (1u << c) - 1u;
+  // incident face: vertex c of (+,+) (-,+) (-,-) (+,-)
+  f3 P = F.fc + F.y1 * ((c == 0 || c == 3) ? F.hY1 : -F.hY1) + F.y2 * (c < 2 ? F.hY2 : -F.hY2);
+  int np = 4;
+  auto clip = [&](f3 pn, float pd) __attribute__((always_inline)) {
+    const bool valid = c < np;
+    const float da = dot(pn, P) - pd;
+    const int nxt = (c + 1 < np) ? c + 1 : 0;
+    const f3 b = f3{gbc(P.x, nxt), gbc(P.y, nxt), gbc(P.z, nxt)};
+    const float db = gbc(da, nxt);
+    const bool ea = valid && da <= 0.f;
+    const bool et = valid && ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f));
+    const unsigned ma = ballot16(ea), mt = ballot16(et);
+    const int pa = __popc(ma & below) + __popc(mt & below);
+    const int pt = pa + (ea ? 1 : 0);
+    if (ea && pa < 8) { scr[3 * pa] = P.x; scr[3 * pa + 1] = P.y; scr[3 * pa + 2] = P.z; }
+    if (et && pt < 8) {
+      const float t = da / (da - db);
+      const f3 x = P + (b - P) * t;
+      scr[3 * pt] = x.x; scr[3 * pt + 1] = x.y; scr[3 * pt + 2] = x.z;
+    }
+    const int tot = __popc(ma) + __popc(mt);
+    np = tot < 8 ? tot : 8;
+    const int rd = c & 7;
+    P = f3{scr[3 * rd], scr[3 * rd + 1], scr[3 * rd + 2]};
+  };
+  clip(F.x1, dot(F.x1, F.Xc) + F.hX1);
+  clip(-F.x1, -dot(F.x1, F.Xc) + F.hX1);
+  clip(F.x2, dot(F.x2, F.Xc) + F.hX2);
+  clip(-F.x2, -dot(F.x2, F.Xc) + F.hX2);
+  // points within the offset, projected half way onto the reference face
+  const float sp = dot(P - F.Xc, F.nref) - F.hXr;
+  const bool keep = c < np && sp <= offset;
+  const unsigned mk = ballot16(keep);
+  const int n = __popc(mk);
+  const f3 q = P - F.nref * (0.5f * sp);
+  int slot = -1, count = n;
+  if (n <= 4) {
+    slot = keep ? __popc(mk & below) : -1;
+  } else {
+    // deepest, farthest from it, then the two of largest area on either side; earliest candidate wins ties
+    const float mn = -gmax16(keep ? -sp : -3e38f);
+    const int l0 = __ffs(ballot16(keep && sp == mn)) - 1;
+    const f3 p0 = f3{gbc(q.x, l0), gbc(q.y, l0), gbc(q.z, l0)};
+    const f3 d0 = q - p0;
+    const float v1 = dot(d0, d0);
+    const bool c1 = keep && c != l0;
+    const float m1 = gmax16(c1 ? v1 : -1.f);
+    const int l1 = __ffs(ballot16(c1 && v1 == m1)) - 1;
+    const f3 e = f3{gbc(q.x, l1), gbc(q.y, l1), gbc(q.z, l1)} - p0;
+    const float ar = dot(cross(e, q - p0), F.nref);
+    const bool c2 = c1 && c != l1;
+    const float m2 = gmax16(c2 ? fabsf(ar) : -1.f);
+    const int l2 = __ffs(ballot16(c2 && fabsf(ar) == m2)) - 1;
+    const float sgn2 = gbc(ar, l2);
+    const bool c3 = c2 && c != l2;
+    const float v3 = sgn2 >= 0.f ? -ar : ar;
+    const float m3 = gmax16(c3 ? v3 : 0.f);
+    const int l3 = m3 > 0.f ? __ffs(ballot16(c3 && v3 == m3)) - 1 : -1;
+    slot = c == l0 ? 0 : (c == l1 ? 1 : (c == l2 ? 2 : (c == l3 ? 3 : -1)));
+    count = l3 >= 0 ? 4 : 3;
+  }
+  if (c == 0) {
+    const f3 nn = F.refA ? -F.nref : F.nref;
+    out[0] = __int_as_float(count);
+    out[1] = nn.x; out[2] = nn.y; out[3] = nn.z;
+  }
+  if (slot >= 0) { out[4 + 4 * slot] = q.x; out[5 + 4 * slot] = q.y; out[6 + 4 * slot] = q.z; out[7 + 4 * slot] = sp; }
 }
 // pose-table slot of a body: -1 = fixed in the env frame
 MS_DEV int pose_slot(int kind, int index) {
@@ -547,16 +648,18 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // (hull scans shared by its lanes); the MPR pairs of all 4 envs form one task list that the 4
       // groups take round-robin, so an env with many such pairs does not serialise on its own group.
       int nml = 0;  // MPR pairs of this env
+      int nbl = 0;  // box-box pairs of this env
       {
         bool over = false;
         for (int base = 0; base < nh; base += 16) {
           const int idx = base + c;
-          bool is_mpr = false;
+          bool is_mpr = false, is_bb = false;
           if (idx < nh) {
             const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
             const int ta = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 14]) & 7u);
             const int tb = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]) & 7u);
-            is_mpr = !(ta == SH_PLANE || (ta == SH_BOX && tb == SH_BOX));
+            is_bb = ta == SH_BOX && tb == SH_BOX;
+            is_mpr = !(ta == SH_PLANE || is_bb);
           }
           const unsigned m16 = (unsigned)(__ballot(is_mpr) >> (16 * g)) & 0xFFFFu;
           const int rank = nml + __popc(m16 & ((1u << c) - 1u));
@@ -565,6 +668,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             else { over = true; reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = 0; }
           }
           nml += __popc(m16);
+          const unsigned b16 = (unsigned)(__ballot(is_bb) >> (16 * g)) & 0xFFFFu;
+          const int brank = nbl + __popc(b16 & ((1u << c) - 1u));
+          if (is_bb && brank < S16_MAX_BBC) reinterpret_cast<int*>(L)[S16_NP_BL + brank] = idx;
+          nbl += __popc(b16);
         }
         if (__any(over) && over && live) S.overflow[e] = 1;
         nml = nml < S16_MAX_MPR ? nml : S16_MAX_MPR;
@@ -602,8 +709,39 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
       __syncthreads();
       PH(25);
-      // ---- manifolds, part 2: plane and box-box pairs, all such (env, pair) tasks of the wave spread
-      // over the 64 lanes
+      // ---- manifolds, part 2a: box-box pairs. With few of them in the wave (the usual case: cube on table,
+      // peg on table) one lane per pair leaves the wave almost empty for ~3400 instructions, so the 4 groups
+      // take the wave's box-box pairs round-robin, 16 lanes per pair; results are staged like the MPR
+      // contacts. Many box-box pairs: one lane per pair in part 2b.
+      bool bb_coop;
+      {
+        int bcum[S16_ENVS_PER_BLOCK + 1];
+        bcum[0] = 0;
+#pragma unroll
+        for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) bcum[j + 1] = bcum[j] + __shfl(nbl, 16 * j);
+        const int TB = bcum[S16_ENVS_PER_BLOCK];
+        bb_coop = TB <= S16_MAX_BBC;  // wave-uniform (and no env's list was cut)
+        if (bb_coop) {
+          for (int t = g; t < TB; t += S16_ENVS_PER_BLOCK) {
+            int ge = 0;
+#pragma unroll
+            for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= bcum[j] ? 1 : 0;
+            const int k = t - bcum[ge];
+            float* Lg = sm + ge * S16_ENV_FLOATS;
+            const int idx = reinterpret_cast<const int*>(Lg)[S16_NP_BL + k];
+            const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+            const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
+            const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
+            float* out = Lg + S16_NP_BS + 20 * k;
+            collide_box_box_coop(A, B, M.contact_offset, L + S16_NP_BSCR, out, c, g);
+            if (c == 0) reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = __float_as_int(out[0]);
+          }
+        }
+      }
+      __syncthreads();
+      PH(13);
+      // ---- manifolds, part 2b: plane (and, without part 2a, box-box) pairs, all such (env, pair) tasks of
+      // the wave spread over the 64 lanes
       int cum[S16_ENVS_PER_BLOCK + 1];
       cum[0] = 0;
 #pragma unroll
@@ -628,7 +766,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           PH_ADD(27, __popcll(__ballot(A.type == SH_PLANE)));
           PH_ADD(28, __popcll(__ballot(A.type == SH_BOX && B.type == SH_BOX)));
           PH(10);
-          const bool is_plane = A.type == SH_PLANE, is_bb = A.type == SH_BOX && B.type == SH_BOX;
+          const bool is_plane = A.type == SH_PLANE, is_bb = !bb_coop && A.type == SH_BOX && B.type == SH_BOX;
           if (is_plane) collide_plane(A, B, M.contact_offset, m);
           PH(11);
           if (is_bb) collide_box_box<16>(A, B, M.contact_offset, m, sm + g * S16_ENV_FLOATS + S16_NP_SCR + c);
@@ -656,6 +794,33 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             }
         }
         __syncthreads();
+      }
+      // the staged box-box manifolds go to their slots (all manifold sizes are known now)
+      if (bb_coop) {
+        for (int k = c; k < nbl; k += 16) {
+          const int idx = reinterpret_cast<const int*>(L)[S16_NP_BL + k];
+          const float* o = L + S16_NP_BS + 20 * k;
+          const int cnt = __float_as_int(o[0]);
+          if (cnt > 0) {
+            int off = 0;
+            for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
+            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
+            const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
+            const float mu = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
+            const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
+                                     (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16));
+            for (int q = 0; q < cnt; q++)
+              if (off + q < MAXC) {
+                float* r = L + S16_REC + S16_REC_LEN * (off + q);
+                r[0] = o[1]; r[1] = o[2]; r[2] = o[3];
+                r[3] = o[4 + 4 * q]; r[4] = o[5 + 4 * q]; r[5] = o[6 + 4 * q];
+                r[6] = o[7 + 4 * q] - M.rest_offset;
+                r[7] = __int_as_float(pk & 0xFFFF);
+                r[8] = __int_as_float(bodies);
+                r[9] = mu;
+              }
+          }
+        }
       }
       // the staged MPR contacts go to their slots (all manifold sizes are known now)
       for (int k = c; k < nml; k += 16) {

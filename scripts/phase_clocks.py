@@ -24,7 +24,7 @@ env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
 buf = (ctypes.c_ulonglong * 32)()
 names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
-         "dyn: S stage", "dyn: V sum", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: MPR",
+         "dyn: S stage", "dyn: V sum", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: coop box-box",
          "#coop MPR task slots (max over groups)", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
          "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: plane/box-box rounds + record writes", "np: coop MPR",
          "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
@@ -59,7 +59,18 @@ for b in order[:3]:
         if i < 26 and i != 14 and a[b, i] > 0.01 * cyc[b]:
             print(f"    {nm:40s} {a[b, i]:9.0f}  {100 * a[b, i] / cyc[b]:5.1f} %")
 
+print(" slowest 16 blocks: total | coop MPR | PGS contacts | row build | contacts | MPR slots")
+for b in order[:16]:
+    print(f"   {cyc[b]:9.0f} {a[b, 25]:9.0f} {a[b, 19] + a[b, 20]:9.0f} {a[b, 4]:9.0f} {a[b, 30]:5.0f} {a[b, 14]:4.0f}")
+print(" blocks with MPR slots: %d of %d; mean total with / without: %.0f / %.0f" % ((a[:, 14] > 0).sum(), nb, cyc[a[:, 14] > 0].mean() if (a[:, 14] > 0).any() else 0, cyc[a[:, 14] == 0].mean()))
+
 h = (ctypes.c_uint * 32)()
 dbg.mssim_debug_mpr_hist(h)
 print("MPR portal-discovery iterations (bins of 4):", list(h)[:16])
 print("MPR refinement iterations       (bins of 4):", list(h)[16:])
+
+mc = (ctypes.c_ulonglong * 8)()
+dbg.mssim_debug_mpr_clocks(mc, 0)
+if mc[4]:
+    print("MPR as seen by thread 0 of each wave (whole run): calls %d, cycles to portal %.0f, refinement %.0f (%.1f iterations, %.0f cycles each), contact point %.0f"
+          % (mc[4], mc[0] / mc[4], mc[1] / mc[4], mc[3] / mc[4], mc[1] / max(mc[3], 1), mc[2] / mc[4]))
