@@ -1853,4 +1853,8 @@ extern "C" int mssim_debug_mpr_clocks(unsigned long long* out8, int reset) {
 extern "C" int mssim_debug_phase_blocks(unsigned* out, int nblocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_blk), (size_t)nblocks * 32 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
 }
+#elif defined(MSSIM_BLOCK_TIMES)
+extern "C" int mssim_debug_phase_blocks(unsigned* out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_blk), (size_t)nblocks * 32 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
+}
 #endif

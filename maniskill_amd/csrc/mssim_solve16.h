@@ -96,6 +96,27 @@ __device__ unsigned g_phase_blk[2048 * 32];  // per-block deltas of the most rec
       _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) g_phase_blk[blockIdx.x * 32 + i_] = ph_d[i_]; \
     }                                                                             \
   }
+#elif defined(MSSIM_BLOCK_TIMES)
+// scripts/block_times.py: start / duration (100 MHz wall clock), core-clock cycles and placement (HW_ID,
+// XCC_ID) of every block of the most recent launch, with the work counters of the phase-clock build --
+// two clock reads per block, so the timing is that of the product kernel
+__device__ unsigned g_phase_blk[2048 * 32];
+#define PH_INIT                                             \
+  unsigned ph_d[32];                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) ph_d[i_] = 0u; \
+  const unsigned long long bt_w0 = wall_clock64(), bt_c0 = clock64();
+#define PH(i)
+#define PH_ADD(i, v) ph_d[i] += (unsigned)(v)
+#define PH_FLUSH                                                                   \
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {                                     \
+    unsigned* o_ = g_phase_blk + blockIdx.x * 32;                                  \
+    _Pragma("unroll") for (int i_ = 8; i_ < 32; i_++) o_[i_] = ph_d[i_];           \
+    o_[0] = (unsigned)bt_w0; o_[1] = (unsigned)(bt_w0 >> 32);                      \
+    o_[2] = (unsigned)(wall_clock64() - bt_w0);                                    \
+    o_[3] = (unsigned)(clock64() - bt_c0);                                         \
+    o_[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                             \
+    o_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                            \
+  }
 #else
 #define PH_INIT
 #define PH(i)
