@@ -28,6 +28,7 @@ from maniskill_amd.utils import common, gym_utils
 from maniskill_amd.utils.structs.actor import Actor
 from maniskill_amd.utils.structs.articulation import Articulation
 from maniskill_amd.utils.structs.pose import Pose
+from maniskill_amd import physx
 from maniskill_amd.utils.structs.types import SimConfig, strict_from_dict
 
 
@@ -105,6 +106,9 @@ class BaseEnv(gym.Env):
         common.dict_merge(merged, sim_config)
         self.sim_config: SimConfig = strict_from_dict(SimConfig, merged)
 
+        if self.device.type == "cuda" and not physx.is_gpu_enabled():
+            physx.enable_gpu()
+        physx.set_gpu_memory_config(**self.sim_config.gpu_memory_config.dict())
         self._sim_freq = self.sim_config.sim_freq
         self._control_freq = self.sim_config.control_freq
         assert self._sim_freq % self._control_freq == 0, f"sim_freq({self._sim_freq}) is not divisible by control_freq({self._control_freq})."

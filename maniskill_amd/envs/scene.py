@@ -15,6 +15,7 @@ import torch
 from maniskill_amd.model.compile import SceneModelBuilder
 from maniskill_amd.physx.system import MssimSystem
 from maniskill_amd.utils import common
+from maniskill_amd import physx
 from maniskill_amd.utils.building.actor_builder import ActorBuilder, PhysxMaterial
 from maniskill_amd.utils.building.urdf_loader import URDFLoader
 from maniskill_amd.utils.structs.actor import Actor, Link
@@ -138,6 +139,16 @@ class ManiSkillScene:
                     g[group] = int(value)
                     s.collision_groups = tuple(g)
 
+    def _set_scene_config(self):
+        sc = self.sim_config.scene_config
+        physx.set_shape_config(contact_offset=sc.contact_offset, rest_offset=sc.rest_offset)
+        physx.set_body_config(solver_position_iterations=sc.solver_position_iterations, solver_velocity_iterations=sc.solver_velocity_iterations,
+                              sleep_threshold=sc.sleep_threshold)
+        physx.set_scene_config(gravity=np.asarray(sc.gravity), bounce_threshold=sc.bounce_threshold, enable_pcm=sc.enable_pcm, enable_tgs=sc.enable_tgs,
+                               enable_ccd=sc.enable_ccd, enable_enhanced_determinism=sc.enable_enhanced_determinism,
+                               enable_friction_every_iteration=sc.enable_friction_every_iteration, cpu_workers=sc.cpu_workers)
+        physx.set_default_material(**self.sim_config.default_materials_config.dict())
+
     # ------------------------------------------------------------------ setup / stepping
     def _setup(self, enable_gpu: bool = True):
         """px.gpu_init + initial apply/fetch (scene.py:897-939)"""
@@ -146,17 +157,20 @@ class ManiSkillScene:
                 f"actors {sorted(self._fragments)} exist in a subset of the envs and were never merged: per-env distinct "
                 "object sets are not supported by this core (only Actor.merge of one fragment per env)"
             )
-        sc = self.sim_config.scene_config
+        # the env's SimConfig goes through the module-level setters like the reference's _set_scene_config
+        # (sapien_env.py:1066-1070); the model is compiled from the resulting process-wide defaults
+        self._set_scene_config()
+        cfg = physx.current_config()
         model = self._builder.compile(
             num_envs=self.num_envs,
             timestep=self.px.timestep,
-            gravity=tuple(float(g) for g in np.asarray(sc.gravity)),
-            contact_offset=sc.contact_offset,
-            rest_offset=sc.rest_offset,
-            bounce_threshold=sc.bounce_threshold,
-            position_iterations=sc.solver_position_iterations,
-            velocity_iterations=sc.solver_velocity_iterations,
-            sleep_threshold=sc.sleep_threshold,
+            gravity=cfg["scene"]["gravity"],
+            contact_offset=cfg["shape"]["contact_offset"],
+            rest_offset=cfg["shape"]["rest_offset"],
+            bounce_threshold=cfg["scene"]["bounce_threshold"],
+            position_iterations=cfg["body"]["solver_position_iterations"],
+            velocity_iterations=cfg["body"]["solver_velocity_iterations"],
+            sleep_threshold=cfg["body"]["sleep_threshold"],
         )
         self.px.gpu_init(model, self.num_envs)
         self.model = model

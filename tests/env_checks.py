@@ -338,3 +338,30 @@ def check_ee_controllers(sim_backend):
     now = base.agent.robot.pose.inv() * base.agent.tcp.pose
     assert torch.allclose(now.p, tgt[:, :3], atol=0.01), (now.p - tgt[:, :3])
     env.close()
+
+
+def check_physx_module_config(sim_backend):
+    """the env's SimConfig reaches the core through the module-level setters of `physx`, as in the reference
+    (sapien_env.py:256, 1066-1070); the setters reject arguments sapien.physx does not have"""
+    import pytest
+
+    from maniskill_amd import physx
+
+    physx.reset_config()
+    env = make("PickCube-v1", 2, sim_backend, sim_config=dict(scene_config=dict(contact_offset=0.03, solver_position_iterations=10, gravity=[0, 0, -5.0]),
+                                                               default_materials_config=dict(static_friction=0.5, dynamic_friction=0.5, restitution=0)))
+    cfg = physx.current_config()
+    assert cfg["shape"]["contact_offset"] == 0.03 and cfg["body"]["solver_position_iterations"] == 10
+    assert cfg["scene"]["gravity"] == (0.0, 0.0, -5.0) and cfg["material"]["static_friction"] == 0.5
+    assert cfg["gpu_memory"]["max_rigid_contact_count"] == 2**19
+    sc = env.unwrapped.scene.model.scalars
+    assert abs(float(sc["contact_offset"]) - 0.03) < 1e-7 and int(sc["position_iterations"]) == 10 and abs(float(sc["gravity"][2]) + 5.0) < 1e-6
+    env.close()
+    with pytest.raises(TypeError):
+        physx.set_shape_config(contact_ofset=0.01)
+    with pytest.raises(TypeError):
+        physx.set_scene_config(enable_magic=True)
+    physx.set_gpu_memory_config(max_rigid_contact_count=2**20)
+    assert physx.current_config()["gpu_memory"]["max_rigid_contact_count"] == 2**20
+    physx.reset_config()
+    assert physx.current_config()["shape"]["contact_offset"] == 0.02

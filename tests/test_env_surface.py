@@ -71,6 +71,10 @@ def test_unmerged_fragment_is_rejected():
         Partial(num_envs=4, sim_backend=BACKEND)
 
 
+def test_physx_module_config_flow():
+    ec.check_physx_module_config(BACKEND)
+
+
 def test_hip_backend_fails_loudly_without_gpu():
     import gymnasium as gym
 
