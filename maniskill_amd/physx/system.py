@@ -325,3 +325,27 @@ class MssimSystem:
     def body_rows(self, body_row: int) -> slice:
         """rows of `cuda_rigid_body_data` holding body `body_row` for envs 0..N-1"""
         return slice(body_row * self.num_envs, (body_row + 1) * self.num_envs)
+
+    # sub-scene bookkeeping of the reference (sapien_env.py:1080-1096) -----------------------------------
+    def set_scene_offset(self, scene, offset):
+        """The reference isolates its envs by spacing them out in ONE PhysX scene. Here every env has its own
+        frame, bodies of different envs can never meet, so the offset is recorded for `get_scene_offset` and
+        otherwise unused."""
+        self.__dict__.setdefault("_scene_offsets", {})[id(scene)] = np.asarray(offset, dtype=np.float32).reshape(3)
+
+    def get_scene_offset(self, scene) -> np.ndarray:
+        return self.__dict__.get("_scene_offsets", {}).get(id(scene), np.zeros(3, dtype=np.float32))
+
+    @property
+    def rigid_dynamic_components(self):
+        """names of the dynamic / kinematic free bodies, in row order (the reference lists component objects)"""
+        return list(self.model.free_names) + list(self.model.kin_names) if self.model is not None else []
+
+    @property
+    def articulation_link_components(self):
+        return list(self.model.link_names) if self.model is not None else []
+
+    def sync_poses_gpu_to_cpu(self):
+        """viewer hook of the reference (copies poses into the CPU entities for rendering); there are no CPU
+        entities here, the buffers read through `cuda_rigid_body_data` are the state"""
+        self.gpu_fetch_all()
