@@ -198,6 +198,12 @@ float MSSIM_FN(get_timestep)(mssim_handle h);
 int MSSIM_FN(apply)(mssim_handle h, uint32_t what, void* stream);
 /* px.gpu_fetch_*  (scene.py:959-977): simulation state -> user buffers */
 int MSSIM_FN(fetch)(mssim_handle h, uint32_t what, void* stream);
+/* The same copy-out, owed until the next call on the handle: a task epilogue (task_*_outputs) performs it
+ * inside its own launch, any other call that touches the state or the buffers performs it first. For the
+ * caller this is fetch() with one launch less per control step -- provided it does not read the bound buffers
+ * itself before that next call (BaseEnv.step: _gpu_fetch_all is directly followed by evaluate / get_obs,
+ * envs/sapien_env.py:1023-1049). */
+int MSSIM_FN(defer_fetch)(mssim_handle h, uint32_t what);
 /* px.step() x n_substeps (scene.py:374-375; loop at sapien_env.py:1016-1021).  No host sync. */
 int MSSIM_FN(step)(mssim_handle h, int32_t n_substeps, void* stream);
 /* px.gpu_update_articulation_kinematics() (sapien_env.py:861-865) */
@@ -234,6 +240,10 @@ int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
  * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host. */
 int MSSIM_FN(set_action_map)(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags);
 int MSSIM_FN(apply_action)(mssim_handle h, const float* action /* device [N][action_dim] */, int32_t action_dim, void* stream);
+/* apply_action followed by step(n_substeps) -- BaseEnv._step_action's set_action + substep loop
+ * (envs/sapien_env.py:1009-1021) -- as ONE launch when the control-step kernel is in use (the action map runs
+ * at its head); two launches otherwise. Same results as the two calls. */
+int MSSIM_FN(step_action)(mssim_handle h, const float* action /* device [N][action_dim] */, int32_t action_dim, int32_t n_substeps, void* stream);
 
 /* PickCube-style evaluate + state observation + dense reward in one launch
  * (envs/tasks/tabletop/pick_cube.py:99-158, agents/robots/panda/panda.py:236-298). Reads the

@@ -63,6 +63,15 @@ struct DevState {
   int* overflow;                                // [N]
   int row_slots;                                // LDS slots per lane for packed solver rows
   int glb_slots;                                // overflow slots per lane in `rows` (wave-contiguous: [block][slot][64])
+  // action of this control step, mapped to drive targets at the head of the fused launch (mssim_step_action);
+  // null = targets were set before the launch
+  const float* act;                             // [N][act_dim]
+  int act_dim;
+  const int* act_col;                           // [n_dof] action column, < 0: joint untouched
+  const float *act_lo, *act_hi;                 // [n_dof]
+  const int* act_flags;                         // [n_dof] 1: delta on the current position, 2: clip + affine map
+  const float* act_qpos;                        // user-visible qpos buffer (what the controller reads) or null
+  float* act_target;                            // user-visible target_qpos buffer or null
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -970,48 +979,67 @@ __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) 
 
 // fetch: grid (N/64, n_rows + 1). blockIdx.y < n_rows: one (body row, env) per lane -> consecutive
 // lanes write consecutive 52-byte records (coalesced); blockIdx.y == n_rows: the articulation arrays
-__global__ __launch_bounds__(64) void k_fetch(DevModel M, DevState S, mssim_buffers B, unsigned what) {
+// (device functions: k_fetch runs them one (row, env) per lane, the fetch + task-epilogue launches run the
+// rows of an env over 4 lanes of one block)
+MS_DEV void fetch_row(const DevModel& M, const DevState& S, const mssim_buffers& B, unsigned what, int e, int row) {
   const int N = S.N;
-  const int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  if (e >= N) return;
-  const int n = M.n_dof;
-  const int R = M.n_link + M.n_free + M.n_kin;
-  const int row = blockIdx.y;
-  if (row < R) {
-    if (!B.rigid_body_data) return;
-    float* r = B.rigid_body_data + 13 * ((size_t)row * N + e);
-    if (row < M.n_link) {
-      if (!(what & (MSSIM_LINK_POSE | MSSIM_LINK_VEL))) return;
-      const pose_t root = pose_soa(S.root, 0, N, e);
-      const int b = M.link_body[row];
-      const pose_t P = pmul(b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e), pose_from(M.link_frame + 7 * row));
-      if (what & MSSIM_LINK_POSE) { r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z; }
-      if (what & MSSIM_LINK_VEL) {
-        f3 w = f3{0, 0, 0}, vv = f3{0, 0, 0};
-        if (b >= 0) {
-          w = f3{SOA(S.bodyvel, 6 * b), SOA(S.bodyvel, 6 * b + 1), SOA(S.bodyvel, 6 * b + 2)};
-          vv = f3{SOA(S.bodyvel, 6 * b + 3), SOA(S.bodyvel, 6 * b + 4), SOA(S.bodyvel, 6 * b + 5)} + cross(w, P.p - root.p);
-        }
-        r[7] = vv.x; r[8] = vv.y; r[9] = vv.z; r[10] = w.x; r[11] = w.y; r[12] = w.z;
+  if (!B.rigid_body_data) return;
+  float* r = B.rigid_body_data + 13 * ((size_t)row * N + e);
+  if (row < M.n_link) {
+    if (!(what & (MSSIM_LINK_POSE | MSSIM_LINK_VEL))) return;
+    const pose_t root = pose_soa(S.root, 0, N, e);
+    const int b = M.link_body[row];
+    const pose_t P = pmul(b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e), pose_from(M.link_frame + 7 * row));
+    if (what & MSSIM_LINK_POSE) { r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z; }
+    if (what & MSSIM_LINK_VEL) {
+      f3 w = f3{0, 0, 0}, vv = f3{0, 0, 0};
+      if (b >= 0) {
+        w = f3{SOA(S.bodyvel, 6 * b), SOA(S.bodyvel, 6 * b + 1), SOA(S.bodyvel, 6 * b + 2)};
+        vv = f3{SOA(S.bodyvel, 6 * b + 3), SOA(S.bodyvel, 6 * b + 4), SOA(S.bodyvel, 6 * b + 5)} + cross(w, P.p - root.p);
       }
-    } else if (what & MSSIM_RIGID_DATA) {
-      if (row < M.n_link + M.n_free) {
-        const int b = row - M.n_link;
-        for (int c = 0; c < 13; c++) r[c] = SOA(S.free_s, 13 * b + c);
-      } else {
-        const int k = row - M.n_link - M.n_free;
-        const pose_t P = pose_soa(S.kin, 7 * k, N, e);
-        r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z;
-        for (int c = 7; c < 13; c++) r[c] = 0.f;
-      }
+      r[7] = vv.x; r[8] = vv.y; r[9] = vv.z; r[10] = w.x; r[11] = w.y; r[12] = w.z;
     }
-    return;
+  } else if (what & MSSIM_RIGID_DATA) {
+    if (row < M.n_link + M.n_free) {
+      const int b = row - M.n_link;
+      for (int c = 0; c < 13; c++) r[c] = SOA(S.free_s, 13 * b + c);
+    } else {
+      const int k = row - M.n_link - M.n_free;
+      const pose_t P = pose_soa(S.kin, 7 * k, N, e);
+      r[0] = P.p.x; r[1] = P.p.y; r[2] = P.p.z; r[3] = P.q.w; r[4] = P.q.x; r[5] = P.q.y; r[6] = P.q.z;
+      for (int c = 7; c < 13; c++) r[c] = 0.f;
+    }
   }
+}
+MS_DEV void fetch_art(const DevModel& M, const DevState& S, const mssim_buffers& B, unsigned what, int e) {
+  const int N = S.N;
+  const int n = M.n_dof;
   if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) B.art_qpos[(size_t)e * n + j] = SOA(S.q, j);
   if ((what & MSSIM_ART_QVEL) && B.art_qvel) for (int j = 0; j < n; j++) B.art_qvel[(size_t)e * n + j] = SOA(S.qd, j);
   if ((what & MSSIM_ART_QACC) && B.art_qacc) for (int j = 0; j < n; j++) B.art_qacc[(size_t)e * n + j] = SOA(S.qacc, j);
   if ((what & MSSIM_ART_TARGET_POS) && B.art_target_qpos) for (int j = 0; j < n; j++) B.art_target_qpos[(size_t)e * n + j] = SOA(S.qt, j);
   if ((what & MSSIM_ART_TARGET_VEL) && B.art_target_qvel) for (int j = 0; j < n; j++) B.art_target_qvel[(size_t)e * n + j] = SOA(S.qdt, j);
+}
+__global__ __launch_bounds__(64) void k_fetch(DevModel M, DevState S, mssim_buffers B, unsigned what) {
+  const int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  if (e >= S.N) return;
+  const int R = M.n_link + M.n_free + M.n_kin;
+  if ((int)blockIdx.y < R) fetch_row(M, S, B, what, e, blockIdx.y);
+  else fetch_art(M, S, B, what, e);
+}
+// fetch inside a task-epilogue launch (256 threads = 64 envs x 4 lanes): the 4 lanes of an env share its
+// rows, then one of them runs the epilogue on what the block just wrote (same CU, same L1)
+MS_DEV int fetch_in_block(const DevModel& M, const DevState& S, const mssim_buffers& B, unsigned what) {
+  const int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + (threadIdx.x & 63);
+  const int ty = threadIdx.x >> 6;
+  if (e < S.N) {
+    const int R = M.n_link + M.n_free + M.n_kin;
+    for (int row = ty; row < R; row += 4) fetch_row(M, S, B, what, e, row);
+    if (ty == 3) fetch_art(M, S, B, what, e);
+  }
+  __threadfence_block();
+  __syncthreads();
+  return (ty == 0 && e < S.N) ? e : -1;
 }
 
 // contact impulse queries: q = [nq][2] body rows (pair query) or [nq] rows (body query)
@@ -1059,11 +1087,14 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
 }
 
 // PickCube-style evaluate / obs / reward
-__global__ __launch_bounds__(64) void k_task_pick(DevModel M, DevState S, mssim_buffers B, mssim_pick_task T, const int* __restrict__ pairs, int npairs,
-                                                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags) {
+// FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
+template <bool FETCH>
+__global__ __launch_bounds__(256) void k_task_pick(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_pick_task T, const int* __restrict__ pairs, int npairs,
+                                                    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags) {
   const int N = S.N;
-  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= N) return;
+  int e;
+  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
+  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= N) return; }
   const int n = M.n_dof;
   const int D = 2 * n + 24;
   float* o = obs + (size_t)e * D;
@@ -1126,11 +1157,13 @@ __global__ __launch_bounds__(64) void k_task_pick(DevModel M, DevState S, mssim_
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
 
-__global__ void k_task_push(DevModel M, DevState S, mssim_buffers B, mssim_push_task T, float* __restrict__ obs, float* __restrict__ reward,
-                            uint8_t* __restrict__ flags) {
+template <bool FETCH>
+__global__ __launch_bounds__(256) void k_task_push(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_push_task T, float* __restrict__ obs, float* __restrict__ reward,
+                                                    uint8_t* __restrict__ flags) {
   const int N = S.N;
-  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= N) return;
+  int e;
+  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
+  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= N) return; }
   const int n = M.n_dof;
   float* o = obs + (size_t)e * (2 * n + 17);
   auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
@@ -1177,11 +1210,13 @@ MS_DEV pose_t tq_inv(pose_t a) {
   return pose_t{tq_apply(qc, -a.p), qc};
 }
 // PegInsertionSide evaluate / obs / reward (peg_insertion_side.py:247-355)
-__global__ __launch_bounds__(64) void k_task_peg(DevModel M, DevState S, mssim_buffers B, mssim_peg_task T, const int* __restrict__ pairs, int npairs,
-                                                  float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, float* __restrict__ head_out) {
+template <bool FETCH>
+__global__ __launch_bounds__(256) void k_task_peg(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_peg_task T, const int* __restrict__ pairs, int npairs,
+                                                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, float* __restrict__ head_out) {
   const int N = S.N;
-  int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= N) return;
+  int e;
+  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
+  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= N) return; }
   const int n = M.n_dof;
   float* o = obs + (size_t)e * (2 * n + 25);
   auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
@@ -1290,6 +1325,7 @@ struct mssim_sim {
   float* d_drive = nullptr;
   bool panda = false;
   bool dirty = true;
+  unsigned deferred_fetch = 0u;  // mssim_defer_fetch: copy-out owed to the next call on the handle
   std::vector<float> h_dof_pack; float* d_dof_pack = nullptr;  // (drive gains are patched by set_drive_properties)
   std::vector<int32_t> h_shape_row, h_pair_shape;  // host copies (contact-pair lists of the task epilogues)
   int* d_pick_pairs = nullptr; int n_pick_pairs = 0; int pick_rows[3] = {-1, -1, -1};
@@ -1555,7 +1591,9 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   return 0;
 }
 
+static void flush_deferred_fetch(mssim_handle h, hipStream_t st);
 int mssim_bind_buffers(mssim_handle h, const mssim_buffers* b) {
+  flush_deferred_fetch(h, (hipStream_t)0);
   if (!h || !b) return 1;
   h->buf = *b;
   return 0;
@@ -1581,13 +1619,32 @@ static inline int pad8(int n) { return (n + 7) / 8 * 8; }
 static inline dim3 env_grid(int N, int block) { return dim3(pad8((N + block - 1) / block)); }  // kernels map blocks with xcd_chunk
 
 int mssim_apply(mssim_handle h, uint32_t what, void* stream) {
+  flush_deferred_fetch(h, (hipStream_t)stream);
   hipLaunchKernelGGL(k_apply, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
   h->dirty = true;
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
+// Deferred fetch (mssim_defer_fetch): the copy-out is owed until the next call on the handle. A task epilogue
+// performs it inside its own launch (k_task_*<true>); every other entry point that touches the state or
+// the buffers performs it first, so the deferral is only an ordering of launches, never a change of results.
+static unsigned take_deferred_fetch(mssim_handle h) {
+  const unsigned w = h->deferred_fetch;
+  h->deferred_fetch = 0u;
+  return w;
+}
+static void flush_deferred_fetch(mssim_handle h, hipStream_t st) {
+  if (const unsigned w = take_deferred_fetch(h))
+    hipLaunchKernelGGL(k_fetch, dim3(pad8((h->N + 63) / 64), h->M.n_link + h->M.n_free + h->M.n_kin + 1), dim3(64), 0, st, h->M, h->S, h->buf, w);
+}
+int mssim_defer_fetch(mssim_handle h, uint32_t what) {
+  h->deferred_fetch |= what;
+  return 0;
+}
+
 int mssim_fetch(mssim_handle h, uint32_t what, void* stream) {
+  what |= take_deferred_fetch(h);
   hipLaunchKernelGGL(k_fetch, dim3(pad8((h->N + 63) / 64), h->M.n_link + h->M.n_free + h->M.n_kin + 1), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -1599,6 +1656,7 @@ static void launch_fk(mssim_handle h, hipStream_t st) {
 }
 
 int mssim_update_kinematics(mssim_handle h, void* stream) {
+  flush_deferred_fetch(h, (hipStream_t)stream);
   launch_fk(h, (hipStream_t)stream);
   h->dirty = false;
   HIPCHK(h, hipGetLastError());
@@ -1611,6 +1669,7 @@ static inline void prof_mark(mssim_handle h, int k, hipStream_t st) {
 }
 
 int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
+  flush_deferred_fetch(h, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
   if (h->fused && n_substeps > 0) {
@@ -1633,6 +1692,27 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
     else hipLaunchKernelGGL(k_solve<TopoDyn>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
     prof_mark(h, 0, st);
   }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int mssim_step_action(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream) {
+  flush_deferred_fetch(h, (hipStream_t)stream);
+  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (!(h->fused && n_substeps > 0)) {  // per-substep kernels: the two launches of apply_action + step
+    const int rc = mssim_apply_action(h, action, action_dim, stream);
+    return rc ? rc : mssim_step(h, n_substeps, stream);
+  }
+  if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+  DevState S = h->S;
+  S.act = action; S.act_dim = action_dim;
+  S.act_col = h->d_act_col; S.act_lo = h->d_act_lo; S.act_hi = h->d_act_hi; S.act_flags = h->d_act_flags;
+  S.act_qpos = h->buf.art_qpos; S.act_target = h->buf.art_target_qpos;
+  prof_mark(h, 0, st);
+  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<true, 9>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, (int)n_substeps);
+  else hipLaunchKernelGGL((k_solve16<true, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, (int)n_substeps);
+  prof_mark(h, 0, st);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1692,6 +1772,7 @@ int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low
 }
 
 int mssim_apply_action(mssim_handle h, const float* action, int32_t action_dim, void* stream) {
+  flush_deferred_fetch(h, (hipStream_t)stream);
   if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
   hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, action, action_dim,
                      h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags);
@@ -1728,7 +1809,10 @@ int mssim_task_peg_outputs(mssim_handle h, const mssim_peg_task* task, float* ob
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
   if (!task->peg_half_sizes || !task->box_hole_offsets || !task->box_hole_radii || !head_at_hole) { h->err = "task_peg_outputs: missing per-env geometry / output"; return 3; }
   { int rc = finger_pair_list(h, task->peg_row, task->finger1_row, task->finger2_row); if (rc) return rc; }
-  hipLaunchKernelGGL(k_task_peg, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags, head_at_hole);
+  if (const unsigned what = take_deferred_fetch(h))
+    hipLaunchKernelGGL(k_task_peg<true>, env_grid(h->N, 64), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags, head_at_hole);
+  else
+    hipLaunchKernelGGL(k_task_peg<false>, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, 0u, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags, head_at_hole);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1740,7 +1824,10 @@ int mssim_task_pick_outputs(mssim_handle h, const mssim_pick_task* task, float* 
     if (r < 0 || r >= R) { h->err = "task_pick_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
   { int rc = finger_pair_list(h, task->obj_row, task->finger1_row, task->finger2_row); if (rc) return rc; }
-  hipLaunchKernelGGL(k_task_pick, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags);
+  if (const unsigned what = take_deferred_fetch(h))
+    hipLaunchKernelGGL(k_task_pick<true>, env_grid(h->N, 64), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags);
+  else
+    hipLaunchKernelGGL(k_task_pick<false>, env_grid(h->N, 64), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, 0u, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1751,7 +1838,10 @@ int mssim_task_push_outputs(mssim_handle h, const mssim_push_task* task, float* 
   for (int r : rows)
     if (r < 0 || r >= R) { h->err = "task_push_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
-  hipLaunchKernelGGL(k_task_push, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, *task, obs, reward, flags);
+  if (const unsigned what = take_deferred_fetch(h))
+    hipLaunchKernelGGL(k_task_push<true>, env_grid(h->N, 64), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what, *task, obs, reward, flags);
+  else
+    hipLaunchKernelGGL(k_task_push<false>, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, 0u, *task, obs, reward, flags);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -485,6 +485,25 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     aw_c = f3{SOA(S.bodyaux, 6 * c), SOA(S.bodyaux, 6 * c + 1), SOA(S.bodyaux, 6 * c + 2)};
     an_c = f3{SOA(S.bodyaux, 6 * c + 3), SOA(S.bodyaux, 6 * c + 4), SOA(S.bodyaux, 6 * c + 5)};
   }
+  // this control step's action -> drive target of joint c (mssim_step_action; same arithmetic as
+  // k_apply_action). The target is read back by this lane in every substep.
+  if (FUSED && S.act && art) {
+    const int cj = S.act_col[c];
+    if (cj >= 0) {
+      float a = S.act[(size_t)e * S.act_dim + cj];
+      const int fl = S.act_flags[c];
+      if (fl & 2) {
+        a = fminf(fmaxf(a, -1.f), 1.f);
+        a = 0.5f * (S.act_hi[c] + S.act_lo[c]) + 0.5f * (S.act_hi[c] - S.act_lo[c]) * a;
+      }
+      const float qj = S.act_qpos ? S.act_qpos[(size_t)e * n + c] : q_c;
+      const float t = ((fl & 1) ? qj : 0.f) + a;
+      if (live) {
+        SOA(S.qt, c) = t;
+        if (S.act_target) S.act_target[(size_t)e * n + c] = t;
+      }
+    }
+  }
   const unsigned self_c = art ? (1u << c) : 0u;
   float qacc_c = 0.f;
   // free-body velocity component of this lane; pose and the external force live in the pose table / registers

@@ -455,7 +455,9 @@ class BaseEnv(gym.Env):
 
     # ------------------------------------------------------------------ step
     def step(self, action: Union[None, np.ndarray, torch.Tensor, Dict]):
+        self._fused_epilogue_next = self._use_fused_callers and self._fused_ok()
         action = self._step_action(action)
+        self._fused_epilogue_next = False
         # the fused task epilogue also advances `_elapsed_steps` (one launch instead of add + copy)
         fused = self._fused_step_outputs(action) if self._use_fused_callers else None
         if fused is not None:
@@ -514,7 +516,13 @@ class BaseEnv(gym.Env):
             if self.num_envs == 1 and unbatched:
                 action = common.batch(action)
             if self._fused_action_ready(action):
-                # one launch instead of the controller's ~10 torch ops + 2 applies (same arithmetic)
+                # one launch instead of the controller's ~10 torch ops + 2 applies (same arithmetic); without
+                # hooks between set_action and the substeps the map runs at the head of the step's own launch
+                if self._no_step_hooks():
+                    self.scene.px.step_action(action, self._sim_steps_per_control)
+                    # `step` runs the task's fused epilogue next: it copies the state out in its own launch
+                    self.scene._gpu_fetch_all(defer=self._fused_epilogue_next)
+                    return action
                 self.scene.px.apply_action(action)
             else:
                 self.agent.set_action(action)
@@ -538,6 +546,20 @@ class BaseEnv(gym.Env):
         self.scene._gpu_fetch_all()
         return action
 
+    def _no_step_hooks(self) -> bool:
+        """no task / controller code has to run between setting the action and the end of the control step"""
+        ok = self.__dict__.get("_no_step_hooks_cached")
+        if ok is None:
+            cls = type(self)
+            ok = (
+                cls._before_control_step is BaseEnv._before_control_step
+                and cls._after_control_step is BaseEnv._after_control_step
+                and not self._substep_hooks_overridden()
+                and hasattr(self.scene.px, "step_action")
+            )
+            self.__dict__["_no_step_hooks_cached"] = ok
+        return ok and not getattr(self.agent.controller, "needs_per_substep_update", False)
+
     def _fused_action_ready(self, action) -> bool:
         """native affine action->target map usable for the current controller? (HIP backend only)"""
         if not self._use_fused_callers or not isinstance(action, torch.Tensor) or action.dtype != torch.float32 or action.dim() != 2:
@@ -550,6 +572,12 @@ class BaseEnv(gym.Env):
             if spec is not None:
                 self.scene.px.set_action_map(*spec)
         return self._fused_action_ok and action.is_contiguous()
+
+    _fused_epilogue_next = False
+
+    def _fused_ok(self) -> bool:
+        """will `_fused_step_outputs` produce this step's outputs? (tasks with a native epilogue override both)"""
+        return False
 
     def _fused_step_outputs(self, action):
         """tasks may return (obs, reward, info) computed by a fused native kernel; None = torch path"""

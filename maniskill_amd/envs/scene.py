@@ -200,9 +200,12 @@ class ManiSkillScene:
         self.px.gpu_apply_all()
         self._needs_fetch = True
 
-    def _gpu_fetch_all(self):
-        """scene.py:959-977"""
-        self.px.gpu_fetch_all()
+    def _gpu_fetch_all(self, defer: bool = False):
+        """scene.py:959-977. `defer`: the caller runs a fused task epilogue next, which copies out in its own launch"""
+        if defer:
+            self.px.defer_fetch_all()
+        else:
+            self.px.gpu_fetch_all()
         self._needs_fetch = False
 
     # ------------------------------------------------------------------ contacts

@@ -186,6 +186,8 @@ class NativeLib:
         f("overflow_count", C.c_int, [H, C.c_void_p])
         f("set_action_map", C.c_int, [H, _I32P, _F32P, _F32P, _I32P])
         f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
+        f("step_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
+        f("defer_fetch", C.c_int, [H, C.c_uint32])
         f("task_pick_outputs", C.c_int, [H, C.POINTER(PickTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("task_peg_outputs", C.c_int, [H, C.POINTER(PegTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("task_push_outputs", C.c_int, [H, C.POINTER(PushTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
@@ -200,7 +202,7 @@ class NativeLib:
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
         "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map",
-        "apply_action", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
+        "apply_action", "step_action", "defer_fetch", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
         "profile_read", "last_error",
         "abi_version",
     ]
@@ -261,6 +263,9 @@ class NativeSim:
     def fetch(self, what, stream=None):
         self._check(self.lib.fetch(self.h, what, stream), "fetch")
 
+    def defer_fetch(self, what):
+        self._check(self.lib.defer_fetch(self.h, what), "defer_fetch")
+
     def step(self, n_substeps=1, stream=None):
         self._check(self.lib.step(self.h, n_substeps, stream), "step")
 
@@ -315,6 +320,9 @@ class NativeSim:
 
     def apply_action(self, action_ptr, action_dim, stream=None):
         self._check(self.lib.apply_action(self.h, action_ptr, action_dim, stream), "apply_action")
+
+    def step_action(self, action_ptr, action_dim, n_substeps, stream=None):
+        self._check(self.lib.step_action(self.h, action_ptr, action_dim, n_substeps, stream), "step_action")
 
     def task_peg_outputs(self, task: "PegTask", obs_ptr, reward_ptr, flags_ptr, head_ptr, stream=None):
         self._check(self.lib.task_peg_outputs(self.h, C.byref(task), obs_ptr, reward_ptr, flags_ptr, head_ptr, stream), "task_peg_outputs")

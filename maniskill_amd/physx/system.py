@@ -246,6 +246,11 @@ class MssimSystem:
     def gpu_fetch_all(self):
         self._fetch(native.ALL)
 
+    def defer_fetch_all(self):
+        """gpu_fetch_all owed to the next native call: the task epilogue that follows performs it inside its own
+        launch (include/mssim.h `defer_fetch`). Only for callers that issue that call next."""
+        self._sim.defer_fetch(native.ALL)
+
     # ------------------------------------------------------------------ contact queries
     def gpu_create_contact_pair_impulse_query(self, body_pairs: Sequence[Tuple[int, int]]) -> ContactPairImpulseQuery:
         """body_pairs: (row_a, row_b) body rows of `cuda_rigid_body_data` (row index // num_envs),
@@ -301,6 +306,11 @@ class MssimSystem:
         """affine action -> drive targets in one launch (include/mssim.h `apply_action`)"""
         assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs
         self._sim.apply_action(action.data_ptr(), action.shape[1], self._stream())
+
+    def step_action(self, action: torch.Tensor, n_substeps: int):
+        """`apply_action` + `step(n_substeps)` in one launch (include/mssim.h `step_action`)"""
+        assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs
+        self._sim.step_action(action.data_ptr(), action.shape[1], n_substeps, self._stream())
 
     def task_peg_outputs(self, task, obs: torch.Tensor, reward: torch.Tensor, flags: torch.Tensor, head: torch.Tensor):
         self._sim.task_peg_outputs(task, obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), head.data_ptr(), self._stream())
