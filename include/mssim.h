@@ -244,6 +244,11 @@ int MSSIM_FN(apply_action)(mssim_handle h, const float* action /* device [N][act
  * (envs/sapien_env.py:1009-1021) -- as ONE launch when the control-step kernel is in use (the action map runs
  * at its head); two launches otherwise. Same results as the two calls. */
 int MSSIM_FN(step_action)(mssim_handle h, const float* action /* device [N][action_dim] */, int32_t action_dim, int32_t n_substeps, void* stream);
+/* The same, owed until the next call on the handle (the action array must stay valid until then). If that call
+ * is a task epilogue (task_*_outputs) on the same stream with a copy-out owed as well (defer_fetch), the WHOLE
+ * control step -- action map, substeps, copy-out, evaluate / obs / reward -- is one launch of the control-step
+ * kernel; any other call first performs what is owed, in order. Results are those of the separate calls. */
+int MSSIM_FN(defer_step_action)(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream);
 
 /* PickCube-style evaluate + state observation + dense reward in one launch
  * (envs/tasks/tabletop/pick_cube.py:99-158, agents/robots/panda/panda.py:236-298). Reads the

@@ -72,6 +72,13 @@ struct DevState {
   const int* act_flags;                         // [n_dof] 1: delta on the current position, 2: clip + affine map
   const float* act_qpos;                        // user-visible qpos buffer (what the controller reads) or null
   float* act_target;                            // user-visible target_qpos buffer or null
+  // copy-out + task epilogue at the tail of the fused launch (whole control step = one launch); 0 = none
+  unsigned tail_fetch;                          // mssim_fetch mask
+  mssim_buffers tail_buf;
+  union { mssim_pick_task pick; mssim_push_task push; mssim_peg_task peg; } tail_task;  // kind = template TASK
+  const int* tail_pairs; int tail_npairs;       // finger <-> object candidate pairs
+  float *tail_obs, *tail_reward, *tail_head;
+  uint8_t* tail_flags;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -942,8 +949,6 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
 #undef FB
 }
 
-#include "mssim_solve16.h"
-
 // ------------------------------------------------------------------------------------------------
 // apply / fetch: transposes between the user-visible AoS buffers and the SoA state
 __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) {
@@ -1010,6 +1015,16 @@ MS_DEV void fetch_row(const DevModel& M, const DevState& S, const mssim_buffers&
       for (int c = 7; c < 13; c++) r[c] = 0.f;
     }
   }
+}
+// one joint per lane (the control-step kernel's tail)
+MS_DEV void fetch_art_joint(const DevModel& M, const DevState& S, const mssim_buffers& B, unsigned what, int e, int j) {
+  const int N = S.N;
+  const int n = M.n_dof;
+  if ((what & MSSIM_ART_QPOS) && B.art_qpos) B.art_qpos[(size_t)e * n + j] = SOA(S.q, j);
+  if ((what & MSSIM_ART_QVEL) && B.art_qvel) B.art_qvel[(size_t)e * n + j] = SOA(S.qd, j);
+  if ((what & MSSIM_ART_QACC) && B.art_qacc) B.art_qacc[(size_t)e * n + j] = SOA(S.qacc, j);
+  if ((what & MSSIM_ART_TARGET_POS) && B.art_target_qpos) B.art_target_qpos[(size_t)e * n + j] = SOA(S.qt, j);
+  if ((what & MSSIM_ART_TARGET_VEL) && B.art_target_qvel) B.art_target_qvel[(size_t)e * n + j] = SOA(S.qdt, j);
 }
 MS_DEV void fetch_art(const DevModel& M, const DevState& S, const mssim_buffers& B, unsigned what, int e) {
   const int N = S.N;
@@ -1088,13 +1103,9 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
 
 // PickCube-style evaluate / obs / reward
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
-template <bool FETCH>
-__global__ __launch_bounds__(256) void k_task_pick(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_pick_task T, const int* __restrict__ pairs, int npairs,
-                                                    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags) {
+MS_DEV void task_pick_env(const DevModel& M, const DevState& S, const mssim_buffers& B, const mssim_pick_task& T, const int* __restrict__ pairs, int npairs,
+                                                    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, int e) {
   const int N = S.N;
-  int e;
-  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
-  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= N) return; }
   const int n = M.n_dof;
   const int D = 2 * n + 24;
   float* o = obs + (size_t)e * D;
@@ -1156,14 +1167,19 @@ __global__ __launch_bounds__(256) void k_task_pick(DevModel M, DevState S, mssim
   f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
-
+// FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
 template <bool FETCH>
-__global__ __launch_bounds__(256) void k_task_push(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_push_task T, float* __restrict__ obs, float* __restrict__ reward,
-                                                    uint8_t* __restrict__ flags) {
-  const int N = S.N;
+__global__ __launch_bounds__(256) void k_task_pick(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_pick_task T, const int* __restrict__ pairs, int npairs,
+                                                    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags) {
   int e;
   if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
-  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= N) return; }
+  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= S.N) return; }
+  task_pick_env(M, S, B, T, pairs, npairs, obs, reward, flags, e);
+}
+
+MS_DEV void task_push_env(const DevModel& M, const DevState& S, const mssim_buffers& B, const mssim_push_task& T, float* __restrict__ obs, float* __restrict__ reward,
+                                                    uint8_t* __restrict__ flags, int e) {
+  const int N = S.N;
   const int n = M.n_dof;
   float* o = obs + (size_t)e * (2 * n + 17);
   auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
@@ -1191,6 +1207,15 @@ __global__ __launch_bounds__(256) void k_task_push(DevModel M, DevState S, mssim
   flags[e] = success;
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
+// FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
+template <bool FETCH>
+__global__ __launch_bounds__(256) void k_task_push(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_push_task T, float* __restrict__ obs, float* __restrict__ reward,
+                                                    uint8_t* __restrict__ flags) {
+  int e;
+  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
+  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= S.N) return; }
+  task_push_env(M, S, B, T, obs, reward, flags, e);
+}
 
 // Pose algebra exactly as the Python `Pose` class does it (utils/structs/pose.py, rotation_conversions.py:
 // no re-normalisation, rotation as p + w t + v x t with t = 2 v x p, product standardised to w >= 0), so
@@ -1210,13 +1235,9 @@ MS_DEV pose_t tq_inv(pose_t a) {
   return pose_t{tq_apply(qc, -a.p), qc};
 }
 // PegInsertionSide evaluate / obs / reward (peg_insertion_side.py:247-355)
-template <bool FETCH>
-__global__ __launch_bounds__(256) void k_task_peg(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_peg_task T, const int* __restrict__ pairs, int npairs,
-                                                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, float* __restrict__ head_out) {
+MS_DEV void task_peg_env(const DevModel& M, const DevState& S, const mssim_buffers& B, const mssim_peg_task& T, const int* __restrict__ pairs, int npairs,
+                                                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, float* __restrict__ head_out, int e) {
   const int N = S.N;
-  int e;
-  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
-  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= N) return; }
   const int n = M.n_dof;
   float* o = obs + (size_t)e * (2 * n + 25);
   auto rowp = [&](int row) { return B.rigid_body_data + 13 * ((size_t)row * N + e); };
@@ -1278,6 +1299,15 @@ __global__ __launch_bounds__(256) void k_task_peg(DevModel M, DevState S, mssim_
   head_out[3 * (size_t)e] = hah.x; head_out[3 * (size_t)e + 1] = hah.y; head_out[3 * (size_t)e + 2] = hah.z;
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
 }
+// FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
+template <bool FETCH>
+__global__ __launch_bounds__(256) void k_task_peg(DevModel M, DevState S, mssim_buffers B, unsigned what, mssim_peg_task T, const int* __restrict__ pairs, int npairs,
+                                                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, float* __restrict__ head_out) {
+  int e;
+  if (FETCH) { e = fetch_in_block(M, S, B, what); if (e < 0) return; }
+  else { e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x; if (e >= S.N) return; }
+  task_peg_env(M, S, B, T, pairs, npairs, obs, reward, flags, head_out, e);
+}
 
 // geometric Jacobian of link `link` in the root frame: out [N][6][n_dof] (see include/mssim.h)
 __global__ void k_link_jacobian(DevModel M, DevState S, int link, float* __restrict__ out) {
@@ -1314,6 +1344,8 @@ __global__ void k_i2f(const int* src, float* dst, size_t count) {
 
 // =================================================================================================
 // host side
+#include "mssim_solve16.h"
+
 struct mssim_sim {
   int device = 0;
   int N = 0;
@@ -1325,7 +1357,11 @@ struct mssim_sim {
   float* d_drive = nullptr;
   bool panda = false;
   bool dirty = true;
+  int n_cu = 256;  // compute units of the device
   unsigned deferred_fetch = 0u;  // mssim_defer_fetch: copy-out owed to the next call on the handle
+  // mssim_defer_step_action: a step_action owed to the next call; a task epilogue runs it, the copy-out and
+  // itself as ONE launch of the control-step kernel
+  const float* deferred_action = nullptr; int deferred_adim = 0, deferred_nsub = 0; hipStream_t deferred_stream = nullptr;
   std::vector<float> h_dof_pack; float* d_dof_pack = nullptr;  // (drive gains are patched by set_drive_properties)
   std::vector<int32_t> h_shape_row, h_pair_shape;  // host copies (contact-pair lists of the task epilogues)
   int* d_pick_pairs = nullptr; int n_pick_pairs = 0; int pick_rows[3] = {-1, -1, -1};
@@ -1408,6 +1444,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   S->N = num_envs;
   hipError_t e0 = hipSetDevice(device);
   if (e0 != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e0); delete S; return 6; }
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) S->n_cu = ncu; }
   DevModel& M = S->M;
   M.n_dof = d->n_dof; M.n_tendon = d->n_tendon; M.n_link = d->n_link; M.n_free = d->n_free; M.n_kin = d->n_kin;
   M.n_shape = d->n_shape; M.n_pair = d->n_pair; M.n_words = (d->n_pair + 31) / 32;
@@ -1591,15 +1628,16 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   return 0;
 }
 
-static void flush_deferred_fetch(mssim_handle h, hipStream_t st);
+static void flush_deferred(mssim_handle h, hipStream_t st);
 int mssim_bind_buffers(mssim_handle h, const mssim_buffers* b) {
-  flush_deferred_fetch(h, (hipStream_t)0);
+  if (h) flush_deferred(h, (hipStream_t)0);
   if (!h || !b) return 1;
   h->buf = *b;
   return 0;
 }
 
 int mssim_set_timestep(mssim_handle h, float dt) {
+  flush_deferred(h, h->deferred_stream);
   if (!(dt > 0.f)) { h->err = "timestep must be positive"; return 1; }
   h->M.dt = dt;
   return 0;
@@ -1607,6 +1645,7 @@ int mssim_set_timestep(mssim_handle h, float dt) {
 float mssim_get_timestep(mssim_handle h) { return h->M.dt; }
 
 int mssim_set_drive_properties(mssim_handle h, const float* drive) {
+  flush_deferred(h, h->deferred_stream);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpy(h->d_drive, drive, sizeof(float) * 4 * h->M.n_dof, hipMemcpyHostToDevice));
   for (int j = 0; j < h->M.n_dof; j++)
@@ -1619,7 +1658,7 @@ static inline int pad8(int n) { return (n + 7) / 8 * 8; }
 static inline dim3 env_grid(int N, int block) { return dim3(pad8((N + block - 1) / block)); }  // kernels map blocks with xcd_chunk
 
 int mssim_apply(mssim_handle h, uint32_t what, void* stream) {
-  flush_deferred_fetch(h, (hipStream_t)stream);
+  flush_deferred(h, (hipStream_t)stream);
   hipLaunchKernelGGL(k_apply, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
   h->dirty = true;
   HIPCHK(h, hipGetLastError());
@@ -1645,6 +1684,7 @@ int mssim_defer_fetch(mssim_handle h, uint32_t what) {
 
 int mssim_fetch(mssim_handle h, uint32_t what, void* stream) {
   what |= take_deferred_fetch(h);
+  flush_deferred(h, (hipStream_t)stream);
   hipLaunchKernelGGL(k_fetch, dim3(pad8((h->N + 63) / 64), h->M.n_link + h->M.n_free + h->M.n_kin + 1), dim3(64), 0, (hipStream_t)stream, h->M, h->S, h->buf, what);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -1656,7 +1696,7 @@ static void launch_fk(mssim_handle h, hipStream_t st) {
 }
 
 int mssim_update_kinematics(mssim_handle h, void* stream) {
-  flush_deferred_fetch(h, (hipStream_t)stream);
+  flush_deferred(h, (hipStream_t)stream);
   launch_fk(h, (hipStream_t)stream);
   h->dirty = false;
   HIPCHK(h, hipGetLastError());
@@ -1669,7 +1709,7 @@ static inline void prof_mark(mssim_handle h, int k, hipStream_t st) {
 }
 
 int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
-  flush_deferred_fetch(h, (hipStream_t)stream);
+  flush_deferred(h, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
   if (h->fused && n_substeps > 0) {
@@ -1696,28 +1736,59 @@ int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
   return 0;
 }
 
-int mssim_step_action(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream) {
-  flush_deferred_fetch(h, (hipStream_t)stream);
-  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
-  hipStream_t st = (hipStream_t)stream;
-  if (!(h->fused && n_substeps > 0)) {  // per-substep kernels: the two launches of apply_action + step
-    const int rc = mssim_apply_action(h, action, action_dim, stream);
-    return rc ? rc : mssim_step(h, n_substeps, stream);
-  }
-  if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+// TASK: 0 = plain control step, 1 / 2 / 3 = copy-out + PickCube / PushCube / PegInsertionSide epilogue at its tail
+extern "C++" {
+template <int TASK>
+static void launch_control_step(mssim_handle h, const DevState& S, int n_substeps, hipStream_t st) {
+  prof_mark(h, 0, st);
+  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<true, 9, TASK>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
+  else hipLaunchKernelGGL((k_solve16<true, 0, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
+  prof_mark(h, 0, st);
+}
+}  // extern "C++"
+static DevState state_with_action(mssim_handle h, const float* action, int action_dim) {
   DevState S = h->S;
   S.act = action; S.act_dim = action_dim;
   S.act_col = h->d_act_col; S.act_lo = h->d_act_lo; S.act_hi = h->d_act_hi; S.act_flags = h->d_act_flags;
   S.act_qpos = h->buf.art_qpos; S.act_target = h->buf.art_target_qpos;
-  prof_mark(h, 0, st);
-  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<true, 9>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, (int)n_substeps);
-  else hipLaunchKernelGGL((k_solve16<true, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, (int)n_substeps);
-  prof_mark(h, 0, st);
+  return S;
+}
+static int step_action_now(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, hipStream_t st) {
+  if (!(h->fused && n_substeps > 0)) {  // per-substep kernels: the two launches of apply_action + step
+    hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, st, h->M, h->S, h->buf, action, action_dim,
+                       h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags);
+    return mssim_step(h, n_substeps, st);
+  }
+  if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+  launch_control_step<0>(h, state_with_action(h, action, action_dim), n_substeps, st);
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
+// everything owed to the handle (see mssim_defer_step_action / mssim_defer_fetch), in order
+static void flush_deferred(mssim_handle h, hipStream_t st) {
+  if (h->deferred_action) {
+    const float* a = h->deferred_action;
+    h->deferred_action = nullptr;
+    (void)step_action_now(h, a, h->deferred_adim, h->deferred_nsub, h->deferred_stream);
+  }
+  flush_deferred_fetch(h, st);
+}
+
+int mssim_step_action(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream) {
+  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  flush_deferred(h, (hipStream_t)stream);
+  return step_action_now(h, action, action_dim, n_substeps, (hipStream_t)stream);
+}
+
+int mssim_defer_step_action(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream) {
+  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  flush_deferred(h, (hipStream_t)stream);
+  h->deferred_action = action; h->deferred_adim = action_dim; h->deferred_nsub = n_substeps; h->deferred_stream = (hipStream_t)stream;
   return 0;
 }
 
 int mssim_link_jacobian(mssim_handle h, int32_t link_index, float* out, void* stream) {
+  flush_deferred(h, (hipStream_t)stream);
   if (link_index < 0 || link_index >= h->M.n_link || !out) { h->err = "link_jacobian: bad link index / output"; return 1; }
   hipStream_t st = (hipStream_t)stream;
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
@@ -1740,6 +1811,7 @@ int mssim_profile_enable(mssim_handle h, int32_t on) {
 }
 
 int mssim_profile_read(mssim_handle h, float* out_ms, int32_t* out_counts) {
+  flush_deferred(h, h->deferred_stream);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipDeviceSynchronize());
   for (int k = 0; k < 2; k++) {
@@ -1758,6 +1830,7 @@ int mssim_profile_read(mssim_handle h, float* out_ms, int32_t* out_counts) {
 }
 
 int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags) {
+  flush_deferred(h, h->deferred_stream);
   HIPCHK(h, hipSetDevice(h->device));
   const int n = h->M.n_dof > 0 ? h->M.n_dof : 1;
   if (!h->d_act_col) {
@@ -1772,7 +1845,7 @@ int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low
 }
 
 int mssim_apply_action(mssim_handle h, const float* action, int32_t action_dim, void* stream) {
-  flush_deferred_fetch(h, (hipStream_t)stream);
+  flush_deferred(h, (hipStream_t)stream);
   if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
   hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, action, action_dim,
                      h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags);
@@ -1801,6 +1874,28 @@ static int finger_pair_list(mssim_handle h, int obj_row, int f1_row, int f2_row)
   return 0;
 }
 
+// A deferred step_action + deferred fetch + this epilogue = one launch of the control-step kernel (Panda
+// models: the task tail is compiled into k_solve16<true, 9, TASK>). Returns false if that does not apply.
+extern "C++" {
+template <int TASK>
+static bool control_step_with_task(mssim_handle h, DevState& S, hipStream_t st) {
+  if (!(h->deferred_action && h->deferred_fetch && h->fused && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream)) return false;
+  // The tail runs at the kernel's one wave per SIMD: worth it while all blocks are resident at once (4 per CU) and
+  // the launch is latency-bound anyway; with more blocks the separate, fully occupied copy-out + epilogue launch
+  // is cheaper than a tail per block.
+  if ((h->N + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK > 4 * h->n_cu) return false;
+  const DevState A = state_with_action(h, h->deferred_action, h->deferred_adim);
+  S.act = A.act; S.act_dim = A.act_dim; S.act_col = A.act_col; S.act_lo = A.act_lo; S.act_hi = A.act_hi; S.act_flags = A.act_flags;
+  S.act_qpos = A.act_qpos; S.act_target = A.act_target;
+  S.tail_fetch = take_deferred_fetch(h);
+  S.tail_buf = h->buf;
+  h->deferred_action = nullptr;
+  if (h->dirty) { launch_fk(h, st); h->dirty = false; }
+  launch_control_step<TASK>(h, S, h->deferred_nsub, st);
+  return true;
+}
+}  // extern "C++"
+
 int mssim_task_peg_outputs(mssim_handle h, const mssim_peg_task* task, float* obs, float* reward, uint8_t* flags, float* head_at_hole, void* stream) {
   const int R = h->M.n_link + h->M.n_free + h->M.n_kin;
   const int rows[5] = {task->tcp_row, task->peg_row, task->box_row, task->finger1_row, task->finger2_row};
@@ -1809,6 +1904,13 @@ int mssim_task_peg_outputs(mssim_handle h, const mssim_peg_task* task, float* ob
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
   if (!task->peg_half_sizes || !task->box_hole_offsets || !task->box_hole_radii || !head_at_hole) { h->err = "task_peg_outputs: missing per-env geometry / output"; return 3; }
   { int rc = finger_pair_list(h, task->peg_row, task->finger1_row, task->finger2_row); if (rc) return rc; }
+  {
+    DevState S = h->S;
+    S.tail_task.peg = *task; S.tail_pairs = h->d_pick_pairs; S.tail_npairs = h->n_pick_pairs;
+    S.tail_obs = obs; S.tail_reward = reward; S.tail_flags = flags; S.tail_head = head_at_hole;
+    if (control_step_with_task<3>(h, S, (hipStream_t)stream)) { HIPCHK(h, hipGetLastError()); return 0; }
+  }
+  if (h->deferred_action) { const unsigned w = take_deferred_fetch(h); flush_deferred(h, (hipStream_t)stream); h->deferred_fetch = w; }
   if (const unsigned what = take_deferred_fetch(h))
     hipLaunchKernelGGL(k_task_peg<true>, env_grid(h->N, 64), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags, head_at_hole);
   else
@@ -1824,6 +1926,13 @@ int mssim_task_pick_outputs(mssim_handle h, const mssim_pick_task* task, float* 
     if (r < 0 || r >= R) { h->err = "task_pick_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
   { int rc = finger_pair_list(h, task->obj_row, task->finger1_row, task->finger2_row); if (rc) return rc; }
+  {
+    DevState S = h->S;
+    S.tail_task.pick = *task; S.tail_pairs = h->d_pick_pairs; S.tail_npairs = h->n_pick_pairs;
+    S.tail_obs = obs; S.tail_reward = reward; S.tail_flags = flags; S.tail_head = nullptr;
+    if (control_step_with_task<1>(h, S, (hipStream_t)stream)) { HIPCHK(h, hipGetLastError()); return 0; }
+  }
+  if (h->deferred_action) { const unsigned w = take_deferred_fetch(h); flush_deferred(h, (hipStream_t)stream); h->deferred_fetch = w; }
   if (const unsigned what = take_deferred_fetch(h))
     hipLaunchKernelGGL(k_task_pick<true>, env_grid(h->N, 64), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what, *task, h->d_pick_pairs, h->n_pick_pairs, obs, reward, flags);
   else
@@ -1838,6 +1947,13 @@ int mssim_task_push_outputs(mssim_handle h, const mssim_push_task* task, float* 
   for (int r : rows)
     if (r < 0 || r >= R) { h->err = "task_push_outputs: body row out of range"; return 1; }
   if (!h->buf.rigid_body_data || !h->buf.art_qpos || !h->buf.art_qvel) { h->err = "buffers not bound"; return 2; }
+  {
+    DevState S = h->S;
+    S.tail_task.push = *task; S.tail_pairs = nullptr; S.tail_npairs = 0;
+    S.tail_obs = obs; S.tail_reward = reward; S.tail_flags = flags; S.tail_head = nullptr;
+    if (control_step_with_task<2>(h, S, (hipStream_t)stream)) { HIPCHK(h, hipGetLastError()); return 0; }
+  }
+  if (h->deferred_action) { const unsigned w = take_deferred_fetch(h); flush_deferred(h, (hipStream_t)stream); h->deferred_fetch = w; }
   if (const unsigned what = take_deferred_fetch(h))
     hipLaunchKernelGGL(k_task_push<true>, env_grid(h->N, 64), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, what, *task, obs, reward, flags);
   else
@@ -1865,6 +1981,7 @@ int mssim_create_pair_query(mssim_handle h, const int32_t* body_pairs, int32_t n
 int mssim_create_body_query(mssim_handle h, const int32_t* rows, int32_t n, int32_t* qid) { return make_query(h, rows, n, n, 1, qid); }
 
 static int run_query(mssim_handle h, int32_t qid, int kind, float* out, void* stream) {
+  flush_deferred(h, (hipStream_t)stream);
   if (qid < 0 || qid >= (int)h->queries.size() || h->query_kind[qid] != kind) { h->err = "bad query id"; return 1; }
   int nq = h->query_n[qid];
   if (nq == 0) return 0;
@@ -1876,6 +1993,7 @@ int mssim_query_pair_impulses(mssim_handle h, int32_t qid, float* out, void* str
 int mssim_query_body_impulses(mssim_handle h, int32_t qid, float* out, void* stream) { return run_query(h, qid, 1, out, stream); }
 
 int mssim_read_internal(mssim_handle h, const char* name, float* out, int32_t max_items, void* stream) {
+  flush_deferred(h, (hipStream_t)stream);
   std::string s(name);
   const size_t N = (size_t)h->N;
   const float* src = nullptr;
@@ -1906,6 +2024,7 @@ int mssim_read_internal(mssim_handle h, const char* name, float* out, int32_t ma
 }
 
 int mssim_overflow_count(mssim_handle h, void* stream) {
+  flush_deferred(h, (hipStream_t)stream);
   std::vector<int> host(h->N);
   hipStream_t st = (hipStream_t)stream;
   if (hipStreamSynchronize(st) != hipSuccess) return -1;

@@ -446,7 +446,10 @@ struct SupCoop16 {
 
 // NDOF > 0: the number of joints is a compile-time constant (9 for the Panda), so the loops over the
 // joints are unrolled and their masks folded; NDOF = 0 reads it from the model.
-template <bool FUSED, int NDOF = 0>
+// TASK > 0 (with FUSED): the launch ends with the copy-out (mssim_fetch) of its envs and the evaluate / obs /
+// reward epilogue of a task -- 1 PickCube, 2 PushCube, 3 PegInsertionSide -- so that a whole control step
+// (action map, substeps, copy-out, epilogue) is one launch.
+template <bool FUSED, int NDOF = 0, int TASK = 0>
 __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S, int n_sub) {
   __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   const int N = S.N;
@@ -1621,5 +1624,24 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   if (!FUSED && live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
   (void)nrow_con;
   PH(7);
+  // ================================================================ copy-out + task epilogue of this env
+  if (FUSED && TASK > 0) {
+    // the state written above is read back below by other lanes of this wave, through the CU's own L1 (which its
+    // stores keep current): a block-scope fence = wait for the stores. (A device-scope fence would write back and
+    // invalidate caches -- tens of microseconds per wave here.)
+    __threadfence_block();
+    if (live) {
+      const int R = M.n_link + M.n_free + M.n_kin;
+      for (int row = c; row < R; row += 16) fetch_row(M, S, S.tail_buf, S.tail_fetch, e, row);
+      if (art) fetch_art_joint(M, S, S.tail_buf, S.tail_fetch, e, c);
+    }
+    __threadfence_block();
+    if (live && c == 0) {
+      if (TASK == 1) task_pick_env(M, S, S.tail_buf, S.tail_task.pick, S.tail_pairs, S.tail_npairs, S.tail_obs, S.tail_reward, S.tail_flags, e);
+      if (TASK == 2) task_push_env(M, S, S.tail_buf, S.tail_task.push, S.tail_obs, S.tail_reward, S.tail_flags, e);
+      if (TASK == 3) task_peg_env(M, S, S.tail_buf, S.tail_task.peg, S.tail_pairs, S.tail_npairs, S.tail_obs, S.tail_reward, S.tail_flags, S.tail_head, e);
+    }
+    PH(8);
+  }
   PH_FLUSH
 }

@@ -519,8 +519,9 @@ class BaseEnv(gym.Env):
                 # one launch instead of the controller's ~10 torch ops + 2 applies (same arithmetic); without
                 # hooks between set_action and the substeps the map runs at the head of the step's own launch
                 if self._no_step_hooks():
-                    self.scene.px.step_action(action, self._sim_steps_per_control)
-                    # `step` runs the task's fused epilogue next: it copies the state out in its own launch
+                    # `step` runs the task's fused epilogue next: the step and the copy-out are owed to that call,
+                    # which then launches the whole control step as one kernel
+                    self.scene.px.step_action(action, self._sim_steps_per_control, defer=self._fused_epilogue_next)
                     self.scene._gpu_fetch_all(defer=self._fused_epilogue_next)
                     return action
                 self.scene.px.apply_action(action)

@@ -188,6 +188,7 @@ class NativeLib:
         f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
         f("step_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
         f("defer_fetch", C.c_int, [H, C.c_uint32])
+        f("defer_step_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
         f("task_pick_outputs", C.c_int, [H, C.POINTER(PickTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("task_peg_outputs", C.c_int, [H, C.POINTER(PegTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
         f("task_push_outputs", C.c_int, [H, C.POINTER(PushTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
@@ -202,7 +203,7 @@ class NativeLib:
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
         "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
         "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map",
-        "apply_action", "step_action", "defer_fetch", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
+        "apply_action", "step_action", "defer_fetch", "defer_step_action", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
         "profile_read", "last_error",
         "abi_version",
     ]
@@ -262,6 +263,9 @@ class NativeSim:
 
     def fetch(self, what, stream=None):
         self._check(self.lib.fetch(self.h, what, stream), "fetch")
+
+    def defer_step_action(self, action_ptr, action_dim, n_substeps, stream=None):
+        self._check(self.lib.defer_step_action(self.h, action_ptr, action_dim, n_substeps, stream), "defer_step_action")
 
     def defer_fetch(self, what):
         self._check(self.lib.defer_fetch(self.h, what), "defer_fetch")

@@ -307,10 +307,16 @@ class MssimSystem:
         assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs
         self._sim.apply_action(action.data_ptr(), action.shape[1], self._stream())
 
-    def step_action(self, action: torch.Tensor, n_substeps: int):
-        """`apply_action` + `step(n_substeps)` in one launch (include/mssim.h `step_action`)"""
+    def step_action(self, action: torch.Tensor, n_substeps: int, defer: bool = False):
+        """`apply_action` + `step(n_substeps)` in one launch (include/mssim.h `step_action`). `defer`: owed to the
+        next native call -- a task epilogue then runs the whole control step as one launch (`defer_step_action`);
+        the action tensor is kept alive until that call."""
         assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs
-        self._sim.step_action(action.data_ptr(), action.shape[1], n_substeps, self._stream())
+        if defer:
+            self._deferred_action = action
+            self._sim.defer_step_action(action.data_ptr(), action.shape[1], n_substeps, self._stream())
+        else:
+            self._sim.step_action(action.data_ptr(), action.shape[1], n_substeps, self._stream())
 
     def task_peg_outputs(self, task, obs: torch.Tensor, reward: torch.Tensor, flags: torch.Tensor, head: torch.Tensor):
         self._sim.task_peg_outputs(task, obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), head.data_ptr(), self._stream())

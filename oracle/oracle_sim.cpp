@@ -856,6 +856,7 @@ int mssim_ref_link_jacobian(mssim_handle h, int32_t link, float* out, void*) {
 }
 int mssim_ref_apply_action(mssim_handle h, const float*, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_defer_fetch(mssim_handle h, uint32_t) { h->err = "not available in the oracle"; return 1; }
+int mssim_ref_defer_step_action(mssim_handle h, const float*, int32_t, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_step_action(mssim_handle h, const float*, int32_t, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_task_pick_outputs(mssim_handle h, const mssim_pick_task*, float*, float*, uint8_t*, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_task_peg_outputs(mssim_handle h, const mssim_peg_task*, float*, float*, uint8_t*, float*, void*) { h->err = "not available in the oracle"; return 1; }
