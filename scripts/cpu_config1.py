@@ -51,7 +51,10 @@ def run(procs, steps):
 
 
 if __name__ == "__main__":
+    # CPU-only measurement: the workers must not open the GPU (a GPU box admits few processes on its card)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        os.environ[k] = ""
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MSSIM_HOST_CORES", "16")))  # a 1-GPU box shares 16 cores
     for procs in sorted({4, cores}):
         run(procs, steps)
