@@ -160,3 +160,47 @@ def test_long_random_rollout_stays_sane(env_id):
     assert base.scene.px.overflow_count() <= N // 50
     env.close()
 
+
+
+def test_owed_calls_equal_separate_calls():
+    """mssim_defer_step_action / mssim_defer_fetch (include/mssim.h): the one-launch control step and every way
+    of flushing what is owed give bit-identical buffers and outputs to the separate calls"""
+    import gymnasium as gym
+
+    N = 64
+    g = torch.Generator().manual_seed(11)
+    acts = [(2 * torch.rand(N, 8, generator=g) - 1).cuda() for _ in range(6)]
+
+    def run(mode):
+        env = gym.make("PickCube-v1", num_envs=N, sim_backend="physx_cuda")
+        base = env.unwrapped
+        env.reset(seed=9)
+        env.step(acts[0])  # sets the action map, builds the task struct
+        px, task = base.scene.px, base._fused_state["task"]
+        out = []
+        for a in acts[1:]:
+            obs = torch.empty((N, 42), device="cuda"); rew = torch.empty(N, device="cuda"); fl = torch.empty((N, 4), dtype=torch.uint8, device="cuda")
+            es = torch.empty_like(base._elapsed_steps)
+            task.elapsed_steps, task.elapsed_out = base._elapsed_steps.data_ptr(), es.data_ptr()
+            if mode == "separate":
+                px.apply_action(a); px.step(5); px.gpu_fetch_all()
+            elif mode == "one_launch":
+                px.step_action(a, 5, defer=True); px.defer_fetch_all()
+            elif mode == "flushed_by_query":  # another entry point comes first: it performs what is owed
+                px.step_action(a, 5, defer=True); px.defer_fetch_all()
+                base.scene.get_pairwise_contact_impulses(base.agent.finger1_link, base.cube)
+            elif mode == "flushed_by_fetch":
+                px.step_action(a, 5, defer=True); px.gpu_fetch_all()
+            px.task_pick_outputs(task, obs, rew, fl)
+            base._elapsed_steps.copy_(es)
+            out.append([t.cpu().clone() for t in (obs, rew, fl, px.cuda_rigid_body_data.torch(), px.cuda_articulation_qpos.torch(),
+                                                   px.cuda_articulation_target_qpos.torch(), px.cuda_articulation_qacc.torch())])
+        env.close()
+        return out
+
+    ref = run("separate")
+    for mode in ("one_launch", "flushed_by_query", "flushed_by_fetch"):
+        got = run(mode)
+        for step, (r, o) in enumerate(zip(ref, got)):
+            for k, (x, y) in enumerate(zip(r, o)):
+                assert torch.equal(x, y), (mode, step, k, (x.float() - y.float()).abs().max())
