@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MSSIM_ABI_VERSION 2
+#define MSSIM_ABI_VERSION 3
 #define MSSIM_MAX_DOF 16        /* max articulation degrees of freedom per env            */
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
@@ -263,6 +263,8 @@ typedef struct mssim_pick_task {
   float reward_scale;         /* 1 (dense) or 1/5 (normalized_dense) */
   int32_t* elapsed_steps;     /* optional device [N]: incremented in place (BaseEnv.step, sapien_env.py:951) ... */
   int32_t* elapsed_out;       /* ... and the new value copied here (info["elapsed_steps"], sapien_env.py:739)      */
+  uint8_t* truncated_out;     /* optional device [N]: new elapsed_steps >= time_limit (TimeLimitWrapper, utils/registration.py:160-168) */
+  int32_t time_limit;
 } mssim_pick_task;
 /* obs [N][2*n_dof+24] f32 (qpos, qvel, is_grasped, tcp_pose7, goal_pos3, obj_pose7, tcp_to_obj3,
  * obj_to_goal3), reward [N] f32, flags [N][4] u8 = success, is_obj_placed, is_robot_static, is_grasped */
@@ -278,6 +280,8 @@ typedef struct mssim_push_task {
   float reward_scale;                 /* 1 (dense) or 1/3 (normalized_dense) */
   int32_t* elapsed_steps;             /* optional, as in mssim_pick_task */
   int32_t* elapsed_out;
+  uint8_t* truncated_out;     /* optional device [N]: new elapsed_steps >= time_limit (TimeLimitWrapper, utils/registration.py:160-168) */
+  int32_t time_limit;
 } mssim_push_task;
 int MSSIM_FN(task_push_outputs)(mssim_handle h, const mssim_push_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
 
@@ -296,6 +300,8 @@ typedef struct mssim_peg_task {
   const float* box_hole_radii;   /* device [N]    */
   int32_t* elapsed_steps;     /* optional, as in mssim_pick_task */
   int32_t* elapsed_out;
+  uint8_t* truncated_out;     /* optional device [N]: new elapsed_steps >= time_limit (TimeLimitWrapper, utils/registration.py:160-168) */
+  int32_t time_limit;
 } mssim_peg_task;
 int MSSIM_FN(task_peg_outputs)(mssim_handle h, const mssim_peg_task* task, float* obs, float* reward, uint8_t* flags, float* head_at_hole, void* stream);
 

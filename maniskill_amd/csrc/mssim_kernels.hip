@@ -1165,7 +1165,7 @@ MS_DEV void task_pick_env(const DevModel& M, const DevState& S, const mssim_buff
   reward[e] = r * T.reward_scale;
   uint8_t* f = flags + 4 * (size_t)e;
   f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
-  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
+  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; if (T.truncated_out) T.truncated_out[e] = v >= T.time_limit ? 1 : 0; }
 }
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
 template <bool FETCH>
@@ -1205,7 +1205,7 @@ MS_DEV void task_push_env(const DevModel& M, const DevState& S, const mssim_buff
   if (success) r = 3.f;
   reward[e] = r * T.reward_scale;
   flags[e] = success;
-  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
+  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; if (T.truncated_out) T.truncated_out[e] = v >= T.time_limit ? 1 : 0; }
 }
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
 template <bool FETCH>
@@ -1297,7 +1297,7 @@ MS_DEV void task_peg_env(const DevModel& M, const DevState& S, const mssim_buffe
   reward[e] = r * T.reward_scale;
   flags[e] = success;
   head_out[3 * (size_t)e] = hah.x; head_out[3 * (size_t)e + 1] = hah.y; head_out[3 * (size_t)e + 2] = hah.z;
-  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; }
+  if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; if (T.truncated_out) T.truncated_out[e] = v >= T.time_limit ? 1 : 0; }
 }
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
 template <bool FETCH>

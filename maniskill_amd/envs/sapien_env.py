@@ -455,6 +455,7 @@ class BaseEnv(gym.Env):
 
     # ------------------------------------------------------------------ step
     def step(self, action: Union[None, np.ndarray, torch.Tensor, Dict]):
+        self._fused_truncated = None
         self._fused_epilogue_next = self._use_fused_callers and self._fused_ok()
         action = self._step_action(action)
         self._fused_epilogue_next = False
@@ -575,6 +576,16 @@ class BaseEnv(gym.Env):
         return self._fused_action_ok and action.is_contiguous()
 
     _fused_epilogue_next = False
+    _time_limit = None  # set by TimeLimitWrapper: the fused epilogue then also writes `elapsed_steps >= limit`
+    _fused_truncated = None
+
+    def _fused_time_limit_out(self):
+        """(device pointer, limit) for the task struct of a fused epilogue; (None, 0) without a time limit"""
+        if self._time_limit is None:
+            self._fused_truncated = None
+            return None, 0
+        self._fused_truncated = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        return self._fused_truncated.data_ptr(), int(self._time_limit)
 
     def _fused_ok(self) -> bool:
         """will `_fused_step_outputs` produce this step's outputs? (tasks with a native epilogue override both)"""

@@ -247,5 +247,6 @@ class PegInsertionSideEnv(BaseEnv):
         head = torch.empty((N, 3), dtype=torch.float32, device=self.device)
         es = torch.empty_like(self._elapsed_steps)
         st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
+        st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
         px.task_peg_outputs(st["task"], obs, reward, flags, head)
         return obs, reward, dict(elapsed_steps=es, success=flags.view(torch.bool)[:, 0], peg_head_pos_at_hole=head)

@@ -151,6 +151,7 @@ class PickCubeEnv(BaseEnv):
         flags = torch.empty((N, 4), dtype=torch.uint8, device=self.device)
         es = torch.empty_like(self._elapsed_steps)
         st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
+        st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
         px.task_pick_outputs(st["task"], obs, reward, flags)
         fb = flags.view(torch.bool)
         info = dict(elapsed_steps=es, success=fb[:, 0], is_obj_placed=fb[:, 1], is_robot_static=fb[:, 2], is_grasped=fb[:, 3])

@@ -121,5 +121,6 @@ class PushCubeEnv(BaseEnv):
         flags = torch.empty((N, 1), dtype=torch.uint8, device=self.device)
         es = torch.empty_like(self._elapsed_steps)
         st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
+        st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
         px.task_push_outputs(st["task"], obs, reward, flags)
         return obs, reward, dict(elapsed_steps=es, success=flags.view(torch.bool)[:, 0])

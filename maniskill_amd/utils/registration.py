@@ -42,6 +42,8 @@ class TimeLimitWrapper(gym.Wrapper):
     def __init__(self, env, max_episode_steps: int):
         super().__init__(env)
         self._max_episode_steps = max_episode_steps
+        # tasks with a fused native epilogue evaluate the comparison below in that launch
+        self.env.unwrapped._time_limit = max_episode_steps
 
     @property
     def base_env(self):
@@ -50,7 +52,8 @@ class TimeLimitWrapper(gym.Wrapper):
     def step(self, action):
         obs, reward, terminated, truncated, info = self.env.step(action)
         if self._max_episode_steps is not None:
-            truncated = self.base_env.elapsed_steps >= self._max_episode_steps
+            fused = self.base_env._fused_truncated  # this step's `elapsed_steps >= limit` from the fused epilogue, if any
+            truncated = fused.view(torch.bool) if fused is not None else self.base_env.elapsed_steps >= self._max_episode_steps
         else:
             truncated = torch.zeros((self.base_env.num_envs,), dtype=torch.bool, device=self.base_env.device)
         return obs, reward, terminated, truncated, info

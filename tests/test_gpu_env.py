@@ -98,19 +98,20 @@ def test_fused_callers_match_torch_path(monkeypatch, env_id):
     outs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("MS_FUSED", fused)
-        env = gym.make(env_id, num_envs=N, sim_backend="physx_cuda")
+        env = gym.make(env_id, num_envs=N, sim_backend="physx_cuda", max_episode_steps=8)  # truncation switches on at step 8 of 12
         assert env.unwrapped._use_fused_callers == (fused == "1")
         obs, _ = env.reset(seed=5)
         traj = []
         for a in acts:
             obs, rew, term, trunc, info = env.step(a.cuda())
-            traj.append((obs.cpu().clone(), rew.cpu().clone(), term.cpu().clone(), {k: v.cpu().clone() for k, v in info.items()}))
+            traj.append((obs.cpu().clone(), rew.cpu().clone(), term.cpu().clone(), {k: v.cpu().clone() for k, v in info.items()}, trunc.cpu().clone()))
         outs.append(traj)
         env.close()
     # (the native action map rounds `low + 0.5 (a + 1)(high - low)` differently from the torch expression by
     # an ulp, so the two 12-step trajectories drift apart at the 1e-5 level; contact-rich Peg a bit more)
     tol = 5e-5 if env_id == "PegInsertionSide-v1" else 1e-5
-    for (o1, r1, t1, i1), (o2, r2, t2, i2) in zip(*outs):
+    for (o1, r1, t1, i1, tr1), (o2, r2, t2, i2, tr2) in zip(*outs):
+        assert tr1.dtype == torch.bool and torch.equal(tr1, tr2)  # time limit: fused epilogue vs TimeLimitWrapper's comparison
         assert torch.allclose(o1, o2, atol=tol), (o1 - o2).abs().max()
         assert torch.allclose(r1, r2, atol=tol)
         assert torch.equal(t1, t2)
