@@ -58,8 +58,8 @@ MS_DEV f3 support(const shape_t& s, f3 d) {
       break;
     }
     case SH_CYLINDER: {
-      float rr = sqrtf(dl.y * dl.y + dl.z * dl.z);
-      float k = rr > 1e-12f ? s.p0 / rr : 0.f;
+      float rr = sqrt_f(dl.y * dl.y + dl.z * dl.z);
+      float k = rr > 1e-12f ? s.p0 * rcp_f(rr) : 0.f;
       pl = f3{dl.x >= 0.f ? s.p1 : -s.p1, dl.y * k, dl.z * k};
       break;
     }
@@ -178,7 +178,7 @@ MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
       const float da = d[i], db = (i == 7 || wrap) ? d[0] : d[(i + 1) & 7];
       if (da <= 0.f && m < 8) out.put(m++, a);
       if (((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) && m < 8) {
-        float t = da / (da - db);
+        float t = da * rcp_f(da - db);
         out.put(m++, a + (b - a) * t);
       }
     }
@@ -229,7 +229,7 @@ MS_DEV int bb_setup(const shape_t& A, const shape_t& B, float offset, manifold_t
       const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       float ra = hA[i1] * Ra[i2][j] + hA[i2] * Ra[i1][j];
       float rb = hB[j1] * Ra[i][j2] + hB[j2] * Ra[i][j1];
-      float s = (fabsf(T[i2] * Rm[i1][j] - T[i1] * Rm[i2][j]) - (ra + rb)) / sqrtf(fmaxf(l2, 1e-12f));
+      float s = (fabsf(T[i2] * Rm[i1][j] - T[i1] * Rm[i2][j]) - (ra + rb)) * rsq_f(fmaxf(l2, 1e-12f));
       if (l2 >= 1e-6f && s > sE) { sE = s; eI = i; eJ = j; }
     }
   float sF = sA > sB ? sA : sB;
@@ -252,8 +252,8 @@ MS_DEV int bb_setup(const shape_t& A, const shape_t& B, float offset, manifold_t
     f3 w0 = pa - pb;
     float uv = dot(aE, bE), uw = dot(aE, w0), vw = dot(bE, w0);
     float den = 1.f - uv * uv;
-    float sa = den > 1e-9f ? (uv * vw - uw) / den : 0.f;
-    float sb = den > 1e-9f ? (vw - uv * uw) / den : 0.f;
+    float sa = den > 1e-9f ? (uv * vw - uw) * rcp_f(den) : 0.f;
+    float sb = den > 1e-9f ? (vw - uv * uw) * rcp_f(den) : 0.f;
     sa = fminf(fmaxf(sa, -hAe), hAe);
     sb = fminf(fmaxf(sb, -hBe), hBe);
     f3 qa = pa + aE * sa, qb = pb + bE * sb;
@@ -437,18 +437,18 @@ MS_DEV void closest_on_triangle(f3 a, f3 b, f3 c, float w[3]) {
   float d3 = dot(ab, bp), d4 = dot(ac, bp);
   if (d3 >= 0.f && d4 <= d3) { w[0] = 0.f; w[1] = 1.f; w[2] = 0.f; return; }
   float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 / (d1 - d3); w[0] = 1.f - v; w[1] = v; w[2] = 0.f; return; }
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 * rcp_f(d1 - d3); w[0] = 1.f - v; w[1] = v; w[2] = 0.f; return; }
   f3 cp = -c;
   float d5 = dot(ab, cp), d6 = dot(ac, cp);
   if (d6 >= 0.f && d5 <= d6) { w[0] = 0.f; w[1] = 0.f; w[2] = 1.f; return; }
   float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float v = d2 / (d2 - d6); w[0] = 1.f - v; w[1] = 0.f; w[2] = v; return; }
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float v = d2 * rcp_f(d2 - d6); w[0] = 1.f - v; w[1] = 0.f; w[2] = v; return; }
   float va = d3 * d6 - d5 * d4;
   if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
-    float v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    float v = (d4 - d3) * rcp_f((d4 - d3) + (d5 - d6));
     w[0] = 0.f; w[1] = 1.f - v; w[2] = v; return;
   }
-  float den = 1.f / (va + vb + vc);
+  float den = rcp_f(va + vb + vc);
   w[1] = vb * den; w[2] = vc * den; w[0] = 1.f - w[1] - w[2];
 }
 
@@ -484,7 +484,7 @@ MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, mani
   if (dot(dir, dir) < 1e-14f) {
     f3 w = v1.v; float D = norm(w);
     m.count = 1;
-    m.n = D > 1e-9f ? w * (-1.f / D) : normalized(v0.v);
+    m.n = D > 1e-9f ? w * (-rcp_f(D)) : normalized(v0.v);
     m.sep[0] = margin - D;
     m.x[0] = (v1.a + v1.b) * 0.5f;
     return;
@@ -511,7 +511,7 @@ MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, mani
     dir = cross(v2.v - v1.v, v3.v - v1.v);
     float dl = norm(dir);
     if (dl < 1e-14f) break;
-    dir = dir * (1.f / dl);
+    dir = dir * rcp_f(dl);
     if (dot(dir, v1.v) >= 0.f) hit = true;
     v4 = msupport(sup, A, B, dir, margin);
     float reach = dot(v4.v, dir);
@@ -536,7 +536,7 @@ MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, mani
   float D = norm(wp);
   f3 pn = normalized(cross(v2.v - v1.v, v3.v - v1.v));
   m.count = 1;
-  m.n = D > 1e-7f ? wp * (-1.f / D) : -pn;
+  m.n = D > 1e-7f ? wp * (-rcp_f(D)) : -pn;
   m.sep[0] = margin - D;
   f3 pa = v1.a * w[0] + v2.a * w[1] + v3.a * w[2];
   f3 pb = v1.b * w[0] + v2.b * w[1] + v3.b * w[2];

@@ -18,10 +18,16 @@ MS_DEV f3& operator+=(f3& a, f3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return 
 MS_DEV f3& operator-=(f3& a, f3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
 MS_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MS_DEV f3 cross(f3 a, f3 b) { return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-MS_DEV float norm(f3 a) { return sqrtf(dot(a, a)); }
+// single-instruction reciprocal / square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp). `1.f / x`, `a / b` and
+// sqrtf() compile to 10-instruction IEEE / denormal-safe expansions even with
+// -fno-hip-fp32-correctly-rounded-divide-sqrt; none of the quantities here is denormal or needs the last ulp
+MS_DEV float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+MS_DEV float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
+MS_DEV float rsq_f(float x) { return __builtin_amdgcn_rsqf(x); }
+MS_DEV float norm(f3 a) { return sqrt_f(dot(a, a)); }
 MS_DEV f3 normalized(f3 a) {
-  float n = norm(a);
-  return n > 0.f ? a * (1.f / n) : f3{1.f, 0.f, 0.f};
+  const float nn = dot(a, a);
+  return nn > 0.f ? a * rsq_f(nn) : f3{1.f, 0.f, 0.f};
 }
 MS_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 // value select. `g ? a : b` on struct lvalues can be lowered to a select of ADDRESSES, which forces
@@ -36,8 +42,8 @@ MS_DEV q4 qmul(q4 a, q4 b) {
             a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
 MS_DEV q4 qnormalized(q4 q) {
-  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  float s = n > 0.f ? 1.f / n : 1.f;
+  const float nn = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  float s = nn > 0.f ? rsq_f(nn) : 1.f;
   return q4{q.w * s, q.x * s, q.y * s, q.z * s};
 }
 MS_DEV q4 qaxis_angle(f3 axis, float angle) {
@@ -100,7 +106,7 @@ MS_DEV s3 sinverse(const s3& a) {
   float c01 = a.yz * a.xz - a.xy * a.zz;
   float c02 = a.xy * a.yz - a.yy * a.xz;
   float det = a.xx * c00 + a.xy * c01 + a.xz * c02;
-  float id = 1.f / det;
+  float id = rcp_f(det);
   s3 r;
   r.xx = c00 * id;
   r.xy = c01 * id;

@@ -287,7 +287,7 @@ MS_DEV void collide_box_box_coop(const shape_t& A, const shape_t& B, float offse
     const int pt = pa + (ea ? 1 : 0);
     if (ea && pa < 8) { scr[3 * pa] = P.x; scr[3 * pa + 1] = P.y; scr[3 * pa + 2] = P.z; }
     if (et && pt < 8) {
-      const float t = da / (da - db);
+      const float t = da * rcp_f(da - db);
       const f3 x = P + (b - P) * t;
       scr[3 * pt] = x.x; scr[3 * pt + 1] = x.y; scr[3 * pt + 2] = x.z;
     }
@@ -462,6 +462,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   float* L = sm + g * S16_ENV_FLOATS;
   const int n = NDOF > 0 ? NDOF : M.n_dof, nf = M.n_free;
   const float dt = M.dt;
+  const float inv_dt = rcp_f(dt);
   const f3 g3 = f3{M.gx, M.gy, M.gz};
   const bool art = c < n;
   // lane role among the free-body components
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           PA[j] = a4.x; PA[j + 1] = a4.y; PA[j + 2] = a4.z; PA[j + 3] = a4.w;
           PI[j] = i4.x; PI[j + 1] = i4.y; PI[j + 2] = i4.z; PI[j + 3] = i4.w;
         }
-        const float inv = 1.f / PA[k < NA ? k : 0];
+        const float inv = rcp_f(PA[k < NA ? k : 0]);
         const float fac = Arow[k < NA ? k : 0] * inv;
         const bool piv = c == k;
 #pragma unroll
@@ -1162,7 +1163,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       m3 R = qmat(P.q);
       s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
       s3 Ii = sinverse(Iw);
-      const float minv = 1.f / in[0];
+      const float minv = rcp_f(in[0]);
       f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
       const int base = n + 6 * b;
       f3 v0 = f3{gbc(vfree_c, base), gbc(vfree_c, base + 1), gbc(vfree_c, base + 2)};
@@ -1215,9 +1216,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         L[S16_LIMW + 16 * j + c] = sj * Irow[j];
         if (c == j) dself = Irow[j];
       }
-      lim_inv = (has && dself > 1e-12f) ? 1.f / dself : 0.f;
-      lim_bpos = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
-      lim_bvel = C >= 0.f ? C / dt : 0.f;
+      lim_inv = (has && dself > 1e-12f) ? rcp_f(dself) : 0.f;
+      lim_bpos = C >= 0.f ? C * inv_dt : fmaxf(M.erp * C * inv_dt, -M.max_depen);
+      lim_bvel = C >= 0.f ? C * inv_dt : 0.f;
     }
     // A^-1 row in rotated order for W = A^-1 J^T of the contact rows: Irot[k] = Ainv[c][src_k], src_k = the
     // lane a DPP row rotation by k delivers to lane c (taken from the rotation itself, so no convention
@@ -1269,9 +1270,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       gsum16x3(d0, d1, d2);
       gsum16x3(g10, g20, g21);
       if (c == 0) {
-        const float i0 = d0 > 1e-12f ? 1.f / d0 : 0.f, i1 = d1 > 1e-12f ? 1.f / d1 : 0.f, i2 = d2 > 1e-12f ? 1.f / d2 : 0.f;
+        const float i0 = d0 > 1e-12f ? rcp_f(d0) : 0.f, i1 = d1 > 1e-12f ? rcp_f(d1) : 0.f, i2 = d2 > 1e-12f ? rcp_f(d2) : 0.f;
         float4* cs = reinterpret_cast<float4*>(L + S16_CS + 16 * i);
-        cs[0] = float4{i0, ck ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f, ck ? (sep >= 0.f ? sep / dt : 0.f) : 0.f, ck ? mu : 0.f};
+        cs[0] = float4{i0, ck ? (sep >= 0.f ? sep * inv_dt : fmaxf(M.erp * sep * inv_dt, -M.max_depen)) : 0.f, ck ? (sep >= 0.f ? sep * inv_dt : 0.f) : 0.f, ck ? mu : 0.f};
         cs[1] = float4{i1, g10 * i1, i2, g20 * i2};
         cs[2] = float4{g21 * i2, 0.f, 0.f, 0.f};
         cs[3] = float4{__int_as_float(p), 0.f, 0.f, 0.f};
@@ -1575,7 +1576,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       nan = Jw.p;
     }
     // carry the state into the next substep
-    qacc_c = (v_c - qd_c) / dt;
+    qacc_c = (v_c - qd_c) * inv_dt;
     qd_c = art ? v_c : 0.f;
     vfree_c = freel ? v_c : 0.f;
     bp_c = nb; aw_c = naw; an_c = nan;
