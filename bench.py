@@ -189,7 +189,7 @@ def main():
         fused = narrow_n == 0 and solve_n == args.steps  # k_solve16<FUSED>: one launch = n envs x one control step
         alg_bytes_per_launch = ALG_BYTES_PER_ENV_STEP * n / (1 if fused else substeps)
         if fused:
-            kernel_name, kernel_key = f"k_solve16<FUSED> (whole control step: {substeps} substeps incl. narrowphase, 16 lanes/env)", "k_solve16<true"
+            kernel_name, kernel_key = f"k_solve16<FUSED, NDOF, TASK> (whole env.step in one launch: action map, {substeps} substeps incl. narrowphase, copy-out, task epilogue; 16 lanes/env)", "k_solve16<true"
         elif (px.model.n_dof + 6 * px.model.n_free) <= 16 and os.environ.get("MSSIM_SOLVER") != "lane":
             kernel_name, kernel_key = "k_solve16 (one substep, 16 lanes/env; narrowphase in k_narrow)", "k_solve16<false"
         else:
