@@ -24,7 +24,7 @@ env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
 buf = (ctypes.c_ulonglong * 32)()
 names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
-         "dyn: S stage", "dyn: V sum", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: coop box-box",
+         "tail: copy-out + task epilogue", "(unused)", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: coop box-box",
          "#coop MPR task slots (max over groups)", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
          "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: plane/box-box rounds + record writes", "np: coop MPR",
          "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
