@@ -2,7 +2,7 @@
 # build experiment variants of the HIP library (timing A/B only; results of EXP_* builds are wrong by design)
 set -e
 cd "$(dirname "$0")/.."
-# usage: ab_variants.sh name:flags ...   e.g.  ab_variants.sh base: it1:-DEXP_ITERS=1 fullsync:-DS16_FULL_SYNC
+# usage: ab_variants.sh name:flags ...   e.g.  ab_variants.sh base: it1:-DEXP_ITERS=1
 for v in "base:" "$@"; do
   name=${v%%:*}; flags=${v#*:}
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-pass-failed -fno-hip-fp32-correctly-rounded-divide-sqrt $flags \
