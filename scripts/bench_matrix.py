@@ -26,13 +26,14 @@ def run(env_id, N, steps=200, control_mode="pd_joint_delta_pos", **kw):
         if (i + 1) % 200 == 0:
             env.reset()
     torch.cuda.synchronize(); dt_reset = time.perf_counter() - t
-    out = dict(env_id=env_id, num_envs=N, control_mode=control_mode, step_only=round(N * steps / dt_step), step_reset_every_200=round(N * 2 * steps / dt_reset),
+    out = dict(env_id=env_id, num_envs=N, control_mode=control_mode, substeps=base._sim_steps_per_control, step_only=round(N * steps / dt_step), step_reset_every_200=round(N * 2 * steps / dt_reset),
                ms_per_step=round(dt_step / steps * 1e3, 3), overflow_envs=base.scene.px.overflow_count())
     print(json.dumps(out), flush=True)
     env.close()
 
 only = sys.argv[1:]
 for args, kw in ((("PickCube-v1", 4096), {}), (("PushCube-v1", 4096), {}), (("PegInsertionSide-v1", 2048), {}),
-                 (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pos")), (("PickCube-v1", 16384), {})):
-    if not only or args[0] in only or kw.get("control_mode") in only:
+                 (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pos")), (("PickCube-v1", 16384), {}),
+                 (("PickCube-v1", 4096), dict(sim_config=dict(control_freq=25)))):  # 4 substeps (SURVEY 8d reports 5 and 4)
+    if not only or args[0] in only or kw.get("control_mode") in only or ("substeps4" in only and "sim_config" in kw):
         run(*args, **kw)
