@@ -192,14 +192,23 @@ class CombinedController(DictController):
         sub-controller cannot be expressed as an affine action -> target map"""
         n = self.articulation.max_dof
         col, lo, hi, fl = [-1] * n, [0.0] * n, [0.0] * n, [0] * n
+        ee = None  # end-effector block: (link index, first action column, low, high, flags)
         for uid, c in self.controllers.items():
             spec = getattr(c, "fused_action_spec", lambda: None)()
             if spec is None:
                 return None
             start, _ = self.action_mapping[uid]
+            if isinstance(spec, dict):
+                if ee is not None:
+                    return None  # one end-effector block
+                link, l, h, f = spec["ee"]
+                ee = (link, start, l, h, f)
+                for dof in spec["dofs"]:
+                    fl[dof] = 4  # driven by the end-effector block
+                continue
             for dof, lcol, l, h, f in spec:
                 col[dof], lo[dof], hi[dof], fl[dof] = start + lcol, l, h, f
-        return col, lo, hi, fl
+        return col, lo, hi, fl, ee
 
     def to_action_dict(self, action):
         return {uid: action[s:e] for uid, (s, e) in self.action_mapping.items()}

@@ -1078,10 +1078,19 @@ __global__ void k_query(DevModel M, DevState S, const int* q, int nq, int body_q
   o[0] = s.x; o[1] = s.y; o[2] = s.z;
 }
 
+// End-effector block of the action map (pd_ee_delta_pos): 3 action columns = translation of link `link` in the
+// root frame; the joints flagged 4 in the joint map get  target = qpos + J^T (J J^T + 1e-9 I)^-1 a  with J the
+// translational Jacobian of the link over all joints on its path (agents/controllers/utils/kinematics.py:156-171)
+struct EeMap {
+  int link;    // < 0: no end-effector block
+  int col0;    // first action column
+  float lo, hi;
+  int flags;   // 2: clip to [-1, 1] and map to [lo, hi]
+};
 // affine action -> drive targets (user-visible buffer + simulation state)
 __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const float* __restrict__ action, int adim,
                                const int* __restrict__ col, const float* __restrict__ lo, const float* __restrict__ hi,
-                               const int* __restrict__ flags) {
+                               const int* __restrict__ flags, EeMap ee) {
   const int N = S.N;
   int e = xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= N) return;
@@ -1098,6 +1107,42 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
     const float t = ((flags[j] & 1) ? qj : 0.f) + a;
     SOA(S.qt, j) = t;
     if (B.art_target_qpos) B.art_target_qpos[(size_t)e * n + j] = t;
+  }
+  if (ee.link >= 0) {
+    const pose_t root = pose_soa(S.root, 0, N, e);
+    const m3 Rr = qmat(root.q);
+    const int b = M.link_body[ee.link];
+    const pose_t Pb = b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e);
+    const f3 pe = pmul(Pb, pose_from(M.link_frame + 7 * ee.link)).p;
+    const unsigned path = b < 0 ? 0u : (M.dof_anc[b] | (1u << b));
+    float av[3];
+    for (int r = 0; r < 3; r++) {
+      float a = action[(size_t)e * adim + ee.col0 + r];
+      if (ee.flags & 2) {
+        a = fminf(fmaxf(a, -1.f), 1.f);
+        a = 0.5f * (ee.hi + ee.lo) + 0.5f * (ee.hi - ee.lo) * a;
+      }
+      av[r] = a;
+    }
+    auto jcol = [&](int j) {
+      const f3 a = f3{SOA(S.bodyaux, 6 * j), SOA(S.bodyaux, 6 * j + 1), SOA(S.bodyaux, 6 * j + 2)};
+      const f3 an = f3{SOA(S.bodyaux, 6 * j + 3), SOA(S.bodyaux, 6 * j + 4), SOA(S.bodyaux, 6 * j + 5)};
+      return mtmulv(Rr, M.dof_type[j] == MSSIM_JOINT_REVOLUTE ? cross(a, pe - an) : a);
+    };
+    s3 G = s3{1e-9f, 1e-9f, 1e-9f, 0.f, 0.f, 0.f};  // xx yy zz xy xz yz
+    for (int j = 0; j < n; j++)
+      if ((path >> j) & 1u) {
+        const f3 v = jcol(j);
+        G.xx += v.x * v.x; G.yy += v.y * v.y; G.zz += v.z * v.z; G.xy += v.x * v.y; G.xz += v.x * v.z; G.yz += v.y * v.z;
+      }
+    const f3 y = smulv(sinverse(G), f3{av[0], av[1], av[2]});
+    for (int j = 0; j < n; j++)
+      if (((path >> j) & 1u) && (flags[j] & 4)) {
+        const float qj = B.art_qpos ? B.art_qpos[(size_t)e * n + j] : SOA(S.q, j);
+        const float t = qj + dot(jcol(j), y);
+        SOA(S.qt, j) = t;
+        if (B.art_target_qpos) B.art_target_qpos[(size_t)e * n + j] = t;
+      }
   }
 }
 
@@ -1372,6 +1417,7 @@ struct mssim_sim {
   int row_fields = 0;
   // profiling (bench roofline block): event pairs recorded on the launch stream
   int* d_act_col = nullptr; float* d_act_lo = nullptr; float* d_act_hi = nullptr; int* d_act_flags = nullptr;
+  EeMap ee{-1, 0, 0.f, 0.f, 0};
   unsigned solve_lds_bytes = 0;
   bool coop = false;   // use k_solve16
   bool fused = false;  // k_solve16<true>: one launch per control step, narrowphase in the kernel
@@ -1754,9 +1800,9 @@ static DevState state_with_action(mssim_handle h, const float* action, int actio
   return S;
 }
 static int step_action_now(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, hipStream_t st) {
-  if (!(h->fused && n_substeps > 0)) {  // per-substep kernels: the two launches of apply_action + step
+  if (!(h->fused && n_substeps > 0) || h->ee.link >= 0) {  // per-substep kernels / end-effector block: apply_action, then step
     hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, st, h->M, h->S, h->buf, action, action_dim,
-                       h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags);
+                       h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags, h->ee);
     return mssim_step(h, n_substeps, st);
   }
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
@@ -1844,11 +1890,18 @@ int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low
   return 0;
 }
 
+int mssim_set_ee_action_map(mssim_handle h, int32_t link_index, int32_t column0, float low, float high, int32_t flags) {
+  flush_deferred(h, h->deferred_stream);
+  if (link_index >= h->M.n_link) { h->err = "set_ee_action_map: bad link index"; return 1; }
+  h->ee = EeMap{link_index < 0 ? -1 : (int)link_index, (int)column0, low, high, (int)flags};
+  return 0;
+}
+
 int mssim_apply_action(mssim_handle h, const float* action, int32_t action_dim, void* stream) {
   flush_deferred(h, (hipStream_t)stream);
   if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
   hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, action, action_dim,
-                     h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags);
+                     h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags, h->ee);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1879,7 +1932,7 @@ static int finger_pair_list(mssim_handle h, int obj_row, int f1_row, int f2_row)
 extern "C++" {
 template <int TASK>
 static bool control_step_with_task(mssim_handle h, DevState& S, hipStream_t st) {
-  if (!(h->deferred_action && h->deferred_fetch && h->fused && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream)) return false;
+  if (!(h->deferred_action && h->deferred_fetch && h->fused && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0)) return false;
   // The tail runs at the kernel's one wave per SIMD: worth it while all blocks are resident at once (4 per CU) and
   // the launch is latency-bound anyway; with more blocks the separate, fully occupied copy-out + epilogue launch
   // is cheaper than a tail per block.

@@ -572,7 +572,8 @@ class BaseEnv(gym.Env):
             spec = getattr(ctrl, "fused_action_spec", lambda: None)()
             self._fused_action_key, self._fused_action_ok = key, spec is not None
             if spec is not None:
-                self.scene.px.set_action_map(*spec)
+                self.scene.px.set_action_map(*spec[:4])
+                self.scene.px.set_ee_action_map(spec[4])
         return self._fused_action_ok and action.is_contiguous()
 
     _fused_epilogue_next = False

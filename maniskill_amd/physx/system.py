@@ -302,6 +302,13 @@ class MssimSystem:
     def set_action_map(self, column, low, high, flags):
         self._sim.set_action_map(column, low, high, flags)
 
+    def set_ee_action_map(self, ee):
+        """end-effector block of the action map: `(link_index, column0, low, high, flags)` or None (no block)"""
+        if ee is None:
+            self._sim.set_ee_action_map(-1, 0, 0.0, 0.0, 0)
+        else:
+            self._sim.set_ee_action_map(*ee)
+
     def apply_action(self, action: torch.Tensor):
         """affine action -> drive targets in one launch (include/mssim.h `apply_action`)"""
         assert action.dtype == torch.float32 and action.is_contiguous() and action.shape[0] == self.num_envs

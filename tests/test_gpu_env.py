@@ -87,20 +87,28 @@ def test_env_rollout_matches_oracle_backend(env_id):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
 
 
-@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1"])
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos"])
 def test_fused_callers_match_torch_path(monkeypatch, env_id):
-    """the fused native action map + task epilogue give the same step outputs as the torch path"""
+    """the fused native action map (joint-space map, and the end-effector block of pd_ee_delta_pos) + task
+    epilogue give the same step outputs as the torch path"""
     import gymnasium as gym
+
+    env_id, _, control_mode = env_id.partition(":")
+    kw = dict(control_mode=control_mode) if control_mode else {}
 
     N = 256
     g = torch.Generator().manual_seed(3)
-    acts = [2 * torch.rand(N, 8, generator=g) - 1 for _ in range(12)]
+    adim = 4 if control_mode == "pd_ee_delta_pos" else 8
+    acts = [2 * torch.rand(N, adim, generator=g) - 1 for _ in range(12)]
     outs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("MS_FUSED", fused)
-        env = gym.make(env_id, num_envs=N, sim_backend="physx_cuda", max_episode_steps=8)  # truncation switches on at step 8 of 12
+        env = gym.make(env_id, num_envs=N, sim_backend="physx_cuda", max_episode_steps=8, **kw)  # truncation switches on at step 8 of 12
         assert env.unwrapped._use_fused_callers == (fused == "1")
+        assert env.unwrapped.single_action_space.shape == (adim,)
         obs, _ = env.reset(seed=5)
+        if fused == "1":
+            assert env.unwrapped._fused_action_ready(acts[0].cuda()), "native action map not in use"
         traj = []
         for a in acts:
             obs, rew, term, trunc, info = env.step(a.cuda())
@@ -109,7 +117,8 @@ def test_fused_callers_match_torch_path(monkeypatch, env_id):
         env.close()
     # (the native action map rounds `low + 0.5 (a + 1)(high - low)` differently from the torch expression by
     # an ulp, so the two 12-step trajectories drift apart at the 1e-5 level; contact-rich Peg a bit more)
-    tol = 5e-5 if env_id == "PegInsertionSide-v1" else 1e-5
+    # (the end-effector block inverts J J^T in closed form where torch.linalg.solve factorises it)
+    tol = 5e-5 if (env_id == "PegInsertionSide-v1" or control_mode) else 1e-5
     for (o1, r1, t1, i1, tr1), (o2, r2, t2, i2, tr2) in zip(*outs):
         assert tr1.dtype == torch.bool and torch.equal(tr1, tr2)  # time limit: fused epilogue vs TimeLimitWrapper's comparison
         assert torch.allclose(o1, o2, atol=tol), (o1 - o2).abs().max()
