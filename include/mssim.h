@@ -239,12 +239,14 @@ int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
  *   target[j] = (flags[j] & 1 ? qpos[j] : 0) + a        (column[j] < 0: joint left untouched)
  * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host. */
 int MSSIM_FN(set_action_map)(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags);
-/* End-effector block of the action map, for `pd_ee_delta_pos` (agents/controllers/pd_ee_pose.py:79-96 with
- * Kinematics.compute_ik's delta solver, controllers/utils/kinematics.py:156-171): action columns column0..+2 are
- * a translation of link `link_index` in the root frame (flags & 2: clipped to [-1,1] and mapped to [low, high]);
- * the joints flagged 4 in set_action_map get  target = qpos + J^T (J J^T + 1e-9 I)^-1 a,  J = translational
- * Jacobian of the link over the joints on its path, from the state of the last FK. link_index < 0 removes the block. */
-int MSSIM_FN(set_ee_action_map)(mssim_handle h, int32_t link_index, int32_t column0, float low, float high, int32_t flags);
+/* End-effector block of the action map, for `pd_ee_delta_pos` (rows = 3) and `pd_ee_delta_pose` (rows = 6)
+ * (agents/controllers/pd_ee_pose.py:79-96, 197-210 with Kinematics.compute_ik's delta solver,
+ * controllers/utils/kinematics.py:156-171): action columns column0..+rows-1 are a translation (and a rotation
+ * vector) of link `link_index` in the root frame. flags & 2: translation clipped to [-1,1] and mapped to
+ * [low, high]; rotation clipped by its norm to 1 and multiplied by rot_scale. The joints flagged 4 in
+ * set_action_map get  target = qpos + J^T (J J^T + 1e-9 I)^-1 a,  J = Jacobian of the link over the joints on
+ * its path, from the state of the last FK. link_index < 0 removes the block. */
+int MSSIM_FN(set_ee_action_map)(mssim_handle h, int32_t link_index, int32_t column0, int32_t rows, float low, float high, float rot_scale, int32_t flags);
 int MSSIM_FN(apply_action)(mssim_handle h, const float* action /* device [N][action_dim] */, int32_t action_dim, void* stream);
 /* apply_action followed by step(n_substeps) -- BaseEnv._step_action's set_action + substep loop
  * (envs/sapien_env.py:1009-1021) -- as ONE launch when the control-step kernel is in use (the action map runs

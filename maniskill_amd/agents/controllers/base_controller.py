@@ -192,7 +192,7 @@ class CombinedController(DictController):
         sub-controller cannot be expressed as an affine action -> target map"""
         n = self.articulation.max_dof
         col, lo, hi, fl = [-1] * n, [0.0] * n, [0.0] * n, [0] * n
-        ee = None  # end-effector block: (link index, first action column, low, high, flags)
+        ee = None  # end-effector block: (link index, first action column, rows, low, high, rot_scale, flags)
         for uid, c in self.controllers.items():
             spec = getattr(c, "fused_action_spec", lambda: None)()
             if spec is None:
@@ -201,8 +201,8 @@ class CombinedController(DictController):
             if isinstance(spec, dict):
                 if ee is not None:
                     return None  # one end-effector block
-                link, l, h, f = spec["ee"]
-                ee = (link, start, l, h, f)
+                link, rows, l, h, rs, f = spec["ee"]
+                ee = (link, start, rows, l, h, rs, f)
                 for dof in spec["dofs"]:
                     fl[dof] = 4  # driven by the end-effector block
                 continue

@@ -42,21 +42,31 @@ class PDEEPosController(PDJointPosController):
         self.single_action_space = spaces.Box(low, high, dtype=np.float32)
 
     def fused_action_spec(self):
-        """the delta-translation controller (`pd_ee_delta_pos`) is one pseudo-inverse step of the commanded
-        translation: the native action map has an end-effector block for exactly that (include/mssim.h
-        `set_ee_action_map`). Returns {"ee": (link index, low, high, flags), "dofs": [...]}; every other
-        configuration keeps IK in torch between the action and the joint targets."""
+        """the delta controllers (`pd_ee_delta_pos`, `pd_ee_delta_pose`) are one pseudo-inverse step of the
+        commanded translation (and rotation vector): the native action map has an end-effector block for
+        exactly that (include/mssim.h `set_ee_action_map`). Returns {"ee": (link index, rows, low, high,
+        rot_scale, flags), "dofs": [...]}; every other configuration keeps IK in torch between the action and
+        the joint targets."""
         cfg = self.config
-        if not (type(cfg) is PDEEPosControllerConfig and cfg.use_delta and not cfg.use_target and not cfg.interpolate
-                and cfg.frame == "root_translation"):
+        pose = type(cfg) is PDEEPoseControllerConfig
+        if not (pose or type(cfg) is PDEEPosControllerConfig) or not cfg.use_delta or cfg.use_target or cfg.interpolate:
+            return None
+        if cfg.frame != ("root_translation:root_aligned_body_rotation" if pose else "root_translation"):
             return None
         lo, hi = np.broadcast_to(cfg.pos_lower, 3), np.broadcast_to(cfg.pos_upper, 3)
         if self._normalize_action and not (np.all(lo == lo[0]) and np.all(hi == hi[0])):
             return None  # the native block takes one [low, high] for the three axes
+        rot_scale = 0.0
+        if pose:
+            rl = np.broadcast_to(cfg.rot_lower, 3)
+            if not np.all(rl == rl[0]):
+                return None
+            rot_scale = float(rl[0])
         if set(self.kinematics.active_ancestor_joint_idxs) != set(int(i) for i in self.active_joint_indices.tolist()):
             return None  # the step moves every joint on the link's path: they must all be this controller's
         flags = 2 if self._normalize_action else 0
-        return dict(ee=(self.kinematics.end_link_idx, float(lo[0]), float(hi[0]), flags), dofs=[int(i) for i in self.active_joint_indices.tolist()])
+        return dict(ee=(self.kinematics.end_link_idx, 6 if pose else 3, float(lo[0]), float(hi[0]), rot_scale, flags),
+                    dofs=[int(i) for i in self.active_joint_indices.tolist()])
 
     @property
     def ee_pos(self):

@@ -1084,8 +1084,10 @@ __global__ void k_query(DevModel M, DevState S, const int* q, int nq, int body_q
 struct EeMap {
   int link;    // < 0: no end-effector block
   int col0;    // first action column
+  int rows;    // 3: translation (pd_ee_delta_pos), 6: translation + rotation vector (pd_ee_delta_pose)
   float lo, hi;
-  int flags;   // 2: clip to [-1, 1] and map to [lo, hi]
+  float rot_scale;  // rows == 6: the rotation columns are clipped by their norm to 1 and scaled by this (pd_ee_pose.py:197-210)
+  int flags;   // 2: clip to [-1, 1] and map to [lo, hi] (translation) / clip by norm and scale (rotation)
 };
 // affine action -> drive targets (user-visible buffer + simulation state)
 __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const float* __restrict__ action, int adim,
@@ -1115,7 +1117,7 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
     const pose_t Pb = b < 0 ? root : pose_soa(S.bodypose, 7 * b, N, e);
     const f3 pe = pmul(Pb, pose_from(M.link_frame + 7 * ee.link)).p;
     const unsigned path = b < 0 ? 0u : (M.dof_anc[b] | (1u << b));
-    float av[3];
+    float av[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < 3; r++) {
       float a = action[(size_t)e * adim + ee.col0 + r];
       if (ee.flags & 2) {
@@ -1124,22 +1126,83 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
       }
       av[r] = a;
     }
-    auto jcol = [&](int j) {
+    if (ee.rows == 6) {
+      f3 rot = f3{action[(size_t)e * adim + ee.col0 + 3], action[(size_t)e * adim + ee.col0 + 4], action[(size_t)e * adim + ee.col0 + 5]};
+      if (ee.flags & 2) {
+        const float nr = sqrtf(dot(rot, rot));
+        if (nr > 1.f) rot = rot * (1.f / fmaxf(nr, 1e-12f));
+        rot = rot * ee.rot_scale;
+      }
+      av[3] = rot.x; av[4] = rot.y; av[5] = rot.z;
+    }
+    // column j of the link's Jacobian in the root frame: linear part, angular part
+    auto jcol = [&](int j, f3& jw) {
       const f3 a = f3{SOA(S.bodyaux, 6 * j), SOA(S.bodyaux, 6 * j + 1), SOA(S.bodyaux, 6 * j + 2)};
       const f3 an = f3{SOA(S.bodyaux, 6 * j + 3), SOA(S.bodyaux, 6 * j + 4), SOA(S.bodyaux, 6 * j + 5)};
-      return mtmulv(Rr, M.dof_type[j] == MSSIM_JOINT_REVOLUTE ? cross(a, pe - an) : a);
+      const bool rev = M.dof_type[j] == MSSIM_JOINT_REVOLUTE;
+      jw = rev ? mtmulv(Rr, a) : f3{0.f, 0.f, 0.f};
+      return mtmulv(Rr, rev ? cross(a, pe - an) : a);
     };
-    s3 G = s3{1e-9f, 1e-9f, 1e-9f, 0.f, 0.f, 0.f};  // xx yy zz xy xz yz
-    for (int j = 0; j < n; j++)
-      if ((path >> j) & 1u) {
-        const f3 v = jcol(j);
-        G.xx += v.x * v.x; G.yy += v.y * v.y; G.zz += v.z * v.z; G.xy += v.x * v.y; G.xz += v.x * v.z; G.yz += v.y * v.z;
+    float y[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ee.rows == 3) {
+      s3 G = s3{1e-9f, 1e-9f, 1e-9f, 0.f, 0.f, 0.f};  // xx yy zz xy xz yz
+      for (int j = 0; j < n; j++)
+        if ((path >> j) & 1u) {
+          f3 w;
+          const f3 v = jcol(j, w);
+          G.xx += v.x * v.x; G.yy += v.y * v.y; G.zz += v.z * v.z; G.xy += v.x * v.y; G.xz += v.x * v.z; G.yz += v.y * v.z;
+        }
+      const f3 y3 = smulv(sinverse(G), f3{av[0], av[1], av[2]});
+      y[0] = y3.x; y[1] = y3.y; y[2] = y3.z;
+    } else {
+      // 6 x 6: J J^T + 1e-9 I is symmetric positive definite -> Cholesky without pivoting, two triangular solves
+      float G[6][6];
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) G[r][q] = r == q ? 1e-9f : 0.f;
+      for (int j = 0; j < n; j++)
+        if ((path >> j) & 1u) {
+          f3 w;
+          const f3 v = jcol(j, w);
+          const float cj[6] = {v.x, v.y, v.z, w.x, w.y, w.z};
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int q = 0; q <= r; q++) G[r][q] += cj[r] * cj[q];
+        }
+      float Lc[6][6];
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int q = 0; q <= r; q++) {
+          float sum = G[r][q];
+#pragma unroll
+          for (int m = 0; m < q; m++) sum -= Lc[r][m] * Lc[q][m];
+          Lc[r][q] = r == q ? sqrtf(fmaxf(sum, 1e-20f)) : sum / Lc[q][q];
+        }
+      float z[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        float sum = av[r];
+#pragma unroll
+        for (int m = 0; m < r; m++) sum -= Lc[r][m] * z[m];
+        z[r] = sum / Lc[r][r];
       }
-    const f3 y = smulv(sinverse(G), f3{av[0], av[1], av[2]});
+#pragma unroll
+      for (int r = 5; r >= 0; r--) {
+        float sum = z[r];
+#pragma unroll
+        for (int m = r + 1; m < 6; m++) sum -= Lc[m][r] * y[m];
+        y[r] = sum / Lc[r][r];
+      }
+    }
     for (int j = 0; j < n; j++)
       if (((path >> j) & 1u) && (flags[j] & 4)) {
+        f3 w;
+        const f3 v = jcol(j, w);
         const float qj = B.art_qpos ? B.art_qpos[(size_t)e * n + j] : SOA(S.q, j);
-        const float t = qj + dot(jcol(j), y);
+        const float t = qj + v.x * y[0] + v.y * y[1] + v.z * y[2] + w.x * y[3] + w.y * y[4] + w.z * y[5];
         SOA(S.qt, j) = t;
         if (B.art_target_qpos) B.art_target_qpos[(size_t)e * n + j] = t;
       }
@@ -1417,7 +1480,7 @@ struct mssim_sim {
   int row_fields = 0;
   // profiling (bench roofline block): event pairs recorded on the launch stream
   int* d_act_col = nullptr; float* d_act_lo = nullptr; float* d_act_hi = nullptr; int* d_act_flags = nullptr;
-  EeMap ee{-1, 0, 0.f, 0.f, 0};
+  EeMap ee{-1, 0, 3, 0.f, 0.f, 0.f, 0};
   unsigned solve_lds_bytes = 0;
   bool coop = false;   // use k_solve16
   bool fused = false;  // k_solve16<true>: one launch per control step, narrowphase in the kernel
@@ -1890,10 +1953,10 @@ int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low
   return 0;
 }
 
-int mssim_set_ee_action_map(mssim_handle h, int32_t link_index, int32_t column0, float low, float high, int32_t flags) {
+int mssim_set_ee_action_map(mssim_handle h, int32_t link_index, int32_t column0, int32_t rows, float low, float high, float rot_scale, int32_t flags) {
   flush_deferred(h, h->deferred_stream);
-  if (link_index >= h->M.n_link) { h->err = "set_ee_action_map: bad link index"; return 1; }
-  h->ee = EeMap{link_index < 0 ? -1 : (int)link_index, (int)column0, low, high, (int)flags};
+  if (link_index >= h->M.n_link || (link_index >= 0 && rows != 3 && rows != 6)) { h->err = "set_ee_action_map: bad link index / rows"; return 1; }
+  h->ee = EeMap{link_index < 0 ? -1 : (int)link_index, (int)column0, (int)rows, low, high, rot_scale, (int)flags};
   return 0;
 }
 

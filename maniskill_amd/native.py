@@ -185,7 +185,7 @@ class NativeLib:
         f("link_jacobian", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
         f("overflow_count", C.c_int, [H, C.c_void_p])
         f("set_action_map", C.c_int, [H, _I32P, _F32P, _F32P, _I32P])
-        f("set_ee_action_map", C.c_int, [H, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32])
+        f("set_ee_action_map", C.c_int, [H, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32])
         f("apply_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
         f("step_action", C.c_int, [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p])
         f("defer_fetch", C.c_int, [H, C.c_uint32])
@@ -323,8 +323,8 @@ class NativeSim:
         assert len(col) == len(lo) == len(hi) == len(fl) == self.model.n_dof
         self._check(self.lib.set_action_map(self.h, col.ctypes.data_as(_I32P), lo.ctypes.data_as(_F32P), hi.ctypes.data_as(_F32P), fl.ctypes.data_as(_I32P)), "set_action_map")
 
-    def set_ee_action_map(self, link_index, column0, low, high, flags):
-        self._check(self.lib.set_ee_action_map(self.h, int(link_index), int(column0), float(low), float(high), int(flags)), "set_ee_action_map")
+    def set_ee_action_map(self, link_index, column0, rows, low, high, rot_scale, flags):
+        self._check(self.lib.set_ee_action_map(self.h, int(link_index), int(column0), int(rows), float(low), float(high), float(rot_scale), int(flags)), "set_ee_action_map")
 
     def apply_action(self, action_ptr, action_dim, stream=None):
         self._check(self.lib.apply_action(self.h, action_ptr, action_dim, stream), "apply_action")

@@ -303,9 +303,9 @@ class MssimSystem:
         self._sim.set_action_map(column, low, high, flags)
 
     def set_ee_action_map(self, ee):
-        """end-effector block of the action map: `(link_index, column0, low, high, flags)` or None (no block)"""
+        """end-effector block of the action map: `(link_index, column0, rows, low, high, rot_scale, flags)` or None"""
         if ee is None:
-            self._sim.set_ee_action_map(-1, 0, 0.0, 0.0, 0)
+            self._sim.set_ee_action_map(-1, 0, 3, 0.0, 0.0, 0.0, 0)
         else:
             self._sim.set_ee_action_map(*ee)
 

@@ -855,7 +855,7 @@ int mssim_ref_link_jacobian(mssim_handle h, int32_t link, float* out, void*) {
   return 0;
 }
 int mssim_ref_apply_action(mssim_handle h, const float*, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
-int mssim_ref_set_ee_action_map(mssim_handle h, int32_t, int32_t, float, float, int32_t) { h->err = "not available in the oracle"; return 1; }
+int mssim_ref_set_ee_action_map(mssim_handle h, int32_t, int32_t, int32_t, float, float, float, int32_t) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_defer_fetch(mssim_handle h, uint32_t) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_defer_step_action(mssim_handle h, const float*, int32_t, int32_t, void*) { h->err = "not available in the oracle"; return 1; }
 int mssim_ref_step_action(mssim_handle h, const float*, int32_t, int32_t, void*) { h->err = "not available in the oracle"; return 1; }

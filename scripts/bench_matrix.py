@@ -33,7 +33,8 @@ def run(env_id, N, steps=200, control_mode="pd_joint_delta_pos", **kw):
 
 only = sys.argv[1:]
 for args, kw in ((("PickCube-v1", 4096), {}), (("PushCube-v1", 4096), {}), (("PegInsertionSide-v1", 2048), {}),
-                 (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pos")), (("PickCube-v1", 16384), {}),
+                 (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pos")), (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pose")),
+                 (("PickCube-v1", 16384), {}),
                  (("PickCube-v1", 4096), dict(sim_config=dict(control_freq=25)))):  # 4 substeps (SURVEY 8d reports 5 and 4)
     if not only or args[0] in only or kw.get("control_mode") in only or ("substeps4" in only and "sim_config" in kw):
         run(*args, **kw)

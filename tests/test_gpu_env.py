@@ -87,7 +87,7 @@ def test_env_rollout_matches_oracle_backend(env_id):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
 
 
-@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos"])
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos", "PickCube-v1:pd_ee_delta_pose"])
 def test_fused_callers_match_torch_path(monkeypatch, env_id):
     """the fused native action map (joint-space map, and the end-effector block of pd_ee_delta_pos) + task
     epilogue give the same step outputs as the torch path"""
@@ -98,7 +98,7 @@ def test_fused_callers_match_torch_path(monkeypatch, env_id):
 
     N = 256
     g = torch.Generator().manual_seed(3)
-    adim = 4 if control_mode == "pd_ee_delta_pos" else 8
+    adim = {"pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7}.get(control_mode, 8)
     acts = [2 * torch.rand(N, adim, generator=g) - 1 for _ in range(12)]
     outs = []
     for fused in ("1", "0"):
