@@ -69,8 +69,9 @@ def timed_steps(env, steps, gather, barrier):
         a = 2 * torch.rand((N, 8), device=dev) - 1
         obs, rew, term, trunc, info = env.step(a)
         if gather is not None:
-            gather.start(obs, rew, term | trunc)  # one packed RCCL all-gather per step, overlapping the next step
+            gather.add(obs, rew, term | trunc)  # packed record into the rollout chunk; one RCCL all-gather per chunk
     if gather is not None:
+        gather.flush()
         gather.result()  # the last collective has to be complete inside the timed region
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
@@ -121,6 +122,7 @@ def main():
     ap.add_argument("--env-id", default="PickCube-v1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of step outputs when --gpus > 1")
+    ap.add_argument("--gather-every", type=int, default=8, help="control steps per all-gather (rollout chunk) when --gpus > 1")
     args = ap.parse_args()
 
     import maniskill_amd.envs  # noqa: F401
@@ -138,7 +140,7 @@ def main():
             break
         time.sleep(0.5)
 
-    from maniskill_amd.distributed import StepGather, shard_seeds, world_info
+    from maniskill_amd.distributed import RolloutGather, shard_seeds, world_info
 
     rank, local_rank, world = world_info()
     if world != args.gpus:
@@ -163,11 +165,14 @@ def main():
     base = env.unwrapped
     seeds = shard_seeds(global_seeds, rank, world)
     obs, _ = env.reset(seed=seeds)
-    gather = StepGather(n, obs.shape[1], dev) if (world > 1 and not args.no_gather) else None
+    gather = RolloutGather(n, obs.shape[1], dev, chunk=args.gather_every) if (world > 1 and not args.no_gather) else None
     for _ in range(args.warmup):
         o, r, te, tr, _ = env.step(2 * torch.rand((n, 8), device=dev) - 1)
         if gather is not None:
-            gather.start(o, r, te | tr)
+            gather.add(o, r, te | tr)
+    if gather is not None:
+        gather.flush()
+        gather.result()
     env.reset(seed=seeds)
     px = base.scene.px
     px.profile_enable(True)
@@ -213,7 +218,7 @@ def main():
                 "15+1 solver iterations, random actions 2*U-1, no resets inside the timed region",
                 "envs_per_gpu": n,
                 "substeps": substeps,
-                "parallelism": f"env-sharded x{world}, no in-step collective" + (", one packed RCCL all-gather of obs/reward/done per step (asynchronous, overlaps the next step)" if gather is not None else ""),
+                "parallelism": f"env-sharded x{world}, no in-step collective" + (f", one packed RCCL all-gather of obs/reward/done per {args.gather_every} control steps (asynchronous, overlaps the next chunk)" if gather is not None else ""),
                 "solver_overflow_envs": overflow,
             },
             "roofline": {

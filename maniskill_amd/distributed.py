@@ -77,3 +77,60 @@ class StepGather:
         if self.world == 1:
             return obs, rew, done
         return self.result(self.start(obs, rew, done))
+
+
+class RolloutGather:
+    """All-gather of the step outputs in chunks of `chunk` control steps: fewer, larger collectives.
+
+    A learner consumes rollouts, not single steps, and the ranks' step times differ from step to step (a launch
+    lasts as long as its slowest env block), so a collective per step couples every step to the slowest rank and
+    pays one RCCL launch latency per step. Here each step's packed [n, D+2] record (obs | reward | done) is copied
+    into slot k of a [chunk, n, D+2] send buffer and every `chunk`-th step ONE `all_gather_into_tensor` moves the
+    whole chunk (chunk x 0.7 MB per rank at 4096 envs) -- asynchronously, double-buffered, so the next chunk's
+    steps overlap it. `flush` sends a partial chunk; `result` returns views shaped [world, steps, n, ...].
+    """
+
+    def __init__(self, n_local: int, obs_dim: int, device, chunk: int = 8, world: Optional[int] = None):
+        self.world = dist.get_world_size() if world is None else world
+        self.n, self.D, self.K = n_local, obs_dim, int(chunk)
+        self.send = [torch.empty((self.K, n_local, obs_dim + 2), dtype=torch.float32, device=device) for _ in range(2)]
+        self.recv = [torch.empty((self.world, self.K, n_local, obs_dim + 2), dtype=torch.float32, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.filled = [0, 0]  # steps in the last launched chunk of each buffer
+        self.b, self.k = 0, 0
+        self.last = None
+
+    def add(self, obs: torch.Tensor, rew: torch.Tensor, done: torch.Tensor) -> Optional[int]:
+        """record one step; returns the buffer id when this step completed (and launched) a chunk"""
+        if self.k == 0 and self.work[self.b] is not None:  # about to overwrite a buffer whose collective may be in flight
+            self.work[self.b].wait()
+            self.work[self.b] = None
+        s = self.send[self.b][self.k]
+        s[:, : self.D].copy_(obs)
+        s[:, self.D].copy_(rew)
+        s[:, self.D + 1].copy_(done)
+        self.k += 1
+        return self.flush() if self.k == self.K else None
+
+    def flush(self) -> Optional[int]:
+        """launch the collective of the (possibly partial) current chunk"""
+        if self.k == 0:
+            return None
+        b = self.b
+        if self.world == 1:
+            self.recv[b][0].copy_(self.send[b])
+        else:
+            self.work[b] = dist.all_gather_into_tensor(self.recv[b].view(-1, self.D + 2), self.send[b].view(-1, self.D + 2), async_op=True)
+        self.filled[b] = self.k
+        self.last = b
+        self.b, self.k = b ^ 1, 0
+        return b
+
+    def result(self, b: Optional[int] = None):
+        """(obs [world, steps, n, D], reward [world, steps, n], done [world, steps, n]) of a launched chunk"""
+        b = self.last if b is None else b
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        r = self.recv[b][:, : self.filled[b]]
+        return r[..., : self.D], r[..., self.D], r[..., self.D + 1] > 0.5

@@ -39,8 +39,22 @@ for i, a in enumerate(acts):
         pending = b
 O, R, D = gather.result(pending)
 assert D.dtype == torch.bool and D.shape == (n * world,)
+# chunked form: 2 steps per collective, a full chunk and a flushed partial one
+from maniskill_amd.distributed import RolloutGather
+rg = RolloutGather(n, obs.shape[1], "cpu", chunk=2)
+chunks = []
+for i in range(3):
+    obs, rew, te, tr, _ = env.step(acts[i][rank * n:(rank + 1) * n])
+    b = rg.add(obs, rew, te | tr)
+    if b is not None:
+        chunks.append(tuple(t.clone() for t in rg.result(b)))
+rg.flush()
+chunks.append(tuple(t.clone() for t in rg.result()))
+assert [c[0].shape[:3] for c in chunks] == [(world, 2, n), (world, 1, n)] and chunks[0][2].dtype == torch.bool
+RO = torch.cat([c[0] for c in chunks], 1)   # [world, 3 steps, n, D]
+RR = torch.cat([c[1] for c in chunks], 1)
 if rank == 0:
-    torch.save(dict(obs=O.clone(), rew=R.clone()), os.environ["MS_OUT"])
+    torch.save(dict(obs=O.clone(), rew=R.clone(), robs=RO, rrew=RR), os.environ["MS_OUT"])
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -87,3 +101,10 @@ def test_two_rank_sharded_run_equals_single_process(tmp_path):
         obs, rew, *_ = e4.step(a[:4])
     assert torch.allclose(got["obs"][:4], obs, atol=1e-6)
     assert torch.allclose(got["rew"][:4], rew, atol=1e-6)
+    # chunked (rollout) gather: rank 0's shard over 3 more steps with the same actions
+    ro, rr = got["robs"], got["rrew"]
+    assert ro.shape == (2, 3, 4, 42) and rr.shape == (2, 3, 4)
+    for i, a in enumerate(acts):
+        obs, rew, *_ = e4.step(a[:4])
+        assert torch.allclose(ro[0, i], obs, atol=1e-6) and torch.allclose(rr[0, i], rew, atol=1e-6)
+    assert torch.isfinite(ro).all() and not torch.equal(ro[0], ro[1])

@@ -246,3 +246,25 @@ def test_full_size_run_equals_small_run_env_by_env(env_id):
     assert torch.equal(big.unwrapped.get_state()[:n], small.unwrapped.get_state())
     big.close()
     small.close()
+
+
+def test_rollout_gather_buffers_on_device():
+    """the chunked gather's packing / double buffering on the GPU (world size 1: the collective is a copy;
+    the 2-rank collective itself is covered by the gloo test in tests/test_distributed.py)"""
+    from maniskill_amd.distributed import RolloutGather
+
+    n, D = 32, 42
+    rg = RolloutGather(n, D, "cuda", chunk=4, world=1)
+    g = torch.Generator().manual_seed(0)
+    steps = [(torch.rand(n, D, generator=g).cuda(), torch.rand(n, generator=g).cuda(), (torch.rand(n, generator=g) > 0.5).cuda()) for _ in range(10)]
+    got = []
+    for o, r, d in steps:
+        b = rg.add(o, r, d)
+        if b is not None:
+            got.append(tuple(t.clone() for t in rg.result(b)))
+    rg.flush()
+    got.append(tuple(t.clone() for t in rg.result()))
+    assert [c[0].shape[1] for c in got] == [4, 4, 2]
+    O = torch.cat([c[0][0] for c in got]); R = torch.cat([c[1][0] for c in got]); Dn = torch.cat([c[2][0] for c in got])
+    assert torch.equal(O, torch.stack([s[0] for s in steps])) and torch.equal(R, torch.stack([s[1] for s in steps]))
+    assert torch.equal(Dn, torch.stack([s[2] for s in steps]))
