@@ -237,6 +237,8 @@ int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
  * (agents/controllers/pd_joint_pos.py:73-90, base_controller.py:120-133, utils/gym_utils.py:102-105):
  *   a = action[env][column[j]];  if (flags[j] & 2) a = low[j] + 0.5*(clip(a,-1,1)+1)*(high[j]-low[j]);
  *   target[j] = (flags[j] & 1 ? qpos[j] : 0) + a        (column[j] < 0: joint left untouched)
+ *   flags[j] & 8: a is the joint's velocity drive target instead (pd_joint_vel.py:31-33); flags[j] & 4: the joint
+ *   is driven by the end-effector block (set_ee_action_map)
  * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host. */
 int MSSIM_FN(set_action_map)(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags);
 /* End-effector block of the action map, for `pd_ee_delta_pos` (rows = 3) and `pd_ee_delta_pose` (rows = 6)

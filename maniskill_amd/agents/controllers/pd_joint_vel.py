@@ -30,6 +30,15 @@ class PDJointVelController(BaseController):
         action = self._preprocess_action(action)
         self.articulation.set_joint_drive_velocity_targets(action, self.joints, self.active_joint_indices)
 
+    def fused_action_spec(self):
+        """[(dof, local action column, low, high, flags)] for the native action map: flag 8 = velocity target"""
+        out = []
+        for i, dof in enumerate(self.active_joint_indices.tolist()):
+            lo = float(self.action_space_low[i]) if self._normalize_action else 0.0
+            hi = float(self.action_space_high[i]) if self._normalize_action else 0.0
+            out.append((dof, i, lo, hi, 8 | (2 if self._normalize_action else 0)))
+        return out
+
 
 @dataclass
 class PDJointVelControllerConfig(ControllerConfig):

@@ -72,6 +72,7 @@ struct DevState {
   const int* act_flags;                         // [n_dof] 1: delta on the current position, 2: clip + affine map
   const float* act_qpos;                        // user-visible qpos buffer (what the controller reads) or null
   float* act_target;                            // user-visible target_qpos buffer or null
+  float* act_target_vel;                        // user-visible target_qvel buffer or null
   // copy-out + task epilogue at the tail of the fused launch (whole control step = one launch); 0 = none
   unsigned tail_fetch;                          // mssim_fetch mask
   mssim_buffers tail_buf;
@@ -1105,6 +1106,11 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
       a = fminf(fmaxf(a, -1.f), 1.f);
       a = 0.5f * (hi[j] + lo[j]) + 0.5f * (hi[j] - lo[j]) * a;
     }
+    if (flags[j] & 8) {  // velocity drive target (pd_joint_vel, agents/controllers/pd_joint_vel.py:31-33)
+      SOA(S.qdt, j) = a;
+      if (B.art_target_qvel) B.art_target_qvel[(size_t)e * n + j] = a;
+      continue;
+    }
     const float qj = B.art_qpos ? B.art_qpos[(size_t)e * n + j] : SOA(S.q, j);  // what `controller.qpos` reads
     const float t = ((flags[j] & 1) ? qj : 0.f) + a;
     SOA(S.qt, j) = t;
@@ -1859,7 +1865,7 @@ static DevState state_with_action(mssim_handle h, const float* action, int actio
   DevState S = h->S;
   S.act = action; S.act_dim = action_dim;
   S.act_col = h->d_act_col; S.act_lo = h->d_act_lo; S.act_hi = h->d_act_hi; S.act_flags = h->d_act_flags;
-  S.act_qpos = h->buf.art_qpos; S.act_target = h->buf.art_target_qpos;
+  S.act_qpos = h->buf.art_qpos; S.act_target = h->buf.art_target_qpos; S.act_target_vel = h->buf.art_target_qvel;
   return S;
 }
 static int step_action_now(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, hipStream_t st) {
@@ -2002,7 +2008,7 @@ static bool control_step_with_task(mssim_handle h, DevState& S, hipStream_t st) 
   if ((h->N + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK > 4 * h->n_cu) return false;
   const DevState A = state_with_action(h, h->deferred_action, h->deferred_adim);
   S.act = A.act; S.act_dim = A.act_dim; S.act_col = A.act_col; S.act_lo = A.act_lo; S.act_hi = A.act_hi; S.act_flags = A.act_flags;
-  S.act_qpos = A.act_qpos; S.act_target = A.act_target;
+  S.act_qpos = A.act_qpos; S.act_target = A.act_target; S.act_target_vel = A.act_target_vel;
   S.tail_fetch = take_deferred_fetch(h);
   S.tail_buf = h->buf;
   h->deferred_action = nullptr;

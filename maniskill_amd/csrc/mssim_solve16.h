@@ -503,8 +503,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       const float qj = S.act_qpos ? S.act_qpos[(size_t)e * n + c] : q_c;
       const float t = ((fl & 1) ? qj : 0.f) + a;
       if (live) {
-        SOA(S.qt, c) = t;
-        if (S.act_target) S.act_target[(size_t)e * n + c] = t;
+        if (fl & 8) {  // velocity drive target
+          SOA(S.qdt, c) = a;
+          if (S.act_target_vel) S.act_target_vel[(size_t)e * n + c] = a;
+        } else {
+          SOA(S.qt, c) = t;
+          if (S.act_target) S.act_target[(size_t)e * n + c] = t;
+        }
       }
     }
   }

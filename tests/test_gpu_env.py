@@ -87,7 +87,7 @@ def test_env_rollout_matches_oracle_backend(env_id):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
 
 
-@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos", "PickCube-v1:pd_ee_delta_pose"])
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos", "PickCube-v1:pd_ee_delta_pose", "PickCube-v1:pd_joint_vel"])
 def test_fused_callers_match_torch_path(monkeypatch, env_id):
     """the fused native action map (joint-space map, and the end-effector block of pd_ee_delta_pos) + task
     epilogue give the same step outputs as the torch path"""
