@@ -7,8 +7,9 @@
 Protocol restated from the reference's own harness (mani_skill/examples/benchmarking/gpu_sim.py:
 91-106, profiling.py:90-113): reset(seed=2022...), warm-up, then K env.step() calls with actions
 2*U[0,1)-1 drawn on device, wall time bracketed by device syncs; value = K * num_envs_total / s.
-One process per GPU, `--envs-per-gpu` envs each (weak scaling), no collective inside the step; with
-more than one rank the step outputs are all-gathered (RCCL) inside the timed region.
+One process per GPU, `--envs-per-gpu` envs each (weak scaling). The env path has no exchange step, so there
+is no collective on it (barrier + max-over-ranks timing only); `--gather` adds the optional centralised-learner
+exchange: the step outputs all-gathered over RCCL, in rollout chunks, inside the timed region.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -121,7 +122,10 @@ def main():
     ap.add_argument("--control-freq", type=int, default=20, help="sim_freq is 100: 20 -> 5 substeps (reference default), 25 -> 4")
     ap.add_argument("--env-id", default="PickCube-v1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of step outputs when --gpus > 1")
+    ap.add_argument("--gather", action="store_true",
+                    help="centralised-learner mode: all-gather obs/reward/done over RCCL inside the timed region (--gpus > 1). Off by "
+                         "default: the env path has no exchange step, every rank's learner shard consumes its own envs")
+    ap.add_argument("--no-gather", action="store_true", help="(default behaviour; kept for older command lines)")
     ap.add_argument("--gather-every", type=int, default=8, help="control steps per all-gather (rollout chunk) when --gpus > 1")
     args = ap.parse_args()
 
@@ -165,7 +169,7 @@ def main():
     base = env.unwrapped
     seeds = shard_seeds(global_seeds, rank, world)
     obs, _ = env.reset(seed=seeds)
-    gather = RolloutGather(n, obs.shape[1], dev, chunk=args.gather_every) if (world > 1 and not args.no_gather) else None
+    gather = RolloutGather(n, obs.shape[1], dev, chunk=args.gather_every) if (world > 1 and args.gather and not args.no_gather) else None
     for _ in range(args.warmup):
         o, r, te, tr, _ = env.step(2 * torch.rand((n, 8), device=dev) - 1)
         if gather is not None:
@@ -218,7 +222,7 @@ def main():
                 "15+1 solver iterations, random actions 2*U-1, no resets inside the timed region",
                 "envs_per_gpu": n,
                 "substeps": substeps,
-                "parallelism": f"env-sharded x{world}, no in-step collective" + (f", one packed RCCL all-gather of obs/reward/done per {args.gather_every} control steps (asynchronous, overlaps the next chunk)" if gather is not None else ""),
+                "parallelism": f"env-sharded x{world}, no collective on the env path" + (f"; centralised-learner mode: one packed RCCL all-gather of obs/reward/done per {args.gather_every} control steps (asynchronous, overlaps the next chunk)" if gather is not None else ""),
                 "solver_overflow_envs": overflow,
             },
             "roofline": {
