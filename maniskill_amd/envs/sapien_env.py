@@ -400,8 +400,12 @@ class BaseEnv(gym.Env):
             # the reference resets controllers under the all-ones mask (sapien_env.py:857-871)
             self.agent.controller.reset()
 
-        info = self.get_info()
-        obs = self.get_obs(info)
+        fused = self._fused_step_outputs(None, advance=False) if (self._use_fused_callers and self._fused_ok()) else None
+        if fused is not None:  # evaluate + obs of the reset state in one native launch (same values, see the GPU tests)
+            obs, _, info = fused
+        else:
+            info = self.get_info()
+            obs = self.get_obs(info)
         info["reconfigure"] = reconfigure
         return obs, info
 
@@ -592,8 +596,9 @@ class BaseEnv(gym.Env):
         """will `_fused_step_outputs` produce this step's outputs? (tasks with a native epilogue override both)"""
         return False
 
-    def _fused_step_outputs(self, action):
-        """tasks may return (obs, reward, info) computed by a fused native kernel; None = torch path"""
+    def _fused_step_outputs(self, action, advance: bool = True):
+        """tasks may return (obs, reward, info) computed by a fused native kernel; None = torch path.
+        `advance=False` (reset): the outputs of the current state without advancing `elapsed_steps`"""
         return None
 
     def evaluate(self) -> dict:

@@ -224,7 +224,7 @@ class PegInsertionSideEnv(BaseEnv):
             self._fused_ok_cache = ok
         return ok
 
-    def _fused_step_outputs(self, action):
+    def _fused_step_outputs(self, action, advance: bool = True):
         if not self._fused_ok():
             return None
         from maniskill_amd import native
@@ -245,8 +245,13 @@ class PegInsertionSideEnv(BaseEnv):
         reward = torch.empty((N,), dtype=torch.float32, device=self.device)
         flags = torch.empty((N, 1), dtype=torch.uint8, device=self.device)
         head = torch.empty((N, 3), dtype=torch.float32, device=self.device)
-        es = torch.empty_like(self._elapsed_steps)
-        st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
-        st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
+        if advance:
+            es = torch.empty_like(self._elapsed_steps)
+            st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
+            st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
+        else:  # reset(): outputs of the current state, the step counter stays where it is
+            es = self._elapsed_steps.clone()
+            st["task"].elapsed_steps = st["task"].elapsed_out = st["task"].truncated_out = None
+            st["task"].time_limit = 0
         px.task_peg_outputs(st["task"], obs, reward, flags, head)
         return obs, reward, dict(elapsed_steps=es, success=flags.view(torch.bool)[:, 0], peg_head_pos_at_hole=head)

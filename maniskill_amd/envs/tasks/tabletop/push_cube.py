@@ -54,16 +54,16 @@ class PushCubeEnv(BaseEnv):
         )
 
     def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
-        with torch.device(self.device):
-            b = len(env_idx)
-            self.table_scene.initialize(env_idx)
-            xyz = torch.zeros((b, 3))
-            xyz[..., :2] = torch.rand((b, 2)) * 0.2 - 0.1
-            xyz[..., 2] = self.cube_half_size
-            self.obj.set_pose(Pose.create_from_pq(p=xyz, q=[1, 0, 0, 0]))
-            target = xyz + torch.tensor([0.1 + self.goal_radius, 0, 0])
-            target[..., 2] = 1e-3
-            self.goal_region.set_pose(Pose.create_from_pq(p=target, q=euler2quat(0, np.pi / 2, 0)))
+        dev = self.device  # explicit devices, see PickCubeEnv._initialize_episode
+        b = len(env_idx)
+        self.table_scene.initialize(env_idx)
+        xyz = torch.zeros((b, 3), device=dev)
+        xyz[..., :2] = torch.rand((b, 2), device=dev) * 0.2 - 0.1
+        xyz[..., 2] = self.cube_half_size
+        self.obj.set_pose(Pose.create_from_pq(p=xyz, q=[1, 0, 0, 0]))
+        target = xyz + torch.tensor([0.1 + self.goal_radius, 0, 0], device=dev)
+        target[..., 2] = 1e-3
+        self.goal_region.set_pose(Pose.create_from_pq(p=target, q=euler2quat(0, np.pi / 2, 0)))
 
     def evaluate(self):
         is_obj_placed = (
@@ -103,7 +103,7 @@ class PushCubeEnv(BaseEnv):
             self._fused_ok_cache = ok
         return ok
 
-    def _fused_step_outputs(self, action):
+    def _fused_step_outputs(self, action, advance: bool = True):
         if not self._fused_ok():
             return None
         from maniskill_amd import native
@@ -119,8 +119,13 @@ class PushCubeEnv(BaseEnv):
         obs = torch.empty((N, D), dtype=torch.float32, device=self.device)
         reward = torch.empty((N,), dtype=torch.float32, device=self.device)
         flags = torch.empty((N, 1), dtype=torch.uint8, device=self.device)
-        es = torch.empty_like(self._elapsed_steps)
-        st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
-        st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
+        if advance:
+            es = torch.empty_like(self._elapsed_steps)
+            st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
+            st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
+        else:  # reset(): outputs of the current state, the step counter stays where it is
+            es = self._elapsed_steps.clone()
+            st["task"].elapsed_steps = st["task"].elapsed_out = st["task"].truncated_out = None
+            st["task"].time_limit = 0
         px.task_push_outputs(st["task"], obs, reward, flags)
         return obs, reward, dict(elapsed_steps=es, success=flags.view(torch.bool)[:, 0])

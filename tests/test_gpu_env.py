@@ -106,10 +106,12 @@ def test_fused_callers_match_torch_path(monkeypatch, env_id):
         env = gym.make(env_id, num_envs=N, sim_backend="physx_cuda", max_episode_steps=8, **kw)  # truncation switches on at step 8 of 12
         assert env.unwrapped._use_fused_callers == (fused == "1")
         assert env.unwrapped.single_action_space.shape == (adim,)
-        obs, _ = env.reset(seed=5)
+        obs, rinfo = env.reset(seed=5)
         if fused == "1":
             assert env.unwrapped._fused_action_ready(acts[0].cuda()), "native action map not in use"
-        traj = []
+        # reset(): obs / info of the reset state (native epilogue without advancing the step counter vs torch path)
+        z = torch.zeros(N)
+        traj = [(obs.cpu().clone(), z, z.bool(), {k: v.cpu().clone() for k, v in rinfo.items() if isinstance(v, torch.Tensor)}, z.bool())]
         for a in acts:
             obs, rew, term, trunc, info = env.step(a.cuda())
             traj.append((obs.cpu().clone(), rew.cpu().clone(), term.cpu().clone(), {k: v.cpu().clone() for k, v in info.items()}, trunc.cpu().clone()))
