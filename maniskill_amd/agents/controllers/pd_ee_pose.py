@@ -86,7 +86,7 @@ class PDEEPosController(PDJointPosController):
         if self._target_pose is None or self.scene._reset_mask_all:
             self._target_pose = Pose.create(cur.raw_pose.clone())
         else:
-            m = self.scene._reset_mask
+            m = self.scene._reset_idx
             self._target_pose.raw_pose[m] = cur.raw_pose[m]
 
     def compute_target_pose(self, prev_ee_pose_at_base, action):

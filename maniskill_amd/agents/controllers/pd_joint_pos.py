@@ -45,7 +45,7 @@ class PDJointPosController(BaseController):
             self._start_qpos = self.qpos.clone()
             self._target_qpos = self.qpos.clone()
         else:
-            m = self.scene._reset_mask
+            m = self.scene._reset_idx
             self._start_qpos[m] = self.qpos[m].clone()
             self._target_qpos[m] = self.qpos[m].clone()
 

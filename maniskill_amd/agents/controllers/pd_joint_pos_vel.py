@@ -26,7 +26,7 @@ class PDJointPosVelController(PDJointPosController):
         if self._target_qvel is None or self.scene._reset_mask_all:
             self._target_qvel = torch.zeros_like(self._target_qpos)
         else:
-            self._target_qvel[self.scene._reset_mask] = 0
+            self._target_qvel[self.scene._reset_idx] = 0
 
     def set_action(self, action):
         action = self._preprocess_action(action)

@@ -42,6 +42,7 @@ class ManiSkillScene:
         self._all_env_idx = torch.arange(self.num_envs, device=self.device)
         self._reset_mask_t = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
         self._reset_mask_all = True
+        self._reset_idx_t = self._all_env_idx
         m = self.sim_config.default_materials_config
         self.default_material = PhysxMaterial(m.static_friction, m.dynamic_friction, m.restitution)
         self._pair_queries = {}
@@ -58,6 +59,16 @@ class ManiSkillScene:
         """external assignment (reference style); costs one host sync to learn whether it is all-true"""
         self._reset_mask_t = mask.to(self.device).bool()
         self._reset_mask_all = bool(self._reset_mask_t.all())
+        self._reset_idx_t = None
+
+    @property
+    def _reset_idx(self) -> torch.Tensor:
+        """ascending indices of the envs selected by `_reset_mask`. Writes of `k` rows "where the mask is true" go
+        through these (`buf[idx] = rows`): indexing with the boolean mask itself makes torch count the selected rows
+        on the host, one device synchronisation per write -- a dozen per partial reset."""
+        if self._reset_idx_t is None:
+            self._reset_idx_t = torch.nonzero(self._reset_mask_t).flatten()
+        return self._reset_idx_t
 
     def _set_reset_idx(self, env_idx: Optional[torch.Tensor]):
         """sync-free form used by BaseEnv: None = all envs"""
@@ -69,6 +80,9 @@ class ManiSkillScene:
             m[env_idx] = True
             self._reset_mask_t = m
             self._reset_mask_all = False
+            self._reset_idx_t = torch.sort(env_idx.to(self.device).long()).values  # mask order = ascending env order
+            return
+        self._reset_idx_t = self._all_env_idx
 
     @contextlib.contextmanager
     def _narrow_reset_mask(self, env_idx):
@@ -76,12 +90,12 @@ class ManiSkillScene:
         if env_idx is None:
             yield
             return
-        prev, prev_all = self._reset_mask_t, self._reset_mask_all
+        prev, prev_all, prev_idx = self._reset_mask_t, self._reset_mask_all, self._reset_idx_t
         self._set_reset_idx(common.to_tensor(env_idx, device=self.device).long())
         try:
             yield
         finally:
-            self._reset_mask_t, self._reset_mask_all = prev, prev_all
+            self._reset_mask_t, self._reset_mask_all, self._reset_idx_t = prev, prev_all, prev_idx
 
     # ------------------------------------------------------------------ properties
     @property

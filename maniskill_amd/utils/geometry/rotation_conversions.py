@@ -63,10 +63,9 @@ def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:
 
 
 def _sqrt_positive_part(x: torch.Tensor) -> torch.Tensor:
-    ret = torch.zeros_like(x)
-    pos = x > 0
-    ret[pos] = torch.sqrt(x[pos])
-    return ret
+    # sqrt(max(0, x)) with a zero result for x <= 0 -- as a select: boolean-mask indexing would synchronise the
+    # host with the device on every call (every reset draws random orientations through this)
+    return torch.where(x > 0, torch.sqrt(x.clamp_min(0)), torch.zeros_like(x))
 
 
 def matrix_to_quaternion(matrix: torch.Tensor) -> torch.Tensor:
@@ -88,8 +87,9 @@ def matrix_to_quaternion(matrix: torch.Tensor) -> torch.Tensor:
         -2,
     )
     cand = cand / (2.0 * q_abs[..., None].max(q_abs.new_tensor(0.1)))
-    best = torch.nn.functional.one_hot(q_abs.argmax(-1), num_classes=4) > 0.5
-    return standardize_quaternion(cand[best, :].reshape(batch + (4,)))
+    # the candidate with the largest denominator (gather on the argmax: no boolean-mask indexing, no host sync)
+    idx = q_abs.argmax(-1)[..., None, None].expand(batch + (1, 4))
+    return standardize_quaternion(torch.gather(cand, -2, idx).reshape(batch + (4,)))
 
 
 def _axis_angle_rotation(axis: str, angle: torch.Tensor) -> torch.Tensor:

@@ -56,11 +56,10 @@ class _RigidBase:
     def _masked_write(self, cols: slice, value):
         value = common.to_tensor(value, device=self.device)
         rows = self._rows()
-        mask = self.scene._reset_mask
         if self.scene._reset_mask_all:
             rows[:, cols] = value
         else:
-            rows[mask, cols] = value
+            rows[self.scene._reset_idx, cols] = value  # (index list, not the boolean mask: no host sync)
 
     # velocities -------------------------------------------------------------
     @property
@@ -203,7 +202,7 @@ class Actor(_RigidBase):
         force = common.to_tensor(force, device=self.device)
         N = self.scene.num_envs
         buf = self.px.cuda_rigid_body_force.torch()[self._body_row * N : (self._body_row + 1) * N]
-        buf[self.scene._reset_mask, :3] = force
+        buf[self.scene._reset_idx, :3] = force
         self.px.gpu_apply_rigid_dynamic_force()
 
     @property
@@ -239,7 +238,7 @@ class Actor(_RigidBase):
             if self.scene._reset_mask_all:
                 self.before_hide_pose[:] = raw
             else:
-                self.before_hide_pose[self.scene._reset_mask] = raw
+                self.before_hide_pose[self.scene._reset_idx] = raw
             return
         self._masked_write(slice(0, 7), raw)
 

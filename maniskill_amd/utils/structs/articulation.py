@@ -249,7 +249,7 @@ class Articulation:
         if self.scene._reset_mask_all:
             buf[:, : self.max_dof] = value
         else:
-            buf[self.scene._reset_mask, : self.max_dof] = value
+            buf[self.scene._reset_idx, : self.max_dof] = value
 
     @property
     def qpos(self):
