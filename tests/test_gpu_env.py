@@ -270,3 +270,16 @@ def test_rollout_gather_buffers_on_device():
     O = torch.cat([c[0][0] for c in got]); R = torch.cat([c[1][0] for c in got]); Dn = torch.cat([c[2][0] for c in got])
     assert torch.equal(O, torch.stack([s[0] for s in steps])) and torch.equal(R, torch.stack([s[1] for s in steps]))
     assert torch.equal(Dn, torch.stack([s[2] for s in steps]))
+
+
+def test_yaw_only_random_quaternions_equal_the_generic_route_on_device():
+    import numpy as np
+
+    from maniskill_amd.envs.utils.randomization.pose import _yaw_quaternions
+    from maniskill_amd.utils.geometry.rotation_conversions import euler_angles_to_matrix, matrix_to_quaternion
+
+    g = torch.Generator().manual_seed(0)
+    t = (torch.rand(100000, generator=g) * 2 * np.pi).cuda()
+    ang = torch.zeros(len(t), 3, device="cuda")
+    ang[:, 2] = t
+    assert torch.equal(_yaw_quaternions(t), matrix_to_quaternion(euler_angles_to_matrix(ang, "XYZ")))

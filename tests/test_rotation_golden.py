@@ -32,3 +32,19 @@ def test_matrix_conversions_match_reference():
     close(rc.euler_angles_to_matrix(t("eul"), "ZYX"), "euler_ZYX")
     close(rc.axis_angle_to_quaternion(t("aa")), "axis_angle_to_quaternion")
     close(rc.quaternion_to_axis_angle(qa), "quaternion_to_axis_angle", atol=1e-5)
+
+
+def test_yaw_only_random_quaternions_equal_the_generic_route():
+    """the yaw-only fast path of random_quaternions is the generic euler -> matrix -> quaternion route, bit for bit"""
+    import numpy as np
+    import torch
+
+    from maniskill_amd.envs.utils.randomization.pose import _yaw_quaternions
+    from maniskill_amd.utils.geometry.rotation_conversions import euler_angles_to_matrix, matrix_to_quaternion
+
+    g = torch.Generator().manual_seed(0)
+    t = torch.rand(100000, generator=g) * 2 * np.pi
+    t[:8] = torch.tensor([0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi - 1e-7, 1e-8, np.pi - 1e-7, np.pi + 1e-7])
+    ang = torch.zeros(len(t), 3)
+    ang[:, 2] = t
+    assert torch.equal(_yaw_quaternions(t), matrix_to_quaternion(euler_angles_to_matrix(ang, "XYZ")))
