@@ -39,6 +39,11 @@ extern "C" {
 #endif
 
 #define MSSIM_ABI_VERSION 3
+/* Free bodies: the angular velocity a substep starts from, and the one its pose is integrated with, are clamped
+ * to this magnitude (rad/s) -- PhysX's default PxRigidDynamic maxAngularVelocity. Without it a thin body knocked
+ * into a fast spin (a peg squeezed out of the gripper) feeds the explicitly integrated gyroscopic term until the
+ * velocity overflows. */
+#define MSSIM_MAX_ANGULAR_VELOCITY 100.0f
 #define MSSIM_MAX_DOF 16        /* max articulation degrees of freedom per env            */
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */

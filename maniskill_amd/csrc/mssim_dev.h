@@ -25,6 +25,11 @@ MS_DEV float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
 MS_DEV float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
 MS_DEV float rsq_f(float x) { return __builtin_amdgcn_rsqf(x); }
 MS_DEV float norm(f3 a) { return sqrt_f(dot(a, a)); }
+// |w| <= wmax (MSSIM_MAX_ANGULAR_VELOCITY)
+MS_DEV f3 clamp_norm(f3 w, float wmax) {
+  const float n2 = dot(w, w);
+  return n2 > wmax * wmax ? w * (wmax * rsq_f(n2)) : w;
+}
 MS_DEV f3 normalized(f3 a) {
   const float nn = dot(a, a);
   return nn > 0.f ? a * rsq_f(nn) : f3{1.f, 0.f, 0.f};

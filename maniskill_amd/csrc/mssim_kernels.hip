@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
     float minv = 1.f / in[0];
     f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
     f3 v0 = f3{SOA(S.free_s, 13 * b + 7), SOA(S.free_s, 13 * b + 8), SOA(S.free_s, 13 * b + 9)};
-    f3 w0 = f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)};
+    f3 w0 = clamp_norm(f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)}, MSSIM_MAX_ANGULAR_VELOCITY);
     f3 acc = f3{SOA(S.free_force, 3 * b), SOA(S.free_force, 3 * b + 1), SOA(S.free_force, 3 * b + 2)} * minv;
     if (M.free_gravity[b]) acc += g;
     f3 vv = v0 + acc * dt;
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
         float in[10];
         free_inertial_of(M, N, b, e, in);
         f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)} + f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)} * dt;
-        f3 w = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
+        f3 w = clamp_norm(f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)}, MSSIM_MAX_ANGULAR_VELOCITY);
         q4 qq = q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)};
         qq = qnormalized(qq);
         q4 dq = qmul(q4{0.f, w.x, w.y, w.z}, qq);

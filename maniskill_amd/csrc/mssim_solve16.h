@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
       const int base = n + 6 * b;
       f3 v0 = f3{gbc(vfree_c, base), gbc(vfree_c, base + 1), gbc(vfree_c, base + 2)};
-      f3 w0 = f3{gbc(vfree_c, base + 3), gbc(vfree_c, base + 4), gbc(vfree_c, base + 5)};
+      f3 w0 = clamp_norm(f3{gbc(vfree_c, base + 3), gbc(vfree_c, base + 4), gbc(vfree_c, base + 5)}, MSSIM_MAX_ANGULAR_VELOCITY);
       f3 acc = f3{gbc(fforce_c, base), gbc(fforce_c, base + 1), gbc(fforce_c, base + 2)} * minv;
       if (M.free_gravity[b]) acc += g3;
       f3 vv = v0 + acc * dt;
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const float* in = fin[b];
           const int base = n + 6 * b;
           f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
-          f3 ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
+          f3 ww = clamp_norm(f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)}, MSSIM_MAX_ANGULAR_VELOCITY);
           f3 com = f3{L[S16_COM + 3 * b], L[S16_COM + 3 * b + 1], L[S16_COM + 3 * b + 2]} + vv * dt;
           float* pt = L + S16_PT + 7 * (S16_PT_FREE + b);
           q4 qq = qnormalized(q4{pt[3], pt[4], pt[5], pt[6]});

@@ -27,6 +27,11 @@ template <typename R> inline V3<R> cross(const V3<R>& a, const V3<R>& b) {
   return V3<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 template <typename R> inline R norm(const V3<R>& a) { return std::sqrt(dot(a, a)); }
+// |w| <= wmax (free-body angular velocity limit, MSSIM_MAX_ANGULAR_VELOCITY in include/mssim.h)
+template <typename R> inline V3<R> clamp_norm(const V3<R>& w, R wmax) {
+  const R n = norm(w);
+  return n > wmax ? w * (wmax / n) : w;
+}
 template <typename R> inline V3<R> normalized(const V3<R>& a) {
   R n = norm(a);
   return n > R(0) ? a * (R(1) / n) : V3<R>(1, 0, 0);

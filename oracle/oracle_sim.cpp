@@ -405,7 +405,8 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     Vec acc = E.free_force[b] * fminv[b];
     if (M.free_gravity[b]) acc += g;
     Vec v = E.free_v[b] + acc * dt;
-    Vec w = E.free_w[b] - fIinv[b] * cross(E.free_w[b], Iw * E.free_w[b]) * dt;
+    const Vec w0 = clamp_norm(E.free_w[b], Real(MSSIM_MAX_ANGULAR_VELOCITY));  // include/mssim.h
+    Vec w = w0 - fIinv[b] * cross(w0, Iw * w0) * dt;
     Real ld = Real(1) - dt * M.free_damping[2 * b], ad = Real(1) - dt * M.free_damping[2 * b + 1];
     fv[b] = v * (ld > 0 ? ld : Real(0));
     fw[b] = w * (ad > 0 ? ad : Real(0));
@@ -536,7 +537,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     const float* in = &finert[10 * b];
     Vec com = fcom[b] + fv_pos[b] * dt;
     Quat q = E.free_pose[b].q;
-    Vec w = fw_pos[b];
+    Vec w = clamp_norm(fw_pos[b], Real(MSSIM_MAX_ANGULAR_VELOCITY));
     Quat dq = qmul(Quat(0, w.x, w.y, w.z), q);
     q = qnormalized(Quat(q.w + Real(0.5) * dt * dq.w, q.x + Real(0.5) * dt * dq.x, q.y + Real(0.5) * dt * dq.y,
                          q.z + Real(0.5) * dt * dq.z));
