@@ -44,6 +44,12 @@ extern "C" {
  * into a fast spin (a peg squeezed out of the gripper) feeds the explicitly integrated gyroscopic term until the
  * velocity overflows. */
 #define MSSIM_MAX_ANGULAR_VELOCITY 100.0f
+/* Articulation joints: the joint velocity a substep ends with (what is stored and carried) and the one positions
+ * are integrated with are clamped to this magnitude (rad/s or m/s) -- the articulation counterpart of the limit
+ * above (PhysX: PxArticulationJointReducedCoordinate::setMaxJointVelocity). Without it drive targets far from the
+ * current pose (a pseudo-inverse IK step next to a singular arm configuration asks for tens of radians) accelerate
+ * the arm until the explicitly integrated velocity-product terms diverge. */
+#define MSSIM_MAX_JOINT_VELOCITY 100.0f
 #define MSSIM_MAX_DOF 16        /* max articulation degrees of freedom per env            */
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */

@@ -934,10 +934,11 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
 #pragma unroll T::UNROLL
   for (int j = 0; j < T::MAXD; j++) {
     if (j >= n) break;
-    SOA(S.qacc, j) = (v[j] - qd[j]) / dt;
-    q[j] += dt * vpos[j];
+    const float vj = fminf(fmaxf(v[j], -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
+    SOA(S.qacc, j) = (vj - qd[j]) / dt;
+    q[j] += dt * fminf(fmaxf(vpos[j], -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
     SOA(S.q, j) = q[j];
-    SOA(S.qd, j) = v[j];
+    SOA(S.qd, j) = vj;
   }
   for (int b = 0; b < M.n_free; b++) {
     SOA(S.free_s, 13 * b + 7) = FB(b, FB_V); SOA(S.free_s, 13 * b + 8) = FB(b, FB_V + 1); SOA(S.free_s, 13 * b + 9) = FB(b, FB_V + 2);

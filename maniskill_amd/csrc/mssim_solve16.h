@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #endif
     for (int it = 0; it <= n_iters; it++) {
       if (it == M.pos_iters) {
-        q_c += dt * v_c;
+        q_c += dt * fminf(fmaxf(v_c, -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
 #pragma unroll
         for (int b = 0; b < S16_MAX_FREE; b++) {
           if (b >= nf) break;
@@ -1580,9 +1580,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       naw = qrot(Jw.q, al_c);
       nan = Jw.p;
     }
-    // carry the state into the next substep
-    qacc_c = (v_c - qd_c) * inv_dt;
-    qd_c = art ? v_c : 0.f;
+    // carry the state into the next substep (joint velocities within MSSIM_MAX_JOINT_VELOCITY)
+    {
+      const float vj = art ? fminf(fmaxf(v_c, -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY) : 0.f;
+      qacc_c = (vj - qd_c) * inv_dt;
+      qd_c = vj;
+    }
     vfree_c = freel ? v_c : 0.f;
     bp_c = nb; aw_c = naw; an_c = nan;
     PH(15);
@@ -1591,7 +1594,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (art && live) {
         SOA(S.qacc, c) = qacc_c;
         SOA(S.q, c) = q_c;
-        SOA(S.qd, c) = v_c;
+        SOA(S.qd, c) = qd_c;
       }
       if (freel && live) {
         SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
@@ -1604,7 +1607,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       {
         float* p = L + S16_S + 6 * c;
         p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
-        L[S16_VEC + c] = art ? v_c : 0.f;
+        L[S16_VEC + c] = qd_c;
       }
       __syncthreads();
       sv6 nV = sv6{f3{0, 0, 0}, f3{0, 0, 0}};

@@ -529,9 +529,11 @@ void substep(mssim_sim* S, EnvState& E, int e) {
 
   // 6. integrate
   for (int j = 0; j < n; j++) {
-    E.qacc[j] = (v[j] - E.qd[j]) / dt;
-    E.q[j] += dt * v_pos[j];
-    E.qd[j] = v[j];
+    const Real vmax = Real(MSSIM_MAX_JOINT_VELOCITY);  // include/mssim.h
+    const Real vj = std::min(std::max(v[j], -vmax), vmax);
+    E.qacc[j] = (vj - E.qd[j]) / dt;
+    E.q[j] += dt * std::min(std::max(v_pos[j], -vmax), vmax);
+    E.qd[j] = vj;
   }
   for (int b = 0; b < nf; b++) {
     const float* in = &finert[10 * b];

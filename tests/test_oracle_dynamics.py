@@ -161,6 +161,23 @@ def test_drive_force_limit_saturates(tmp_path):
     assert abs(px.cuda_articulation_qacc.torch()[0, 0].item() - fmax / m) < 1e-6
 
 
+def test_joint_velocity_limit(tmp_path):
+    """a constant 5000 N push on a 1 kg slider: 50 m/s after one 10 ms substep, 100 m/s after two -- and no more than
+    MSSIM_MAX_JOINT_VELOCITY (100) from then on; positions advance with the limited velocity"""
+    dt = 0.01
+    px, _ = _one_joint_system(tmp_path, 0.0, 0.0, np.inf, dt, mass=1.0, lower=-1e6, upper=1e6)
+    vs, qs = [], []
+    for _ in range(6):
+        px.cuda_articulation_qf.torch()[:] = 5000.0
+        px.gpu_apply_all()
+        px.step(1)
+        px.gpu_fetch_all()
+        vs.append(px.cuda_articulation_qvel.torch()[0, 0].item())
+        qs.append(px.cuda_articulation_qpos.torch()[0, 0].item())
+    assert abs(vs[0] - 50.0) < 1e-6 and all(abs(v - 100.0) < 1e-9 for v in vs[1:])
+    assert abs((qs[-1] - qs[-2]) - 100.0 * dt) < 1e-9
+
+
 def test_joint_limit_stops_motion(tmp_path):
     dt = 0.01
     px, _ = _one_joint_system(tmp_path, 0.0, 0.0, np.inf, dt, mass=1.0, lower=-0.05, upper=0.05)
