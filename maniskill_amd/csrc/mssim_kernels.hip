@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
     }
   }
   // ---- implicit PD drives + tendons
-  float A[T::MAXD][T::MAXD], rhs[T::MAXD], tau0[T::MAXD], Dj[T::MAXD], kp[T::MAXD], kd[T::MAXD], qt[T::MAXD], qdt[T::MAXD];
+  float A[T::MAXD][T::MAXD], rhs[T::MAXD], rhs0[T::MAXD], tau0[T::MAXD], Dj[T::MAXD], kp[T::MAXD], kd[T::MAXD], qt[T::MAXD], qdt[T::MAXD];
 #pragma unroll T::UNROLL
   for (int j = 0; j < T::MAXD; j++) {
     if (j >= n) break;
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
       if (k >= n) break;
       mv += Mq[j][k] * qd[k];
     }
-    rhs[j] = mv + dt * (tau0[j] + rhs[j] - bias[j] + SOA(S.qf, j));
+    rhs0[j] = mv + dt * (rhs[j] - bias[j] + SOA(S.qf, j));  // without the drive torque (see k_solve16: no cancellation on saturation)
+    rhs[j] = rhs0[j] + dt * tau0[j];
   }
   // LDL^T, solve, force-limit active set, explicit inverse
   float L[T::MAXD][T::MAXD], v[T::MAXD], Ainv[T::MAXD][T::MAXD];
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
       if (fmax < 1e30f && fabsf(td) > fmax) {
         float sat = td > 0.f ? fmax : -fmax;
         A[j][j] -= Dj[j];
-        rhs[j] += dt * (sat - tau0[j]);
+        rhs[j] = rhs0[j] + dt * sat;
         any = true;
       }
     }

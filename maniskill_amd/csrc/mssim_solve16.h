@@ -1087,7 +1087,11 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #pragma unroll
       for (int k = 0; k < 16; k++) Trow[k] += w * cj * (k == a ? ca : (k == b ? cb : 0.f));
     }
-    float rhs_c = art ? mv + dt * (tau0 + tau_t - bias_c + qf_c) : 0.f;
+    // (the drive torque is kept apart from the rest of the right-hand side: a saturated joint swaps it for the
+    // constant limit torque, and with a target far away -- an IK step near a singular pose asks for 1e8 rad --
+    // `rhs += dt * (limit - tau0)` would cancel 1e9 against 1e9 in f32)
+    const float rhs0_c = art ? mv + dt * (tau_t - bias_c + qf_c) : 0.f;
+    float rhs_c = art ? rhs0_c + dt * tau0 : 0.f;
     PH(1);
 
     // ================================================================ A^-1 by Gauss-Jordan (row per lane)
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       const bool sat = art && fmax < 1e30f && fabsf(td) > fmax;
       if (!__any(sat)) break;
       if (sat) {
-        rhs_c += dt * ((td > 0.f ? fmax : -fmax) - tau0);
+        rhs_c = rhs0_c + dt * (td > 0.f ? fmax : -fmax);
         Dj = 0.f;
       }
     }

@@ -363,6 +363,11 @@ class BaseEnv(gym.Env):
             env_idx = common.to_tensor(options["env_idx"], device=self.device).long()
             if len(env_idx) != self.num_envs and reconfigure:
                 raise RuntimeError("Cannot do a partial reset and reconfigure the environment. You must do one or the other.")
+            if len(env_idx) == 0 and not reconfigure:  # nothing to reset: the current observation, no episode is touched
+                info = self.get_info()
+                obs = self.get_obs(info)
+                info["reconfigure"] = False
+                return obs, info
         else:
             env_idx = torch.arange(0, self.num_envs, device=self.device)
 

@@ -331,7 +331,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     for (int i = M.dof_parent[j]; i >= 0; i = M.dof_parent[i]) Mq[j * n + i] = Mq[i * n + j] = sdot(Sj[i], Fc);
   }
   // drives, tendons (implicit)
-  std::vector<Real> A(Mq), rhs(n), tau0(n), Dj(n), kp(n), kd(n);
+  std::vector<Real> A(Mq), rhs(n), rhs0(n), tau0(n), Dj(n), kp(n), kd(n);
   for (int j = 0; j < n; j++) {
     kp[j] = M.dof_drive[4 * j]; kd[j] = M.dof_drive[4 * j + 1];
     if ((int)M.dof_drive[4 * j + 3] == MSSIM_DRIVE_ACCELERATION) { kp[j] *= Mq[j * n + j]; kd[j] *= Mq[j * n + j]; }
@@ -352,7 +352,8 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   for (int j = 0; j < n; j++) {
     Real mv = 0;
     for (int k = 0; k < n; k++) mv += Mq[j * n + k] * E.qd[k];
-    rhs[j] = mv + dt * (tau0[j] + tau_t[j] - bias[j] + E.qf[j]);
+    rhs0[j] = mv + dt * (tau_t[j] - bias[j] + E.qf[j]);  // without the drive torque: a saturated joint swaps it, no cancellation
+    rhs[j] = rhs0[j] + dt * tau0[j];
   }
   std::vector<Real> L(A), qds(rhs);
   std::vector<Real> Ainv(n * n, Real(0));
@@ -368,7 +369,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
       if (std::fabs(td) > fmax) {
         Real sat = td > 0 ? fmax : -fmax;
         A[j * n + j] -= Dj[j];
-        rhs[j] += dt * (sat - tau0[j]);
+        rhs[j] = rhs0[j] + dt * sat;
         any = true;
       }
     }
