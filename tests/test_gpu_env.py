@@ -283,3 +283,30 @@ def test_yaw_only_random_quaternions_equal_the_generic_route_on_device():
     ang = torch.zeros(len(t), 3, device="cuda")
     ang[:, 2] = t
     assert torch.equal(_yaw_quaternions(t), matrix_to_quaternion(euler_angles_to_matrix(ang, "XYZ")))
+
+
+@pytest.mark.parametrize("env_id,control_mode", [("PickCube-v1", "pd_ee_delta_pose"), ("PegInsertionSide-v1", "pd_ee_delta_pos"), ("PegInsertionSide-v1", "pd_joint_delta_pos")])
+def test_abusive_rollouts_stay_bounded(env_id, control_mode):
+    """random end-effector pushes drive the arm through singular poses (IK steps of tens of radians), into the table
+    and against the peg: 600 control steps with full and partial resets stay finite and bounded -- the regime that
+    exposed the unbounded spin of thin bodies, the unbounded joint velocities and the f32 cancellation of saturated
+    drives (velocity limits of include/mssim.h; scripts/soak.py is the long form)"""
+    import gymnasium as gym
+
+    N = 1024
+    env = gym.make(env_id, num_envs=N, sim_backend=BACKEND, control_mode=control_mode)
+    adim = env.unwrapped.single_action_space.shape[0]
+    env.reset(seed=6)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    worst = torch.zeros((), device="cuda")
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for i in range(1, 601):
+        obs, rew, term, trunc, info = env.step(2 * torch.rand(N, adim, device="cuda", generator=g) - 1)
+        bad += (~torch.isfinite(obs)).sum() + (~torch.isfinite(rew)).sum()
+        worst = torch.maximum(worst, torch.nan_to_num(obs, nan=0.0, posinf=0.0, neginf=0.0).abs().max())
+        if i % 200 == 0:
+            env.reset()
+        elif i % 10 == 0:
+            env.reset(options=dict(env_idx=torch.nonzero(torch.rand(N, device="cuda", generator=g) < 0.02).flatten()))
+    assert int(bad) == 0 and float(worst) < 1e3, (int(bad), float(worst))
+    env.close()
