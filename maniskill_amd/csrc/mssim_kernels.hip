@@ -866,23 +866,6 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
     }
     if (it == n_iters) break;
     const bool use_bias = it < M.pos_iters;
-    // joint-limit rows (registers)
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      if (lim_side[j] != 0.f && Ainv[j][j] > 1e-12f) {
-        float jv = lim_side[j] * v[j];
-        float b = use_bias ? lim_bpos[j] : lim_bvel[j];
-        float nl = lim_lam[j] - (jv + b) / Ainv[j][j];
-        nl = nl < 0.f ? 0.f : nl;
-        float dl = nl - lim_lam[j];
-        lim_lam[j] = nl;
-        if (dl != 0.f) {
-#pragma unroll T::UNROLL
-          for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += lim_side[j] * Ainv[i][j] * dl; }
-        }
-      }
-    }
     // contact rows: LDS records first, then the global overflow records (both stride 64)
     lam_n = 0.f;
     if (nrows_all > 0) {
@@ -900,6 +883,23 @@ __global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
         if (r + 1 < nrows_all) load_row(pa, 64, A);
         process_row(B, pb, 64, use_bias);
         r++;
+      }
+    }
+    // joint-limit rows (registers), after the contacts of the sweep (see the oracle)
+#pragma unroll T::UNROLL
+    for (int j = 0; j < T::MAXD; j++) {
+      if (j >= n) break;
+      if (lim_side[j] != 0.f && Ainv[j][j] > 1e-12f) {
+        float jv = lim_side[j] * v[j];
+        float b = use_bias ? lim_bpos[j] : lim_bvel[j];
+        float nl = lim_lam[j] - (jv + b) / Ainv[j][j];
+        nl = nl < 0.f ? 0.f : nl;
+        float dl = nl - lim_lam[j];
+        lim_lam[j] = nl;
+        if (dl != 0.f) {
+#pragma unroll T::UNROLL
+          for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += lim_side[j] * Ainv[i][j] * dl; }
+        }
       }
     }
   }

@@ -1404,27 +1404,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (it == n_iters) break;
       PH(17);
       const bool use_bias = it < M.pos_iters;
-      // joint-limit rows, exact sequential Gauss-Seidel semantics, but only rows that change are
-      // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
-      // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
-      {
-        int cursor = 0;
-        const float bl = use_bias ? lim_bpos : lim_bvel;
-        while (true) {
-          const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
-          const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
-          const unsigned long long bal = __ballot(cand);
-          if (bal == 0ull) break;
-          const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
-          const bool act = m16 != 0u;
-          const int j = act ? (__ffs(m16) - 1) : 0;
-          float dl = gbc(nl - lim_lam, j);
-          dl = act ? dl : 0.f;
-          if (act && c == j) lim_lam = nl;
-          v_c = fmaf(L[S16_LIMW + 16 * j + c], dl, v_c);
-          cursor = act ? j + 1 : 16;
-        }
-      }
       PH(18);
       // block scalars of contact k + 1 are read from the LDS table before the dependent chain of contact k
       // (one wave per SIMD: nothing else hides the LDS latency); slot k + 1 always exists in the table
@@ -1487,6 +1466,28 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           if (++k >= max_cglb) break;
           gapply(C, k); gload(k + 3, C);
           if (++k >= max_cglb) break;
+        }
+      }
+      // joint-limit rows, after the contacts of the sweep (an articulation's internal constraints are solved after
+      // its contacts, as in PhysX); exact sequential Gauss-Seidel semantics, but only rows that change are
+      // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
+      // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
+      {
+        int cursor = 0;
+        const float bl = use_bias ? lim_bpos : lim_bvel;
+        while (true) {
+          const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
+          const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
+          const unsigned long long bal = __ballot(cand);
+          if (bal == 0ull) break;
+          const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
+          const bool act = m16 != 0u;
+          const int j = act ? (__ffs(m16) - 1) : 0;
+          float dl = gbc(nl - lim_lam, j);
+          dl = act ? dl : 0.f;
+          if (act && c == j) lim_lam = nl;
+          v_c = fmaf(L[S16_LIMW + 16 * j + c], dl, v_c);
+          cursor = act ? j + 1 : 16;
         }
       }
       PH(20);

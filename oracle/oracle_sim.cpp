@@ -438,6 +438,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     r.lo = 0; r.hi = Real(1e30); r.lam = 0; r.friction_of = -1; r.mu = 0; r.contact = -1; r.dirk = -1;
     rows.push_back(r);
   }
+  const size_t n_limit_rows = rows.size();
   for (size_t ci = 0; ci < contacts.size(); ci++) {
     Contact& c = contacts[ci];
     Vec nrm = c.n;
@@ -489,8 +490,11 @@ void substep(mssim_sim* S, EnvState& E, int e) {
 
   // 5. PGS
   std::vector<Real> v(qds);
+  // one Gauss-Seidel sweep: the contact rows in pair order, then the joint-limit rows (an articulation's internal
+  // constraints are solved after its contacts, as in PhysX: a jammed arm gives way at the contact, not at the limit)
   auto sweep = [&](bool use_bias) {
-    for (size_t ri = 0; ri < rows.size(); ri++) {
+    for (size_t k = 0; k < rows.size(); k++) {
+      const size_t ri = k < rows.size() - n_limit_rows ? k + n_limit_rows : k - (rows.size() - n_limit_rows);
       Row& r = rows[ri];
       if (!(r.diag > Real(1e-12))) continue;
       Real jv = 0;
