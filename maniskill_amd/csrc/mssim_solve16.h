@@ -1404,7 +1404,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (it == n_iters) break;
       PH(17);
       const bool use_bias = it < M.pos_iters;
-      PH(18);
       // block scalars of contact k + 1 are read from the LDS table before the dependent chain of contact k
       // (one wave per SIMD: nothing else hides the LDS latency); slot k + 1 always exists in the table
       float4 ns0 = *reinterpret_cast<const float4*>(L + S16_CS), nsk = *reinterpret_cast<const float4*>(L + S16_CS + 4);
@@ -1468,6 +1467,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           if (++k >= max_cglb) break;
         }
       }
+      PH(20);
       // joint-limit rows, after the contacts of the sweep (an articulation's internal constraints are solved after
       // its contacts, as in PhysX); exact sequential Gauss-Seidel semantics, but only rows that change are
       // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           cursor = act ? j + 1 : 16;
         }
       }
-      PH(20);
+      PH(18);
     }
     if (c == 0) {
 #pragma unroll
