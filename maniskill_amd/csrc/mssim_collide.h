@@ -178,7 +178,7 @@ MS_DEV int clip_poly(float* lds, int src, int n, f3 pn, float pd) {
       const float da = d[i], db = (i == 7 || wrap) ? d[0] : d[(i + 1) & 7];
       if (da <= 0.f && m < 8) out.put(m++, a);
       if (((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) && m < 8) {
-        float t = da * rcp_f(da - db);
+        float t = da * rcp_safe(da - db);
         out.put(m++, a + (b - a) * t);
       }
     }
@@ -437,18 +437,18 @@ MS_DEV void closest_on_triangle(f3 a, f3 b, f3 c, float w[3]) {
   float d3 = dot(ab, bp), d4 = dot(ac, bp);
   if (d3 >= 0.f && d4 <= d3) { w[0] = 0.f; w[1] = 1.f; w[2] = 0.f; return; }
   float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 * rcp_f(d1 - d3); w[0] = 1.f - v; w[1] = v; w[2] = 0.f; return; }
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 * rcp_f(fmaxf(d1 - d3, 1e-30f)); w[0] = 1.f - v; w[1] = v; w[2] = 0.f; return; }
   f3 cp = -c;
   float d5 = dot(ab, cp), d6 = dot(ac, cp);
   if (d6 >= 0.f && d5 <= d6) { w[0] = 0.f; w[1] = 0.f; w[2] = 1.f; return; }
   float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float v = d2 * rcp_f(d2 - d6); w[0] = 1.f - v; w[1] = 0.f; w[2] = v; return; }
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float v = d2 * rcp_f(fmaxf(d2 - d6, 1e-30f)); w[0] = 1.f - v; w[1] = 0.f; w[2] = v; return; }
   float va = d3 * d6 - d5 * d4;
   if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
-    float v = (d4 - d3) * rcp_f((d4 - d3) + (d5 - d6));
+    float v = (d4 - d3) * rcp_f(fmaxf((d4 - d3) + (d5 - d6), 1e-30f));
     w[0] = 0.f; w[1] = 1.f - v; w[2] = v; return;
   }
-  float den = rcp_f(va + vb + vc);
+  float den = rcp_f(fmaxf(va + vb + vc, 1e-30f));
   w[1] = vb * den; w[2] = vc * den; w[0] = 1.f - w[1] - w[2];
 }
 

@@ -21,7 +21,8 @@ MS_DEV f3 cross(f3 a, f3 b) { return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 // single-instruction reciprocal / square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp). `1.f / x`, `a / b` and
 // sqrtf() compile to 10-instruction IEEE / denormal-safe expansions even with
 // -fno-hip-fp32-correctly-rounded-divide-sqrt; none of the quantities here is denormal or needs the last ulp
-MS_DEV float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+MS_DEV float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }  // callers keep |x| out of the denormal range (there the result is +-inf)
+MS_DEV float rcp_safe(float x) { return __builtin_amdgcn_rcpf(fabsf(x) > 1e-30f ? x : copysignf(1e-30f, x)); }  // finite for any finite x
 MS_DEV float sqrt_f(float x) { return __builtin_amdgcn_sqrtf(x); }
 MS_DEV float rsq_f(float x) { return __builtin_amdgcn_rsqf(x); }
 MS_DEV float norm(f3 a) { return sqrt_f(dot(a, a)); }
@@ -32,7 +33,7 @@ MS_DEV f3 clamp_norm(f3 w, float wmax) {
 }
 MS_DEV f3 normalized(f3 a) {
   const float nn = dot(a, a);
-  return nn > 0.f ? a * rsq_f(nn) : f3{1.f, 0.f, 0.f};
+  return nn > 1e-30f ? a * rsq_f(nn) : f3{1.f, 0.f, 0.f};  // (v_rsq_f32 of a denormal is +inf)
 }
 MS_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 // value select. `g ? a : b` on struct lvalues can be lowered to a select of ADDRESSES, which forces
@@ -48,7 +49,7 @@ MS_DEV q4 qmul(q4 a, q4 b) {
 }
 MS_DEV q4 qnormalized(q4 q) {
   const float nn = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-  float s = nn > 0.f ? rsq_f(nn) : 1.f;
+  float s = nn > 1e-30f ? rsq_f(nn) : 1.f;
   return q4{q.w * s, q.x * s, q.y * s, q.z * s};
 }
 MS_DEV q4 qaxis_angle(f3 axis, float angle) {

@@ -1160,7 +1160,9 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
           const f3 v = jcol(j, w);
           G.xx += v.x * v.x; G.yy += v.y * v.y; G.zz += v.z * v.z; G.xy += v.x * v.y; G.xz += v.x * v.z; G.yz += v.y * v.z;
         }
-      const f3 y3 = smulv(sinverse(G), f3{av[0], av[1], av[2]});
+      // (G >= 1e-9 I in exact arithmetic; a determinant lost to cancellation moves nothing rather than everything)
+      const float detG = G.xx * (G.yy * G.zz - G.yz * G.yz) - G.xy * (G.xy * G.zz - G.yz * G.xz) + G.xz * (G.xy * G.yz - G.yy * G.xz);
+      const f3 y3 = detG > 1e-30f ? smulv(sinverse(G), f3{av[0], av[1], av[2]}) : f3{0.f, 0.f, 0.f};
       y[0] = y3.x; y[1] = y3.y; y[2] = y3.z;
     } else {
       // 6 x 6: J J^T + 1e-9 I is symmetric positive definite -> Cholesky without pivoting, two triangular solves

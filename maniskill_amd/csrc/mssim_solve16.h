@@ -287,7 +287,7 @@ MS_DEV void collide_box_box_coop(const shape_t& A, const shape_t& B, float offse
     const int pt = pa + (ea ? 1 : 0);
     if (ea && pa < 8) { scr[3 * pa] = P.x; scr[3 * pa + 1] = P.y; scr[3 * pa + 2] = P.z; }
     if (et && pt < 8) {
-      const float t = da * rcp_f(da - db);
+      const float t = da * rcp_safe(da - db);
       const f3 x = P + (b - P) * t;
       scr[3 * pt] = x.x; scr[3 * pt + 1] = x.y; scr[3 * pt + 2] = x.z;
     }
