@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MSSIM_ABI_VERSION 3
+#define MSSIM_ABI_VERSION 4
 /* Free bodies: the angular velocity a substep starts from, and the one its pose is integrated with, are clamped
  * to this magnitude (rad/s) -- PhysX's default PxRigidDynamic maxAngularVelocity. Without it a thin body knocked
  * into a fast spin (a peg squeezed out of the gripper) feeds the explicitly integrated gyroscopic term until the
@@ -54,6 +54,17 @@ extern "C" {
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
 #define MSSIM_MAX_HULL_VERTS 64 /* per convex hull (PhysX GPU-compatible hull limit)      */
+/* Contact patches. A compound body (the Panda finger: 4 boxes, panda_v3.urdf:244-283; the box with a hole: 4 boxes,
+ * envs/tasks/tabletop/peg_insertion_side.py:150-181) touching another compound body yields one <= 4-point manifold per
+ * SHAPE pair -- 16 shape pairs x 4 points for one finger inside the hole. Before the solver the manifolds of one BODY
+ * pair whose normals lie within a cone of each other are merged into a patch and the patch is cut to its 4 most
+ * significant points (deepest, farthest from it, largest area on either side -- the rule the box-box manifold uses):
+ * the per-body-pair persistent-manifold cap of PCM-style narrowphases (types.py:44 enable_pcm). A manifold joins the
+ * patch of the FIRST manifold (pair order) of its body pair whose normal is within MSSIM_PATCH_COS of its own. */
+#define MSSIM_PATCH_COS 0.985f     /* cos of the patch cone half angle (~10 degrees)          */
+#define MSSIM_MAX_CONTACTS 48      /* contact points per env fed to the solver, after the patch reduction */
+#define MSSIM_MAX_HITS 64          /* shape pairs per env that survive the cull               */
+#define MSSIM_MAX_RAW_POINTS 128   /* manifold points per env before the patch reduction      */
 
 /* joint types of the moving articulation bodies (fixed joints are folded at compile time) */
 enum { MSSIM_JOINT_REVOLUTE = 0, MSSIM_JOINT_PRISMATIC = 1 };
@@ -250,7 +261,9 @@ int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
  *   target[j] = (flags[j] & 1 ? qpos[j] : 0) + a        (column[j] < 0: joint left untouched)
  *   flags[j] & 8: a is the joint's velocity drive target instead (pd_joint_vel.py:31-33); flags[j] & 4: the joint
  *   is driven by the end-effector block (set_ee_action_map)
- * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host. */
+ * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host.
+ * apply_action / step_action / defer_step_action fail (non-zero, last_error) when `action_dim` does not cover every
+ * mapped column (the reference asserts action.shape == (num_envs, action_dim), base_controller.py:120-133). */
 int MSSIM_FN(set_action_map)(mssim_handle h, const int32_t* column, const float* low, const float* high, const int32_t* flags);
 /* End-effector block of the action map, for `pd_ee_delta_pos` (rows = 3) and `pd_ee_delta_pose` (rows = 6)
  * (agents/controllers/pd_ee_pose.py:79-96, 197-210 with Kinematics.compute_ik's delta solver,
@@ -286,6 +299,8 @@ typedef struct mssim_pick_task {
   int32_t* elapsed_out;       /* ... and the new value copied here (info["elapsed_steps"], sapien_env.py:739)      */
   uint8_t* truncated_out;     /* optional device [N]: new elapsed_steps >= time_limit (TimeLimitWrapper, utils/registration.py:160-168) */
   int32_t time_limit;
+  uint8_t* terminated_out;    /* optional device [N]: `terminated` of BaseEnv.step = a COPY of success (envs/sapien_env.py:954-964: callers
+                                 such as ManiSkillVectorEnv(ignore_terminations=True) overwrite it in place) */
 } mssim_pick_task;
 /* obs [N][2*n_dof+24] f32 (qpos, qvel, is_grasped, tcp_pose7, goal_pos3, obj_pose7, tcp_to_obj3,
  * obj_to_goal3), reward [N] f32, flags [N][4] u8 = success, is_obj_placed, is_robot_static, is_grasped */
@@ -303,6 +318,8 @@ typedef struct mssim_push_task {
   int32_t* elapsed_out;
   uint8_t* truncated_out;     /* optional device [N]: new elapsed_steps >= time_limit (TimeLimitWrapper, utils/registration.py:160-168) */
   int32_t time_limit;
+  uint8_t* terminated_out;    /* optional device [N]: `terminated` of BaseEnv.step = a COPY of success (envs/sapien_env.py:954-964: callers
+                                 such as ManiSkillVectorEnv(ignore_terminations=True) overwrite it in place) */
 } mssim_push_task;
 int MSSIM_FN(task_push_outputs)(mssim_handle h, const mssim_push_task* task, float* obs, float* reward, uint8_t* flags, void* stream);
 
@@ -323,6 +340,8 @@ typedef struct mssim_peg_task {
   int32_t* elapsed_out;
   uint8_t* truncated_out;     /* optional device [N]: new elapsed_steps >= time_limit (TimeLimitWrapper, utils/registration.py:160-168) */
   int32_t time_limit;
+  uint8_t* terminated_out;    /* optional device [N]: `terminated` of BaseEnv.step = a COPY of success (envs/sapien_env.py:954-964: callers
+                                 such as ManiSkillVectorEnv(ignore_terminations=True) overwrite it in place) */
 } mssim_peg_task;
 int MSSIM_FN(task_peg_outputs)(mssim_handle h, const mssim_peg_task* task, float* obs, float* reward, uint8_t* flags, float* head_at_hole, void* stream);
 

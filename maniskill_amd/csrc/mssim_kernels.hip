@@ -8,12 +8,10 @@
 // wave-instruction. Constant model tables are env-shared and wave-uniform (scalar loads, L2
 // resident).
 //
-// Kernels per substep (all launched on the caller's stream, no host sync):
-//   k_narrow  grid (N/64, n_pair)  one (env, shape pair) per lane; blockIdx.y = pair so the pair's
-//                                  shape types / hull vertices are wave-uniform
-//   k_solve   grid (N/64)          one env per lane: FK, CRBA + RNEA, implicit PD (dense LDL^T),
-//                                  row assembly, projected Gauss-Seidel, integration, FK(new)
-// `Topo` selects compile-time (Panda: 9-DoF tree fully unrolled into VGPRs) or run-time topology.
+// One kernel advances the simulation: k_solve16 (mssim_solve16.h), 16 lanes per env, a whole control step per
+// launch (narrowphase, dynamics, solver, integration, FK for every substep; optionally the action map at its head and
+// the copy-out + task epilogue at its tail). All launches go to the caller's stream, no host sync.
+// `Topo` (FK-only kernel) selects compile-time (Panda: 9-DoF tree unrolled into VGPRs) or run-time topology.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -21,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -30,7 +29,7 @@
 #define MAXC 48  // contact points per env fed to the solver (overflow is reported, never silent)
 
 struct DevModel {
-  int n_dof, n_tendon, n_link, n_free, n_kin, n_shape, n_pair, n_words;
+  int n_dof, n_tendon, n_link, n_free, n_kin, n_shape, n_pair;
   const int *dof_parent, *dof_type, *body_gravity, *tendon_dof, *link_body, *free_gravity;
   const unsigned* dof_anc;  // bitmask of strict ancestors of each dof
   const float *dof_frame, *dof_axis, *dof_limit, *dof_drive, *dof_armature, *body_inertial, *tendon_param, *link_frame;
@@ -54,15 +53,11 @@ struct DevState {
   float *free_s, *free_force, *kin;             // [n_free*13][N], [n_free*3][N], [n_kin*7][N]
   float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
   float* bodyaux;                               // [n_dof*6][N] world joint axis (3) + joint anchor (3)
-  int* pair_cnt;                                // [n_pair][N]
-  float* pair_data;                             // [n_pair*19][N]: n(3), 4 x (x(3), sep)
+  int* pair_cnt;                                // [n_pair][N] contact points of the pair in the last substep (after the patch reduction)
   float* pair_imp;                              // [n_pair*3][N]
-  unsigned* hit_mask;                           // [n_words][N]
   int* hit_list;                                // [1 + MAXC][N]: count, then the pairs in contact after the last fused step
-  float* rows;                                  // [3*MAXC * RF][N] solver scratch
+  float* rows;                                  // [N][S16_ROWS_GLB][32] J | W rows of the contacts beyond the register / LDS resident ones
   int* overflow;                                // [N]
-  int row_slots;                                // LDS slots per lane for packed solver rows
-  int glb_slots;                                // overflow slots per lane in `rows` (wave-contiguous: [block][slot][64])
   // action of this control step, mapped to drive targets at the head of the fused launch (mssim_step_action);
   // null = targets were set before the launch
   const float* act;                             // [N][act_dim]
@@ -210,7 +205,6 @@ __global__ __launch_bounds__(64) void k_fk(DevModel M, DevState S) {
   f3 aw[T::MAXD], anchor[T::MAXD];
   fk_bodies(topo, M, root, q, bp, aw, anchor);
   write_kinematics(topo, M, S, e, root, qd, bp, aw, anchor);
-  for (int w = 0; w < M.n_words; w++) S.hit_mask[(size_t)w * N + e] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -248,708 +242,6 @@ MS_DEV shape_t make_shape(const DevModel& M, const DevState& S, int s, int e) {
   sh.verts = M.hull_verts + 3 * M.shape_hull[2 * s];
   sh.nverts = M.shape_hull[2 * s + 1];
   return sh;
-}
-
-MS_DEV float point_box_dist2(const shape_t& box, f3 pt) {
-  f3 d = mtmulv(box.rot, pt - box.c);
-  f3 q = f3{fmaxf(fabsf(d.x) - box.p0, 0.f), fmaxf(fabsf(d.y) - box.p1, 0.f), fmaxf(fabsf(d.z) - box.p2, 0.f)};
-  return dot(q, q);
-}
-
-__global__ __launch_bounds__(64) void k_narrow(DevModel M, DevState S) {
-  __shared__ float lds[CLIP_SLOTS * 64];
-  const int N = S.N;
-  const int p = blockIdx.y;
-  int e = xcd_chunk(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  if (e >= N) return;
-  const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
-  const int ta = M.shape_type[sa], tb = M.shape_type[sb];
-  // cheap cull first: bounding-sphere centres straight from the body poses (centre offsets are
-  // precomputed in the body frame); the full shape frames are only built for survivors
-  const pose_t PA = body_pose_of(M, S, M.shape_kind[sa], M.shape_index[sa], e);
-  const pose_t PB = body_pose_of(M, S, M.shape_kind[sb], M.shape_index[sb], e);
-  float ra = M.shape_bound[4 * sa + 3], rb = M.shape_bound[4 * sb + 3];
-  f3 cla = f3{M.shape_center[3 * sa], M.shape_center[3 * sa + 1], M.shape_center[3 * sa + 2]};
-  f3 clb = f3{M.shape_center[3 * sb], M.shape_center[3 * sb + 1], M.shape_center[3 * sb + 2]};
-  {
-    const int la = M.shape_env_slot[sa], lb = M.shape_env_slot[sb];
-    if (la >= 0) { const float* b = M.env_shape_bound + (size_t)(4 * la) * N + e; cla = f3{b[0], b[(size_t)N], b[2 * (size_t)N]}; ra = b[3 * (size_t)N]; }
-    if (lb >= 0) { const float* b = M.env_shape_bound + (size_t)(4 * lb) * N + e; clb = f3{b[0], b[(size_t)N], b[2 * (size_t)N]}; rb = b[3 * (size_t)N]; }
-  }
-  const f3 cb = PB.p + qrot(PB.q, clb);
-  f3 ca = f3{0, 0, 0};
-  bool cull;
-  shape_t A, B;
-  if (ta == SH_PLANE) {
-    A = make_shape(M, S, sa, e);
-    cull = dot(mcol(A.rot, 0), cb - A.c) > rb + M.contact_offset;
-  } else {
-    ca = PA.p + qrot(PA.q, cla);
-    f3 d = cb - ca;
-    float rr = ra + rb + M.contact_offset;
-    cull = dot(d, d) > rr * rr;
-  }
-  if (!cull) {
-    if (ta != SH_PLANE) A = make_shape(M, S, sa, e);
-    B = make_shape(M, S, sb, e);
-    // tighter, still conservative: the other shape's bounding sphere against an oriented box
-    if (ta == SH_BOX) { float rr = rb + M.contact_offset; cull = point_box_dist2(A, cb) > rr * rr; }
-    if (!cull && tb == SH_BOX && ta != SH_PLANE) { float rr = ra + M.contact_offset; cull = point_box_dist2(B, ca) > rr * rr; }
-  }
-  manifold_t m;
-  m.count = 0;
-  if (!cull) {
-    if (A.type == SH_PLANE) collide_plane(A, B, M.contact_offset, m);
-    else if (A.type == SH_BOX && B.type == SH_BOX) collide_box_box(A, B, M.contact_offset, m, lds + threadIdx.x);
-    else collide_mpr(A, B, M.contact_offset, m);
-  }
-  S.pair_cnt[(size_t)p * N + e] = m.count;
-  if (m.count > 0) {
-    float* o = S.pair_data + (size_t)(19 * p) * N + e;
-    o[0] = m.n.x; o[(size_t)N] = m.n.y; o[2 * (size_t)N] = m.n.z;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (k < m.count) {
-        o[(size_t)(3 + 4 * k) * N] = m.x[k].x; o[(size_t)(4 + 4 * k) * N] = m.x[k].y; o[(size_t)(5 + 4 * k) * N] = m.x[k].z;
-        o[(size_t)(6 + 4 * k) * N] = m.sep[k] - M.rest_offset;
-      }
-    atomicOr(&S.hit_mask[(size_t)(p >> 5) * N + e], 1u << (p & 31));
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-lane free-body data kept in LDS as [item][64]: 16 items per body
-#define FB_V 0   // linear velocity (3)
-#define FB_W 3   // angular velocity (3)
-#define FB_MINV 6
-#define FB_IINV 7  // 6
-#define FB_COM 13  // 3
-#define FB_ITEMS 16
-
-template <class T>
-__global__ __launch_bounds__(64) void k_solve(DevModel M, DevState S) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* fb = smem;                                              // [n_free*FB_ITEMS][64]
-  float* rowbuf = smem + (size_t)M.n_free * FB_ITEMS * 64 + threadIdx.x;  // [row_slots][64], this lane's column
-  const int row_slots = S.row_slots;
-  const int N = S.N;
-  const int lane = threadIdx.x;
-  int e = blockIdx.x * 64 + lane;
-  if (e >= N) return;
-  T topo(M);
-  const int n = topo.n();
-  const float dt = M.dt;
-  const f3 g = f3{M.gx, M.gy, M.gz};
-  float* fbl = fb + lane;
-#define FB(b, item) fbl[(size_t)((b) * FB_ITEMS + (item)) * 64]
-
-  // ---- state
-  pose_t root = pose_soa(S.root, 0, N, e);
-  const f3 O = root.p;
-  float q[T::MAXD], qd[T::MAXD];
-#pragma unroll T::UNROLL
-  for (int j = 0; j < T::MAXD; j++) {
-    if (j >= n) break;
-    q[j] = SOA(S.q, j);
-    qd[j] = SOA(S.qd, j);
-  }
-  // ---- 1. FK
-  pose_t bp[T::MAXD];
-  f3 aw[T::MAXD], anchor[T::MAXD];
-  fk_bodies(topo, M, root, q, bp, aw, anchor);
-
-  // ---- 3. joint-space dynamics: RNEA bias + CRBA
-  float Mq[T::MAXD][T::MAXD];
-  float bias[T::MAXD];
-  {
-    si10 Ic[T::MAXD];
-    sv6 V[T::MAXD], Ab[T::MAXD];
-    sf6 F[T::MAXD];
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      const float* in = M.body_inertial + 10 * j;
-      m3 R = qmat(bp[j].q);
-      s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
-      f3 c = bp[j].p + mmulv(R, f3{in[1], in[2], in[3]}) - O;
-      float m = in[0], cc = dot(c, c);
-      Iw.xx += m * (cc - c.x * c.x); Iw.yy += m * (cc - c.y * c.y); Iw.zz += m * (cc - c.z * c.z);
-      Iw.xy -= m * c.x * c.y; Iw.xz -= m * c.x * c.z; Iw.yz -= m * c.y * c.z;
-      si10 I = si10{m, c * m, Iw};
-      Ic[j] = I;
-      int p = topo.parent(j);
-      sv6 Vp = sv6{f3{0, 0, 0}, f3{0, 0, 0}}, Ap = Vp;
-      if (T::STATIC) {
-#pragma unroll
-        for (int k = 0; k < T::MAXD; k++)
-          if (k == p) { Vp = V[k]; Ap = Ab[k]; }
-      } else if (p >= 0) {
-        Vp = V[p]; Ap = Ab[p];
-      }
-      sv6 Sj = subspace(topo, j, aw[j], anchor[j] - O);
-      V[j] = sv6{Vp.w + Sj.w * qd[j], Vp.v + Sj.v * qd[j]};
-      sv6 cr = crossm(V[j], Sj);
-      Ab[j] = sv6{Ap.w + cr.w * qd[j], Ap.v + cr.v * qd[j]};
-      sf6 f1 = imul(I, Ab[j]);
-      sf6 f2 = crossf(V[j], imul(I, V[j]));
-      F[j] = sf6{f1.n + f2.n, f1.f + f2.f};
-      if (M.body_gravity[j]) {
-        F[j].f -= g * m;
-        F[j].n -= cross(I.h, g);
-      }
-    }
-#pragma unroll T::UNROLL
-    for (int jj = 0; jj < T::MAXD; jj++) {
-      int j = T::STATIC ? (T::MAXD - 1 - jj) : (n - 1 - jj);
-      if (j < 0) break;
-      sv6 Sj = subspace(topo, j, aw[j], anchor[j] - O);
-      bias[j] = sdot(Sj, F[j]);
-      int p = topo.parent(j);
-      if (T::STATIC) {
-#pragma unroll
-        for (int k = 0; k < T::MAXD; k++)
-          if (k == p) {
-            F[k].n += F[j].n; F[k].f += F[j].f;
-            Ic[k].m += Ic[j].m; Ic[k].h += Ic[j].h; Ic[k].I = sadd(Ic[k].I, Ic[j].I);
-          }
-      } else if (p >= 0) {
-        F[p].n += F[j].n; F[p].f += F[j].f;
-        Ic[p].m += Ic[j].m; Ic[p].h += Ic[j].h; Ic[p].I = sadd(Ic[p].I, Ic[j].I);
-      }
-    }
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      sv6 Sj = subspace(topo, j, aw[j], anchor[j] - O);
-      sf6 Fc = imul(Ic[j], Sj);
-      unsigned am = topo.anc(j);
-#pragma unroll T::UNROLL
-      for (int i = 0; i < T::MAXD; i++) {
-        if (i >= n) break;
-        if (i == j) Mq[j][j] = sdot(Sj, Fc) + M.dof_armature[j];
-        else if (i < j) {
-          float v = 0.f;
-          if ((am >> i) & 1u) v = sdot(subspace(topo, i, aw[i], anchor[i] - O), Fc);
-          Mq[j][i] = v;
-          Mq[i][j] = v;
-        }
-      }
-    }
-  }
-  // ---- implicit PD drives + tendons
-  float A[T::MAXD][T::MAXD], rhs[T::MAXD], rhs0[T::MAXD], tau0[T::MAXD], Dj[T::MAXD], kp[T::MAXD], kd[T::MAXD], qt[T::MAXD], qdt[T::MAXD];
-#pragma unroll T::UNROLL
-  for (int j = 0; j < T::MAXD; j++) {
-    if (j >= n) break;
-    qt[j] = SOA(S.qt, j);
-    qdt[j] = SOA(S.qdt, j);
-    kp[j] = M.dof_drive[4 * j];
-    kd[j] = M.dof_drive[4 * j + 1];
-    if ((int)M.dof_drive[4 * j + 3] == MSSIM_DRIVE_ACCELERATION) { kp[j] *= Mq[j][j]; kd[j] *= Mq[j][j]; }
-    tau0[j] = kp[j] * (qt[j] - q[j]) + kd[j] * qdt[j];
-    Dj[j] = dt * kd[j] + dt * dt * kp[j];
-#pragma unroll T::UNROLL
-    for (int i = 0; i < T::MAXD; i++) {
-      if (i >= n) break;
-      A[j][i] = Mq[j][i] + (i == j ? Dj[j] : 0.f);
-    }
-    rhs[j] = 0.f;
-  }
-  for (int t = 0; t < M.n_tendon; t++) {
-    int a = M.tendon_dof[2 * t], b = M.tendon_dof[2 * t + 1];
-    const float* tp = M.tendon_param + 5 * t;
-    float ca = tp[0], cb = tp[1], qa = 0.f, qb = 0.f;
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      if (j == a) qa = q[j];
-      if (j == b) qb = q[j];
-    }
-    float c = ca * qa + cb * qb - tp[2];
-    float k = tp[3], w = dt * dt * k + dt * tp[4];
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      float cj = j == a ? ca : (j == b ? cb : 0.f);
-      rhs[j] -= k * c * cj;  // tendon torque, folded into rhs below
-#pragma unroll T::UNROLL
-      for (int i = 0; i < T::MAXD; i++) {
-        if (i >= n) break;
-        float ci = i == a ? ca : (i == b ? cb : 0.f);
-        A[j][i] += w * cj * ci;
-      }
-    }
-  }
-#pragma unroll T::UNROLL
-  for (int j = 0; j < T::MAXD; j++) {
-    if (j >= n) break;
-    float mv = 0.f;
-#pragma unroll T::UNROLL
-    for (int k = 0; k < T::MAXD; k++) {
-      if (k >= n) break;
-      mv += Mq[j][k] * qd[k];
-    }
-    rhs0[j] = mv + dt * (rhs[j] - bias[j] + SOA(S.qf, j));  // without the drive torque (see k_solve16: no cancellation on saturation)
-    rhs[j] = rhs0[j] + dt * tau0[j];
-  }
-  // LDL^T, solve, force-limit active set, explicit inverse
-  float L[T::MAXD][T::MAXD], v[T::MAXD], Ainv[T::MAXD][T::MAXD];
-  auto factor = [&]() __attribute__((always_inline)) {
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      float d = A[j][j];
-#pragma unroll T::UNROLL
-      for (int k = 0; k < T::MAXD; k++) {
-        if (k >= j) break;
-        d -= L[j][k] * L[j][k] * L[k][k];
-      }
-      L[j][j] = d;
-      float id = 1.f / d;
-#pragma unroll T::UNROLL
-      for (int i = 0; i < T::MAXD; i++) {
-        if (i >= n) break;
-        if (i > j) {
-          float t = A[i][j];
-#pragma unroll T::UNROLL
-          for (int k = 0; k < T::MAXD; k++) {
-            if (k >= j) break;
-            t -= L[i][k] * L[j][k] * L[k][k];
-          }
-          L[i][j] = t * id;
-        }
-      }
-    }
-  };
-  auto solve = [&](float* b) __attribute__((always_inline)) {
-#pragma unroll T::UNROLL
-    for (int i = 0; i < T::MAXD; i++) {
-      if (i >= n) break;
-#pragma unroll T::UNROLL
-      for (int k = 0; k < T::MAXD; k++) {
-        if (k >= i) break;
-        b[i] -= L[i][k] * b[k];
-      }
-    }
-#pragma unroll T::UNROLL
-    for (int i = 0; i < T::MAXD; i++) {
-      if (i >= n) break;
-      b[i] /= L[i][i];
-    }
-#pragma unroll T::UNROLL
-    for (int ii = 0; ii < T::MAXD; ii++) {
-      int i = T::STATIC ? (T::MAXD - 1 - ii) : (n - 1 - ii);
-      if (i < 0) break;
-#pragma unroll T::UNROLL
-      for (int k = 0; k < T::MAXD; k++) {
-        if (k >= n) break;
-        if (k > i) b[i] -= L[k][i] * b[k];
-      }
-    }
-  };
-  if (n > 0) {
-    factor();
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; v[j] = rhs[j]; }
-    solve(v);
-    bool any = false;
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      float fmax = M.dof_drive[4 * j + 2];
-      float td = kp[j] * (qt[j] - q[j] - dt * v[j]) + kd[j] * (qdt[j] - v[j]);
-      if (fmax < 1e30f && fabsf(td) > fmax) {
-        float sat = td > 0.f ? fmax : -fmax;
-        A[j][j] -= Dj[j];
-        rhs[j] = rhs0[j] + dt * sat;
-        any = true;
-      }
-    }
-    if (any) {
-      factor();
-#pragma unroll T::UNROLL
-      for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; v[j] = rhs[j]; }
-      solve(v);
-    }
-#pragma unroll T::UNROLL
-    for (int c = 0; c < T::MAXD; c++) {
-      if (c >= n) break;
-      float ecol[T::MAXD];
-#pragma unroll T::UNROLL
-      for (int r = 0; r < T::MAXD; r++) { if (r >= n) break; ecol[r] = r == c ? 1.f : 0.f; }
-      solve(ecol);
-#pragma unroll T::UNROLL
-      for (int r = 0; r < T::MAXD; r++) { if (r >= n) break; Ainv[r][c] = ecol[r]; }
-    }
-  }
-  // ---- free bodies: unconstrained velocities into LDS
-  for (int b = 0; b < M.n_free; b++) {
-    float in[10];
-    free_inertial_of(M, N, b, e, in);
-    pose_t P = pose_soa(S.free_s, 13 * b, N, e);
-    m3 R = qmat(P.q);
-    s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
-    s3 Ii = sinverse(Iw);
-    float minv = 1.f / in[0];
-    f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
-    f3 v0 = f3{SOA(S.free_s, 13 * b + 7), SOA(S.free_s, 13 * b + 8), SOA(S.free_s, 13 * b + 9)};
-    f3 w0 = clamp_norm(f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)}, MSSIM_MAX_ANGULAR_VELOCITY);
-    f3 acc = f3{SOA(S.free_force, 3 * b), SOA(S.free_force, 3 * b + 1), SOA(S.free_force, 3 * b + 2)} * minv;
-    if (M.free_gravity[b]) acc += g;
-    f3 vv = v0 + acc * dt;
-    f3 ww = w0 - smulv(Ii, cross(w0, smulv(Iw, w0))) * dt;
-    float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
-    vv = vv * (ld > 0.f ? ld : 0.f);
-    ww = ww * (ad > 0.f ? ad : 0.f);
-    FB(b, FB_V) = vv.x; FB(b, FB_V + 1) = vv.y; FB(b, FB_V + 2) = vv.z;
-    FB(b, FB_W) = ww.x; FB(b, FB_W + 1) = ww.y; FB(b, FB_W + 2) = ww.z;
-    FB(b, FB_MINV) = minv;
-    FB(b, FB_IINV) = Ii.xx; FB(b, FB_IINV + 1) = Ii.yy; FB(b, FB_IINV + 2) = Ii.zz;
-    FB(b, FB_IINV + 3) = Ii.xy; FB(b, FB_IINV + 4) = Ii.xz; FB(b, FB_IINV + 5) = Ii.yz;
-    FB(b, FB_COM) = com.x; FB(b, FB_COM + 1) = com.y; FB(b, FB_COM + 2) = com.z;
-  }
-
-  // ---- 4a. joint-limit rows (registers)
-  float lim_side[T::MAXD], lim_bpos[T::MAXD], lim_bvel[T::MAXD], lim_lam[T::MAXD];
-#pragma unroll T::UNROLL
-  for (int j = 0; j < T::MAXD; j++) {
-    if (j >= n) break;
-    float lo = M.dof_limit[2 * j], hi = M.dof_limit[2 * j + 1];
-    bool has = lo > -1e30f || hi < 1e30f;
-    float dlo = q[j] - lo, dhi = hi - q[j];
-    float C = dlo <= dhi ? dlo : dhi;
-    lim_side[j] = has ? (dlo <= dhi ? 1.f : -1.f) : 0.f;
-    lim_bpos[j] = C >= 0.f ? C / dt : fmaxf(M.erp * C / dt, -M.max_depen);
-    lim_bvel[j] = C >= 0.f ? C / dt : 0.f;
-    lim_lam[j] = 0.f;
-  }
-
-  // ---- 4b. contact rows: packed variable-length records, first in LDS (per-lane column,
-  //      [slot][64 lanes] => conflict-free), overflow in the global scratch with the same layout.
-  //      record = header | inv_diag | bias | mu | lambda | [Ja(n) Wa(n)] | [Jl Jw Ww](9) x free sides
-  //      header bits: 0 has_art, 1 friction, 2 valid, 3 sep>=0, 4-7 free0+1, 8-11 free1+1, 12-27 pair, 28-29 dir
-  int nrows_lds = 0, nrows_glb = 0;
-  {
-    int ncontacts = 0;
-    int off_lds = 0, off_glb = 0;
-    bool lds_full = false;
-    for (int w = 0; w < M.n_words; w++) {
-      unsigned bits = S.hit_mask[(size_t)w * N + e];
-      while (bits) {
-        int bit = __ffs(bits) - 1;
-        bits &= bits - 1;
-        int p = w * 32 + bit;
-        int cnt = S.pair_cnt[(size_t)p * N + e];
-        const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
-        SOA(S.pair_imp, 3 * p) = 0.f; SOA(S.pair_imp, 3 * p + 1) = 0.f; SOA(S.pair_imp, 3 * p + 2) = 0.f;
-        int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
-        int kinds[2] = {M.shape_kind[sa], M.shape_kind[sb]};
-        int idxs[2] = {M.shape_index[sa], M.shape_index[sb]};
-        float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
-        f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
-        f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
-        f3 t2 = cross(nrm, t1);
-        bool hasart = (kinds[0] == MSSIM_BODY_ART && idxs[0] >= 0) || (kinds[1] == MSSIM_BODY_ART && idxs[1] >= 0);
-        int nfree = (kinds[0] == MSSIM_BODY_FREE ? 1 : 0) + (kinds[1] == MSSIM_BODY_FREE ? 1 : 0);
-        const int rlen = 5 + (hasart ? 2 * n : 0) + 9 * nfree;
-        for (int k = 0; k < cnt; k++) {
-          if (ncontacts >= MAXC) { S.overflow[e] = 1; break; }
-          ncontacts++;
-          f3 x = f3{pd[(size_t)(3 + 4 * k) * N], pd[(size_t)(4 + 4 * k) * N], pd[(size_t)(5 + 4 * k) * N]};
-          float sep = pd[(size_t)(6 + 4 * k) * N];
-          for (int dk = 0; dk < 3; dk++) {
-            f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
-            if (!lds_full && off_lds + rlen > row_slots) lds_full = true;
-            float* row;
-            size_t rs;
-            if (!lds_full) { row = rowbuf + (size_t)off_lds * 64; rs = 64; off_lds += rlen; nrows_lds++; }
-            else { row = S.rows + ((size_t)blockIdx.x * S.glb_slots + off_glb) * 64 + threadIdx.x; rs = 64; off_glb += rlen; nrows_glb++; }
-#define RW(f) row[(size_t)(f) * rs]
-            float Ja[T::MAXD];
-#pragma unroll T::UNROLL
-            for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; Ja[i] = 0.f; }
-            float diag = 0.f;
-            int hdr = (hasart ? 1 : 0) | (dk > 0 ? 2 : 0) | (sep >= 0.f ? 8 : 0) | (p << 12) | (dk << 28);
-            int fpos = 5 + (hasart ? 2 * n : 0);
-            int fside = 0;
-            for (int s = 0; s < 2; s++) {
-              float sign = s == 0 ? 1.f : -1.f;
-              if (kinds[s] == MSSIM_BODY_ART && idxs[s] >= 0) {
-                unsigned am = M.dof_anc[idxs[s]] | (1u << idxs[s]);
-#pragma unroll T::UNROLL
-                for (int i = 0; i < T::MAXD; i++) {
-                  if (i >= n) break;
-                  if ((am >> i) & 1u) {
-                    f3 col = topo.revolute(i) ? cross(aw[i], x - anchor[i]) : aw[i];
-                    Ja[i] += sign * dot(d, col);
-                  }
-                }
-              } else if (kinds[s] == MSSIM_BODY_FREE) {
-                int b = idxs[s];
-                f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)};
-                s3 Ii = s3{FB(b, FB_IINV), FB(b, FB_IINV + 1), FB(b, FB_IINV + 2), FB(b, FB_IINV + 3), FB(b, FB_IINV + 4), FB(b, FB_IINV + 5)};
-                float minv = FB(b, FB_MINV);
-                f3 Jl = d * sign, Jw = cross(x - com, d) * sign;
-                f3 Ww = smulv(Ii, Jw);
-                RW(fpos) = Jl.x; RW(fpos + 1) = Jl.y; RW(fpos + 2) = Jl.z;
-                RW(fpos + 3) = Jw.x; RW(fpos + 4) = Jw.y; RW(fpos + 5) = Jw.z;
-                RW(fpos + 6) = Ww.x; RW(fpos + 7) = Ww.y; RW(fpos + 8) = Ww.z;
-                diag += minv + dot(Jw, Ww);  // |Jl| = 1
-                hdr |= (b + 1) << (4 + 4 * fside);
-                fpos += 9;
-                fside++;
-              }
-            }
-            if (hasart) {
-#pragma unroll T::UNROLL
-              for (int i = 0; i < T::MAXD; i++) {
-                if (i >= n) break;
-                float wv = 0.f;
-#pragma unroll T::UNROLL
-                for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; wv += Ainv[i][j] * Ja[j]; }
-                RW(5 + i) = Ja[i];
-                RW(5 + n + i) = wv;
-                diag += Ja[i] * wv;
-              }
-            }
-            if (diag > 1e-12f) hdr |= 4;
-            RW(0) = __int_as_float(hdr);
-            RW(1) = diag > 1e-12f ? 1.f / diag : 0.f;
-            RW(2) = dk == 0 ? (sep >= 0.f ? sep / dt : fmaxf(M.erp * sep / dt, -M.max_depen)) : 0.f;
-            RW(3) = mu;
-            RW(4) = 0.f;
-#undef RW
-          }
-        }
-      }
-    }
-  }
-
-  // ---- 5. projected Gauss-Seidel.
-  // The sweep is one long dependent chain per env (Gauss-Seidel), so per-row latency is what
-  // matters: (a) the twists of the (up to two) free bodies a row touches are cached in VGPRs and
-  // only written back to LDS when a row needs a different body; (b) row records are software
-  // prefetched one row ahead into a second register set so LDS / L2 latency overlaps the
-  // arithmetic of the current row.
-  struct RowRegs {
-    int hdr;
-    float invd, bias, mu, lam;
-    float f0[9], f1[9];
-    float ja[T::MAXD], wa[T::MAXD];
-  };
-  int cb0 = -1, cb1 = -1;  // cached free-body ids per side
-  f3 cv0 = f3{0, 0, 0}, cw0 = cv0, cv1 = cv0, cw1 = cv0;
-  float cm0 = 0.f, cm1 = 0.f;
-  auto wb0 = [&]() __attribute__((always_inline)) {
-    if (cb0 >= 0) {
-      FB(cb0, FB_V) = cv0.x; FB(cb0, FB_V + 1) = cv0.y; FB(cb0, FB_V + 2) = cv0.z;
-      FB(cb0, FB_W) = cw0.x; FB(cb0, FB_W + 1) = cw0.y; FB(cb0, FB_W + 2) = cw0.z;
-    }
-  };
-  auto wb1 = [&]() __attribute__((always_inline)) {
-    if (cb1 >= 0) {
-      FB(cb1, FB_V) = cv1.x; FB(cb1, FB_V + 1) = cv1.y; FB(cb1, FB_V + 2) = cv1.z;
-      FB(cb1, FB_W) = cw1.x; FB(cb1, FB_W + 1) = cw1.y; FB(cb1, FB_W + 2) = cw1.z;
-    }
-  };
-  auto need0 = [&](int b) __attribute__((always_inline)) {
-    if (cb0 == b) return;
-    wb0();
-    if (cb1 == b) { wb1(); cb1 = -1; }
-    cb0 = b;
-    cv0 = f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)};
-    cw0 = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
-    cm0 = FB(b, FB_MINV);
-  };
-  auto need1 = [&](int b) __attribute__((always_inline)) {
-    if (cb1 == b) return;
-    wb1();
-    if (cb0 == b) { wb0(); cb0 = -1; }
-    cb1 = b;
-    cv1 = f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)};
-    cw1 = f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)};
-    cm1 = FB(b, FB_MINV);
-  };
-  auto row_len = [&](int hdr) __attribute__((always_inline)) -> int {
-    return 5 + ((hdr & 1) ? 2 * n : 0) + (((hdr >> 4) & 15) ? 9 : 0) + (((hdr >> 8) & 15) ? 9 : 0);
-  };
-  auto load_row = [&](const float* row, size_t rs, RowRegs& R) __attribute__((always_inline)) {
-    R.hdr = __float_as_int(row[0]);
-    R.invd = row[rs]; R.bias = row[2 * rs]; R.mu = row[3 * rs]; R.lam = row[4 * rs];
-    const bool hasart = R.hdr & 1;
-    const int fbase = 5 + (hasart ? 2 * n : 0);
-    if (hasart) {
-#pragma unroll T::UNROLL
-      for (int i = 0; i < T::MAXD; i++) {
-        if (i >= n) break;
-        R.ja[i] = row[(size_t)(5 + i) * rs];
-        R.wa[i] = row[(size_t)(5 + n + i) * rs];
-      }
-    }
-    if ((R.hdr >> 4) & 15) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) R.f0[k] = row[(size_t)(fbase + k) * rs];
-    }
-    if ((R.hdr >> 8) & 15) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) R.f1[k] = row[(size_t)(fbase + 9 + k) * rs];
-    }
-  };
-  float lam_n = 0.f;
-  auto process_row = [&](const RowRegs& R, float* row, size_t rs, bool use_bias) __attribute__((always_inline)) {
-    const int hdr = R.hdr;
-    const bool hasart = hdr & 1, fric = hdr & 2;
-    const int b0 = ((hdr >> 4) & 15) - 1, b1 = ((hdr >> 8) & 15) - 1;
-    if (!fric) lam_n = R.lam;
-    if (!(hdr & 4)) return;
-    float jv = 0.f;
-    if (hasart) {
-#pragma unroll T::UNROLL
-      for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; jv += R.ja[i] * v[i]; }
-    }
-    if (b0 >= 0) {
-      need0(b0);
-      jv += R.f0[0] * cv0.x + R.f0[1] * cv0.y + R.f0[2] * cv0.z + R.f0[3] * cw0.x + R.f0[4] * cw0.y + R.f0[5] * cw0.z;
-    }
-    if (b1 >= 0) {
-      need1(b1);
-      jv += R.f1[0] * cv1.x + R.f1[1] * cv1.y + R.f1[2] * cv1.z + R.f1[3] * cw1.x + R.f1[4] * cw1.y + R.f1[5] * cw1.z;
-    }
-    float lo = 0.f, hi = 1e30f;
-    if (fric) { hi = R.mu * lam_n; lo = -hi; }
-    float b = use_bias ? R.bias : ((hdr & 8) ? R.bias : 0.f);
-    float nl = R.lam - (jv + b) * R.invd;
-    nl = nl < lo ? lo : (nl > hi ? hi : nl);
-    float dl = nl - R.lam;
-    if (!fric) lam_n = nl;
-    if (dl != 0.f) {
-      row[4 * rs] = nl;
-      if (hasart) {
-#pragma unroll T::UNROLL
-        for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += R.wa[i] * dl; }
-      }
-      if (b0 >= 0) {
-        float mdl = cm0 * dl;
-        cv0.x += R.f0[0] * mdl; cv0.y += R.f0[1] * mdl; cv0.z += R.f0[2] * mdl;
-        cw0.x += R.f0[6] * dl; cw0.y += R.f0[7] * dl; cw0.z += R.f0[8] * dl;
-      }
-      if (b1 >= 0) {
-        float mdl = cm1 * dl;
-        cv1.x += R.f1[0] * mdl; cv1.y += R.f1[1] * mdl; cv1.z += R.f1[2] * mdl;
-        cw1.x += R.f1[6] * dl; cw1.y += R.f1[7] * dl; cw1.z += R.f1[8] * dl;
-      }
-    }
-  };
-  float* const glb_rows = S.rows + (size_t)blockIdx.x * S.glb_slots * 64 + threadIdx.x;  // wave-contiguous chunk
-  const int nrows_all = nrows_lds + nrows_glb;
-  float vpos[T::MAXD];
-  const int n_iters = M.pos_iters + M.vel_iters;
-  for (int it = 0; it <= n_iters; it++) {
-    if (it == M.pos_iters) {
-      // end of the position iterations: integrate poses with the biased velocities
-      wb0(); wb1();
-#pragma unroll T::UNROLL
-      for (int j = 0; j < T::MAXD; j++) { if (j >= n) break; vpos[j] = v[j]; }
-      for (int b = 0; b < M.n_free; b++) {
-        float in[10];
-        free_inertial_of(M, N, b, e, in);
-        f3 com = f3{FB(b, FB_COM), FB(b, FB_COM + 1), FB(b, FB_COM + 2)} + f3{FB(b, FB_V), FB(b, FB_V + 1), FB(b, FB_V + 2)} * dt;
-        f3 w = clamp_norm(f3{FB(b, FB_W), FB(b, FB_W + 1), FB(b, FB_W + 2)}, MSSIM_MAX_ANGULAR_VELOCITY);
-        q4 qq = q4{SOA(S.free_s, 13 * b + 3), SOA(S.free_s, 13 * b + 4), SOA(S.free_s, 13 * b + 5), SOA(S.free_s, 13 * b + 6)};
-        qq = qnormalized(qq);
-        q4 dq = qmul(q4{0.f, w.x, w.y, w.z}, qq);
-        qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
-        f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
-        SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
-        SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
-      }
-    }
-    if (it == n_iters) break;
-    const bool use_bias = it < M.pos_iters;
-    // contact rows: LDS records first, then the global overflow records (both stride 64)
-    lam_n = 0.f;
-    if (nrows_all > 0) {
-      RowRegs A, B;
-      float* pa = nrows_lds > 0 ? rowbuf : glb_rows;
-      load_row(pa, 64, A);
-      int r = 0;
-      while (r < nrows_all) {
-        float* pb = (r + 1 == nrows_lds) ? glb_rows : pa + (size_t)row_len(A.hdr) * 64;
-        if (r + 1 < nrows_all) load_row(pb, 64, B);
-        process_row(A, pa, 64, use_bias);
-        r++;
-        if (r >= nrows_all) break;
-        pa = (r + 1 == nrows_lds) ? glb_rows : pb + (size_t)row_len(B.hdr) * 64;
-        if (r + 1 < nrows_all) load_row(pa, 64, A);
-        process_row(B, pb, 64, use_bias);
-        r++;
-      }
-    }
-    // joint-limit rows (registers), after the contacts of the sweep (see the oracle)
-#pragma unroll T::UNROLL
-    for (int j = 0; j < T::MAXD; j++) {
-      if (j >= n) break;
-      if (lim_side[j] != 0.f && Ainv[j][j] > 1e-12f) {
-        float jv = lim_side[j] * v[j];
-        float b = use_bias ? lim_bpos[j] : lim_bvel[j];
-        float nl = lim_lam[j] - (jv + b) / Ainv[j][j];
-        nl = nl < 0.f ? 0.f : nl;
-        float dl = nl - lim_lam[j];
-        lim_lam[j] = nl;
-        if (dl != 0.f) {
-#pragma unroll T::UNROLL
-          for (int i = 0; i < T::MAXD; i++) { if (i >= n) break; v[i] += lim_side[j] * Ainv[i][j] * dl; }
-        }
-      }
-    }
-  }
-  wb0(); wb1();
-
-  // ---- contact impulses per pair: lambda * direction, direction rebuilt from the pair normal
-  auto accumulate = [&](float* row, size_t rs) __attribute__((always_inline)) -> int {
-    const int hdr = __float_as_int(row[0]);
-    const int b0 = ((hdr >> 4) & 15) - 1, b1 = ((hdr >> 8) & 15) - 1;
-    const int rlen = 5 + ((hdr & 1) ? 2 * n : 0) + (b0 >= 0 ? 9 : 0) + (b1 >= 0 ? 9 : 0);
-    const int p = (hdr >> 12) & 0xFFFF, dk = (hdr >> 28) & 3;
-    const float lam = row[4 * rs];
-    const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
-    f3 nrm = f3{pd[0], pd[(size_t)N], pd[2 * (size_t)N]};
-    f3 d = nrm;
-    if (dk > 0) {
-      f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
-      d = dk == 1 ? t1 : cross(nrm, t1);
-    }
-    SOA(S.pair_imp, 3 * p) += d.x * lam;
-    SOA(S.pair_imp, 3 * p + 1) += d.y * lam;
-    SOA(S.pair_imp, 3 * p + 2) += d.z * lam;
-    return rlen;
-  };
-  {
-    int off = 0;
-    for (int r = 0; r < nrows_lds; r++) off += accumulate(rowbuf + (size_t)off * 64, 64);
-    off = 0;
-    for (int r = 0; r < nrows_glb; r++) off += accumulate(S.rows + ((size_t)blockIdx.x * S.glb_slots + off) * 64 + threadIdx.x, 64);
-  }
-
-  // ---- 6. integrate + FK at the new state
-#pragma unroll T::UNROLL
-  for (int j = 0; j < T::MAXD; j++) {
-    if (j >= n) break;
-    const float vj = fminf(fmaxf(v[j], -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
-    SOA(S.qacc, j) = (vj - qd[j]) / dt;
-    q[j] += dt * fminf(fmaxf(vpos[j], -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
-    SOA(S.q, j) = q[j];
-    SOA(S.qd, j) = vj;
-  }
-  for (int b = 0; b < M.n_free; b++) {
-    SOA(S.free_s, 13 * b + 7) = FB(b, FB_V); SOA(S.free_s, 13 * b + 8) = FB(b, FB_V + 1); SOA(S.free_s, 13 * b + 9) = FB(b, FB_V + 2);
-    SOA(S.free_s, 13 * b + 10) = FB(b, FB_W); SOA(S.free_s, 13 * b + 11) = FB(b, FB_W + 1); SOA(S.free_s, 13 * b + 12) = FB(b, FB_W + 2);
-    SOA(S.free_force, 3 * b) = 0.f; SOA(S.free_force, 3 * b + 1) = 0.f; SOA(S.free_force, 3 * b + 2) = 0.f;
-  }
-  fk_bodies(topo, M, root, q, bp, aw, anchor);
-  write_kinematics(topo, M, S, e, root, v, bp, aw, anchor);
-  for (int w = 0; w < M.n_words; w++) S.hit_mask[(size_t)w * N + e] = 0u;
-#undef FB
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1283,6 +575,7 @@ MS_DEV void task_pick_env(const DevModel& M, const DevState& S, const mssim_buff
   reward[e] = r * T.reward_scale;
   uint8_t* f = flags + 4 * (size_t)e;
   f[0] = success; f[1] = placed; f[2] = is_static; f[3] = grasped;
+  if (T.terminated_out) T.terminated_out[e] = success;
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; if (T.truncated_out) T.truncated_out[e] = v >= T.time_limit ? 1 : 0; }
 }
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
@@ -1323,6 +616,7 @@ MS_DEV void task_push_env(const DevModel& M, const DevState& S, const mssim_buff
   if (success) r = 3.f;
   reward[e] = r * T.reward_scale;
   flags[e] = success;
+  if (T.terminated_out) T.terminated_out[e] = success;
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; if (T.truncated_out) T.truncated_out[e] = v >= T.time_limit ? 1 : 0; }
 }
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
@@ -1415,6 +709,7 @@ MS_DEV void task_peg_env(const DevModel& M, const DevState& S, const mssim_buffe
   reward[e] = r * T.reward_scale;
   flags[e] = success;
   head_out[3 * (size_t)e] = hah.x; head_out[3 * (size_t)e + 1] = hah.y; head_out[3 * (size_t)e + 2] = hah.z;
+  if (T.terminated_out) T.terminated_out[e] = success;
   if (T.elapsed_steps) { const int v = T.elapsed_steps[e] + 1; T.elapsed_steps[e] = v; if (T.elapsed_out) T.elapsed_out[e] = v; if (T.truncated_out) T.truncated_out[e] = v >= T.time_limit ? 1 : 0; }
 }
 // FETCH: the launch first performs mssim_fetch(what) for its envs (fetch_in_block; 256 threads per block)
@@ -1487,13 +782,10 @@ struct mssim_sim {
   std::vector<int> query_n;
   std::vector<int> query_kind;
   std::string err;
-  int row_fields = 0;
   // profiling (bench roofline block): event pairs recorded on the launch stream
   int* d_act_col = nullptr; float* d_act_lo = nullptr; float* d_act_hi = nullptr; int* d_act_flags = nullptr;
   EeMap ee{-1, 0, 3, 0.f, 0.f, 0.f, 0};
-  unsigned solve_lds_bytes = 0;
-  bool coop = false;   // use k_solve16
-  bool fused = false;  // k_solve16<true>: one launch per control step, narrowphase in the kernel
+  int act_max_col = -1;  // highest action column the joint map reads
   bool profiling = false;
   std::vector<hipEvent_t> ev[2];  // [kernel] start/stop interleaved
   size_t ev_used[2] = {0, 0};
@@ -1551,6 +843,14 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   if (!d || !out || num_envs <= 0) { g_create_error = "bad arguments"; return 1; }
   if (d->abi_version != MSSIM_ABI_VERSION) { g_create_error = "ABI version mismatch"; return 2; }
   if (d->n_dof > MSSIM_MAX_DOF || d->n_free > MSSIM_MAX_FREE) { g_create_error = "model exceeds MSSIM_MAX_DOF / MSSIM_MAX_FREE"; return 3; }
+  // the control-step kernel keeps an env on 16 lanes (one velocity component each) and its scene in fixed LDS tables
+  if (d->n_dof + 6 * d->n_free > S16_LANES || d->n_free > S16_MAX_FREE || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE || d->n_pair > 56 * 16) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "model exceeds the control-step kernel's tables: %d velocity components (max %d), %d free bodies (max %d), %d kinematic bodies (max %d), "
+             "%d shapes (max %d), %d candidate pairs (max %d)", d->n_dof + 6 * d->n_free, S16_LANES, d->n_free, S16_MAX_FREE, d->n_kin, S16_MAX_KIN, d->n_shape, S16_MAX_SHAPE, d->n_pair, 56 * 16);
+    g_create_error = msg;
+    return 9;
+  }
   for (int j = 0; j < d->n_dof; j++)
     if (d->dof_parent[j] >= j) { g_create_error = "dof_parent must be topologically sorted"; return 4; }
   for (int s = 0; s < d->n_shape; s++)
@@ -1566,7 +866,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) S->n_cu = ncu; }
   DevModel& M = S->M;
   M.n_dof = d->n_dof; M.n_tendon = d->n_tendon; M.n_link = d->n_link; M.n_free = d->n_free; M.n_kin = d->n_kin;
-  M.n_shape = d->n_shape; M.n_pair = d->n_pair; M.n_words = (d->n_pair + 31) / 32;
+  M.n_shape = d->n_shape; M.n_pair = d->n_pair;
   const int n = d->n_dof, ns = d->n_shape;
   std::vector<unsigned> anc(n > 0 ? n : 1, 0u);
   for (int j = 0; j < n; j++)
@@ -1699,7 +999,6 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   S->panda = (n == 9);
   for (int j = 0; j < n && S->panda; j++)
     if (d->dof_parent[j] != kPandaParent[j] || d->dof_type[j] != kPandaType[j]) S->panda = false;
-  S->row_fields = 5 + 2 * (n > 0 ? n : 0) + 18;  // longest packed row
   DevState& D = S->S;
   D.N = num_envs;
   const size_t N = (size_t)num_envs;
@@ -1707,37 +1006,11 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   AL(root, 7) AL(q, n) AL(qd, n) AL(qt, n) AL(qdt, n) AL(qf, n) AL(qacc, n)
   AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin)
   AL(bodypose, 7 * n) AL(bodyvel, 6 * n) AL(bodyaux, 6 * n)
-  AL(pair_cnt, d->n_pair) AL(pair_data, 19 * d->n_pair) AL(pair_imp, 3 * d->n_pair) AL(hit_mask, M.n_words)
-  D.glb_slots = 3 * MAXC * S->row_fields;
-  {
-    size_t v1_floats = (size_t)D.glb_slots * 64 * (((size_t)num_envs + 63) / 64);
-    size_t v2_floats = (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN;
-    if ((rc = dalloc(S, v1_floats > v2_floats ? v1_floats : v2_floats, &D.rows))) { mssim_destroy(S); return rc; }
-  }
-  // cooperative 16-lanes-per-env kernel when every velocity component fits one DPP row
-  S->coop = (n + 6 * d->n_free <= S16_LANES);
-  // whole control step in one launch (in-kernel narrowphase) when the scene fits the LDS tables
-  S->fused = S->coop && d->n_free <= S16_MAX_FREE && d->n_kin <= S16_MAX_KIN && ns <= S16_MAX_SHAPE && d->n_pair <= 56 * 16 && d->n_pair > 0;
-  if (const char* ev = getenv("MSSIM_SOLVER")) {
-    if (!strcmp(ev, "lane")) S->coop = S->fused = false;
-    if (!strcmp(ev, "split")) S->fused = false;
-  }
+  AL(pair_cnt, d->n_pair) AL(pair_imp, 3 * d->n_pair)
+  if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN, &D.rows))) { mssim_destroy(S); return rc; }
   AL(overflow, 1)
   AL(hit_list, 1 + MAXC)
 #undef AL
-  // LDS budget of the solve kernel: one 64-lane block per CU when the grid is small enough to give
-  // every block its own CU (N <= 256*64 envs), otherwise 64 KB so two blocks share a CU
-  {
-    size_t fb_bytes = (size_t)d->n_free * FB_ITEMS * 64 * sizeof(float);
-    size_t budget = ((size_t)num_envs + 63) / 64 <= 256 ? 144 * 1024 : 64 * 1024;
-    size_t slots = budget > fb_bytes ? (budget - fb_bytes) / (64 * sizeof(float)) : 0;
-    D.row_slots = (int)slots;
-    S->solve_lds_bytes = (unsigned)(fb_bytes + slots * 64 * sizeof(float));
-    if (S->solve_lds_bytes > 64 * 1024) {
-      (void)hipFuncSetAttribute((const void*)k_solve<TopoPanda>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->solve_lds_bytes);
-      (void)hipFuncSetAttribute((const void*)k_solve<TopoDyn>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->solve_lds_bytes);
-    }
-  }
   // identity quaternions
   std::vector<float> ones(N, 1.0f);
   hipMemcpy(D.root + 3 * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
@@ -1827,30 +1100,15 @@ static inline void prof_mark(mssim_handle h, int k, hipStream_t st) {
   (void)hipEventRecord(h->ev[k][h->ev_used[k]++], st);
 }
 
+extern "C++" {
+template <int TASK>
+static void launch_control_step(mssim_handle h, const DevState& S, int n_substeps, hipStream_t st);
+}
 int mssim_step(mssim_handle h, int32_t n_substeps, void* stream) {
   flush_deferred(h, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   if (h->dirty) { launch_fk(h, st); h->dirty = false; }
-  if (h->fused && n_substeps > 0) {
-    prof_mark(h, 0, st);
-    if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<true, 9>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, (int)n_substeps);
-    else hipLaunchKernelGGL((k_solve16<true, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, (int)n_substeps);
-    prof_mark(h, 0, st);
-    HIPCHK(h, hipGetLastError());
-    return 0;
-  }
-  for (int s = 0; s < n_substeps; s++) {
-    if (h->M.n_pair > 0) {
-      prof_mark(h, 1, st);
-      hipLaunchKernelGGL(k_narrow, dim3(pad8((h->N + 63) / 64), h->M.n_pair), dim3(64), 0, st, h->M, h->S);
-      prof_mark(h, 1, st);
-    }
-    prof_mark(h, 0, st);
-    if (h->coop) hipLaunchKernelGGL((k_solve16<false, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, h->S, 1);
-    else if (h->panda) hipLaunchKernelGGL(k_solve<TopoPanda>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
-    else hipLaunchKernelGGL(k_solve<TopoDyn>, dim3((h->N + 63) / 64), dim3(64), h->solve_lds_bytes, st, h->M, h->S);
-    prof_mark(h, 0, st);
-  }
+  if (n_substeps > 0) launch_control_step<0>(h, h->S, (int)n_substeps, st);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1860,8 +1118,8 @@ extern "C++" {
 template <int TASK>
 static void launch_control_step(mssim_handle h, const DevState& S, int n_substeps, hipStream_t st) {
   prof_mark(h, 0, st);
-  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<true, 9, TASK>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
-  else hipLaunchKernelGGL((k_solve16<true, 0, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
+  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, TASK>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
+  else hipLaunchKernelGGL((k_solve16<0, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
   prof_mark(h, 0, st);
 }
 }  // extern "C++"
@@ -1872,8 +1130,18 @@ static DevState state_with_action(mssim_handle h, const float* action, int actio
   S.act_qpos = h->buf.art_qpos; S.act_target = h->buf.art_target_qpos; S.act_target_vel = h->buf.art_target_qvel;
   return S;
 }
+// every column the maps read must exist: the kernels index action[env * action_dim + column] unchecked
+static int check_action_dim(mssim_handle h, int32_t action_dim) {
+  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  const int need = std::max(h->act_max_col + 1, h->ee.link >= 0 ? h->ee.col0 + h->ee.rows : 0);
+  if (action_dim < need) {
+    h->err = "action has " + std::to_string(action_dim) + " columns, the action map reads " + std::to_string(need);
+    return 2;
+  }
+  return 0;
+}
 static int step_action_now(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, hipStream_t st) {
-  if (!(h->fused && n_substeps > 0) || h->ee.link >= 0) {  // per-substep kernels / end-effector block: apply_action, then step
+  if (n_substeps <= 0 || h->ee.link >= 0) {  // end-effector block: apply_action, then step
     hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, st, h->M, h->S, h->buf, action, action_dim,
                        h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags, h->ee);
     return mssim_step(h, n_substeps, st);
@@ -1894,13 +1162,13 @@ static void flush_deferred(mssim_handle h, hipStream_t st) {
 }
 
 int mssim_step_action(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream) {
-  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  if (int rc = check_action_dim(h, action_dim)) return rc;
   flush_deferred(h, (hipStream_t)stream);
   return step_action_now(h, action, action_dim, n_substeps, (hipStream_t)stream);
 }
 
 int mssim_defer_step_action(mssim_handle h, const float* action, int32_t action_dim, int32_t n_substeps, void* stream) {
-  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  if (int rc = check_action_dim(h, action_dim)) return rc;
   flush_deferred(h, (hipStream_t)stream);
   h->deferred_action = action; h->deferred_adim = action_dim; h->deferred_nsub = n_substeps; h->deferred_stream = (hipStream_t)stream;
   return 0;
@@ -1960,6 +1228,8 @@ int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low
   HIPCHK(h, hipMemcpy(h->d_act_lo, low, sizeof(float) * h->M.n_dof, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_act_hi, high, sizeof(float) * h->M.n_dof, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_act_flags, flags, sizeof(int) * h->M.n_dof, hipMemcpyHostToDevice));
+  h->act_max_col = -1;
+  for (int j = 0; j < h->M.n_dof; j++) h->act_max_col = column[j] > h->act_max_col ? column[j] : h->act_max_col;
   return 0;
 }
 
@@ -1972,7 +1242,7 @@ int mssim_set_ee_action_map(mssim_handle h, int32_t link_index, int32_t column0,
 
 int mssim_apply_action(mssim_handle h, const float* action, int32_t action_dim, void* stream) {
   flush_deferred(h, (hipStream_t)stream);
-  if (!h->d_act_col) { h->err = "set_action_map has not been called"; return 1; }
+  if (int rc = check_action_dim(h, action_dim)) return rc;
   hipLaunchKernelGGL(k_apply_action, env_grid(h->N, 256), dim3(256), 0, (hipStream_t)stream, h->M, h->S, h->buf, action, action_dim,
                      h->d_act_col, h->d_act_lo, h->d_act_hi, h->d_act_flags, h->ee);
   HIPCHK(h, hipGetLastError());
@@ -2001,11 +1271,11 @@ static int finger_pair_list(mssim_handle h, int obj_row, int f1_row, int f2_row)
 }
 
 // A deferred step_action + deferred fetch + this epilogue = one launch of the control-step kernel (Panda
-// models: the task tail is compiled into k_solve16<true, 9, TASK>). Returns false if that does not apply.
+// models: the task tail is compiled into k_solve16<9, TASK>). Returns false if that does not apply.
 extern "C++" {
 template <int TASK>
 static bool control_step_with_task(mssim_handle h, DevState& S, hipStream_t st) {
-  if (!(h->deferred_action && h->deferred_fetch && h->fused && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0)) return false;
+  if (!(h->deferred_action && h->deferred_fetch && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0)) return false;
   // The tail runs at the kernel's one wave per SIMD: worth it while all blocks are resident at once (4 per CU) and
   // the launch is latency-bound anyway; with more blocks the separate, fully occupied copy-out + epilogue launch
   // is cheaper than a tail per block.

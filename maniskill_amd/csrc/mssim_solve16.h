@@ -58,19 +58,29 @@
 #define S16_ENV_FLOATS (S16_REC + S16_REC_LEN * MAXC)   // 2448 floats = 9792 B per env (== 16 mod 32 banks)
 #define S16_ROWLEN 32
 #define S16_ROWS_GLB (3 * (MAXC - S16_REGC - S16_LDSC))  // global scratch rows per env (x S16_ROWLEN floats)
-// narrowphase scratch (FUSED), overlays the union below the contact records
+// narrowphase scratch, overlays the union below the contact records
 #define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 pad
 #define S16_NP_SHP (S16_U)        // [28][20] world shape table
 #define S16_NP_HIT (S16_U + 560)  // [64] surviving pairs: pair | sa << 16 | sb << 24
-#define S16_NP_CNT (S16_U + 624)  // [64] manifold sizes
-#define S16_NP_SCR (S16_U + 688)  // [56][16] box-box clip scratch of the group's 16 lanes | pair table during the cull (<= 896 pairs)
-#define S16_MAX_BBC 16             // box-box pairs per wave (and per env) worked on by 16-lane groups
-#define S16_NP_BL (S16_NP_SCR)          // [16] hit indices of this env's box-box pairs       } inside the clip scratch,
-#define S16_NP_BS (S16_NP_SCR + 16)     // [16][20] their staged manifolds                    } which the one-lane-
-#define S16_NP_BSCR (S16_NP_SCR + 336)  // [24] polygon scatter / gather words of the group   } per-pair path owns otherwise
-#define S16_NP_ML (S16_U + 1584)  // [14] hit indices of this env's MPR (generic convex) pairs
-#define S16_NP_MS (S16_U + 1598)  // [14][7] their contacts n(3) x(3) sep, staged until the record offsets are known
-#define S16_MAX_MPR 14
+#define S16_NP_CNT (S16_U + 624)  // [64] manifold sizes (raw, before the patch reduction)
+#define S16_NP_OFF (S16_U + 688)  // [64] first point of each manifold in the point pool
+// [896]: pair table during the cull (<= 896 pairs) | [56][16] box-box clip scratch of the one-lane-per-pair path |
+// afterwards the staged manifolds: normals, point pool, patch bookkeeping
+#define S16_NP_SCR (S16_U + 752)
+#define S16_NP_HN (S16_NP_SCR)            // [64][3] manifold normals
+#define S16_NP_POOL (S16_NP_SCR + 192)    // [MSSIM_MAX_RAW_POINTS][4] x y z sep, in allocation order (16-byte aligned)
+#define S16_NP_BSCR (S16_NP_SCR + 704)    // [24] polygon scatter / gather words of the group (cooperative box-box)
+#define S16_NP_KEEP (S16_NP_SCR + 728)    // [64] patch anchor << 4 | mask of the manifold's points that survive
+#define S16_NP_KEY (S16_NP_SCR + 792)     // [64] body pair of the manifold
+#define S16_NP_ALLOC (S16_NP_SCR + 856)   // [1] points handed out from the pool
+#define S16_NP_BOUT (S16_NP_SCR + 860)    // [20] manifold of the group's current cooperative box-box pair
+#define S16_NP_ML (S16_U + 1648)  // [16 bytes] hit indices of this env's MPR (generic convex) pairs
+#define S16_NP_BL (S16_U + 1652)  // [64 bytes] hit indices of this env's box-box pairs
+#define S16_MAX_BBC 16            // box-box pairs per wave up to which they are worked on by 16-lane groups
+#define S16_MAX_MPR 16
+static_assert(S16_NP_BOUT + 20 <= S16_NP_SCR + 896, "narrowphase staging exceeds the scratch area");
+static_assert(S16_NP_BL + 16 <= S16_REC, "narrowphase lists run into the contact records");
+static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
@@ -449,8 +459,9 @@ struct SupCoop16 {
 // TASK > 0 (with FUSED): the launch ends with the copy-out (mssim_fetch) of its envs and the evaluate / obs /
 // reward epilogue of a task -- 1 PickCube, 2 PushCube, 3 PegInsertionSide -- so that a whole control step
 // (action map, substeps, copy-out, epilogue) is one launch.
-template <bool FUSED, int NDOF = 0, int TASK = 0>
+template <int NDOF = 0, int TASK = 0>
 __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S, int n_sub) {
+  constexpr bool FUSED = true;  // (the per-substep variant fed by a separate narrowphase kernel is gone)
   __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   const int N = S.N;
   const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -471,7 +482,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   const int fb_id = freel ? fc / 6 : 0;
   const int fk = freel ? fc % 6 : 0;  // 0..2 linear xyz, 3..5 angular xyz
   const int fbase = n + 6 * fb_id;
-  if (!FUSED) n_sub = 1;
 
   PH_INIT
   // ---------------------------------------------------------------- carried state (loaded once)
@@ -693,12 +703,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       __syncthreads();
       if (__any(hit_over) && hit_over && live) S.overflow[e] = 1;
       PH(23);
-      // ---- manifolds, part 1: generic convex pairs (MPR). A pair is worked on by one 16-lane group
-      // (hull scans shared by its lanes); the MPR pairs of all 4 envs form one task list that the 4
-      // groups take round-robin, so an env with many such pairs does not serialise on its own group.
+      // ---- classification: generic convex pairs (MPR) and box-box pairs of this env (byte lists of hit indices)
       int nml = 0;  // MPR pairs of this env
       int nbl = 0;  // box-box pairs of this env
       {
+        unsigned char* const ml = reinterpret_cast<unsigned char*>(L + S16_NP_ML);
+        unsigned char* const bl = reinterpret_cast<unsigned char*>(L + S16_NP_BL);
         bool over = false;
         for (int base = 0; base < nh; base += 16) {
           const int idx = base + c;
@@ -709,94 +719,49 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             const int tb = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]) & 7u);
             is_bb = ta == SH_BOX && tb == SH_BOX;
             is_mpr = !(ta == SH_PLANE || is_bb);
+            reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = 0;
           }
           const unsigned m16 = (unsigned)(__ballot(is_mpr) >> (16 * g)) & 0xFFFFu;
           const int rank = nml + __popc(m16 & ((1u << c) - 1u));
           if (is_mpr) {
-            if (rank < S16_MAX_MPR) reinterpret_cast<int*>(L)[S16_NP_ML + rank] = idx;
-            else { over = true; reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = 0; }
+            if (rank < S16_MAX_MPR) ml[rank] = (unsigned char)idx;
+            else over = true;
           }
           nml += __popc(m16);
           const unsigned b16 = (unsigned)(__ballot(is_bb) >> (16 * g)) & 0xFFFFu;
-          const int brank = nbl + __popc(b16 & ((1u << c) - 1u));
-          if (is_bb && brank < S16_MAX_BBC) reinterpret_cast<int*>(L)[S16_NP_BL + brank] = idx;
+          if (is_bb) bl[nbl + __popc(b16 & ((1u << c) - 1u))] = (unsigned char)idx;
           nbl += __popc(b16);
         }
         if (__any(over) && over && live) S.overflow[e] = 1;
         nml = nml < S16_MAX_MPR ? nml : S16_MAX_MPR;
       }
-      __syncthreads();
-      {
-        int mcum[S16_ENVS_PER_BLOCK + 1];
-        mcum[0] = 0;
+      // wave totals: all hits, MPR tasks, box-box tasks
+      int cum[S16_ENVS_PER_BLOCK + 1], mcum[S16_ENVS_PER_BLOCK + 1], bcum[S16_ENVS_PER_BLOCK + 1];
+      cum[0] = mcum[0] = bcum[0] = 0;
 #pragma unroll
-        for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) mcum[j + 1] = mcum[j] + __shfl(nml, 16 * j);
-        const int TM = mcum[S16_ENVS_PER_BLOCK];
-        PH_ADD(14, (TM + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK);
-        for (int t = g; t < TM; t += S16_ENVS_PER_BLOCK) {
-          int ge = 0;
-#pragma unroll
-          for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= mcum[j] ? 1 : 0;
-          const int k = t - mcum[ge];
-          float* Lg = sm + ge * S16_ENV_FLOATS;
-          const int idx = reinterpret_cast<const int*>(Lg)[S16_NP_ML + k];
-          const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
-          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
-          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
-          SupCoop16 sup;
-          sup.c = c;
-          SupCoop16::load_one(sup.va, A, c);
-          SupCoop16::load_one(sup.vb, B, c);
-          manifold_t m;
-          collide_mpr_t(A, B, M.contact_offset, m, sup);
-          if (c == 0) {
-            reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
-            float* o = Lg + S16_NP_MS + 7 * k;
-            o[0] = m.n.x; o[1] = m.n.y; o[2] = m.n.z; o[3] = m.x[0].x; o[4] = m.x[0].y; o[5] = m.x[0].z; o[6] = m.sep[0];
-          }
-        }
+      for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) {
+        cum[j + 1] = cum[j] + __shfl(nh, 16 * j);
+        mcum[j + 1] = mcum[j] + __shfl(nml, 16 * j);
+        bcum[j + 1] = bcum[j] + __shfl(nbl, 16 * j);
       }
+      const int T = cum[S16_ENVS_PER_BLOCK], TM = mcum[S16_ENVS_PER_BLOCK], TB = bcum[S16_ENVS_PER_BLOCK];
+      // Box-box pairs: with few of them in the wave (the usual case: cube on table, peg on table) one lane per pair
+      // leaves the wave almost empty for ~3400 instructions, so the 4 groups take them round-robin, 16 lanes per
+      // pair (stage C). Many of them (fingers on the table: 8 per env): one lane per pair (stage A), whose clip
+      // scratch is this area -- only possible while all tasks of the wave fit one round.
+      const bool bb_lane = TB > S16_MAX_BBC && T <= 64;  // wave-uniform
+      bool pool_over = false;
       __syncthreads();
-      PH(25);
-      // ---- manifolds, part 2a: box-box pairs. With few of them in the wave (the usual case: cube on table,
-      // peg on table) one lane per pair leaves the wave almost empty for ~3400 instructions, so the 4 groups
-      // take the wave's box-box pairs round-robin, 16 lanes per pair; results are staged like the MPR
-      // contacts. Many box-box pairs: one lane per pair in part 2b.
-      bool bb_coop;
-      {
-        int bcum[S16_ENVS_PER_BLOCK + 1];
-        bcum[0] = 0;
-#pragma unroll
-        for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) bcum[j + 1] = bcum[j] + __shfl(nbl, 16 * j);
-        const int TB = bcum[S16_ENVS_PER_BLOCK];
-        bb_coop = TB <= S16_MAX_BBC;  // wave-uniform (and no env's list was cut)
-        if (bb_coop) {
-          for (int t = g; t < TB; t += S16_ENVS_PER_BLOCK) {
-            int ge = 0;
-#pragma unroll
-            for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= bcum[j] ? 1 : 0;
-            const int k = t - bcum[ge];
-            float* Lg = sm + ge * S16_ENV_FLOATS;
-            const int idx = reinterpret_cast<const int*>(Lg)[S16_NP_BL + k];
-            const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
-            const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
-            const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
-            float* out = Lg + S16_NP_BS + 20 * k;
-            collide_box_box_coop(A, B, M.contact_offset, L + S16_NP_BSCR, out, c, g);
-            if (c == 0) reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = __float_as_int(out[0]);
-          }
-        }
-      }
-      __syncthreads();
-      PH(13);
-      // ---- manifolds, part 2b: plane (and, without part 2a, box-box) pairs, all such (env, pair) tasks of
-      // the wave spread over the 64 lanes
-      int cum[S16_ENVS_PER_BLOCK + 1];
-      cum[0] = 0;
-#pragma unroll
-      for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) cum[j + 1] = cum[j] + __shfl(nh, 16 * j);
-      const int T = cum[S16_ENVS_PER_BLOCK];
+      PH_ADD(14, (TM + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK);
       PH_ADD(26, T);
+      // a manifold goes to the staging tables of its env: normal, size, `cnt` points from the pool
+      auto pool_alloc = [&](float* Lg, int cnt) __attribute__((always_inline)) -> int {
+        int off = atomicAdd(reinterpret_cast<int*>(Lg + S16_NP_ALLOC), cnt);
+        if (off + cnt > MSSIM_MAX_RAW_POINTS) { pool_over = true; off = -1; }
+        return off;
+      };
+      // ---- stage A: plane pairs (and the box-box pairs when bb_lane), all such (env, pair) tasks of the wave
+      // spread over the 64 lanes
       for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + (int)threadIdx.x;
         const bool has = t < T;
@@ -807,135 +772,223 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         float* Lg = sm + ge * S16_ENV_FLOATS;
         manifold_t m;
         manifold_clear(m);
-        int pk = 0;
+        bool mine = false;
         if (has) {
-          pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+          const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
           const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
           PH_ADD(27, __popcll(__ballot(A.type == SH_PLANE)));
           PH_ADD(28, __popcll(__ballot(A.type == SH_BOX && B.type == SH_BOX)));
           PH(10);
-          const bool is_plane = A.type == SH_PLANE, is_bb = !bb_coop && A.type == SH_BOX && B.type == SH_BOX;
+          const bool is_plane = A.type == SH_PLANE, is_bb = bb_lane && A.type == SH_BOX && B.type == SH_BOX;
           if (is_plane) collide_plane(A, B, M.contact_offset, m);
           PH(11);
           if (is_bb) collide_box_box<16>(A, B, M.contact_offset, m, sm + g * S16_ENV_FLOATS + S16_NP_SCR + c);
           PH(12);
-          if (is_plane || is_bb) reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
+          mine = is_plane || is_bb;
+        }
+        __syncthreads();  // the clip scratch is dead: the staging tables take its place
+        if (t0 == 0) {
+          if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
+          __syncthreads();
+        }
+        if (mine && m.count > 0) {
+          const int off = pool_alloc(Lg, m.count);
+          if (off >= 0) {
+            reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = m.count;
+            reinterpret_cast<int*>(Lg)[S16_NP_OFF + idx] = off;
+            float* hn = Lg + S16_NP_HN + 3 * idx;
+            hn[0] = m.n.x; hn[1] = m.n.y; hn[2] = m.n.z;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (k < m.count) *reinterpret_cast<float4*>(Lg + S16_NP_POOL + 4 * (off + k)) = float4{m.x[k].x, m.x[k].y, m.x[k].z, m.sep[k]};
+          }
+        }
+      }
+      if (T == 0) {  // (wave-uniform) no round ran: the pool counter is still to be cleared
+        if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
+      }
+      __syncthreads();
+      PH(13);
+      // ---- stage B: generic convex pairs (MPR). A pair is worked on by one 16-lane group (hull scans shared by
+      // its lanes); the MPR pairs of all 4 envs form one task list that the 4 groups take round-robin, so an env
+      // with many such pairs does not serialise on its own group.
+      for (int t = g; t < TM; t += S16_ENVS_PER_BLOCK) {
+        int ge = 0;
+#pragma unroll
+        for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= mcum[j] ? 1 : 0;
+        const int k = t - mcum[ge];
+        float* Lg = sm + ge * S16_ENV_FLOATS;
+        const int idx = reinterpret_cast<const unsigned char*>(Lg + S16_NP_ML)[k];
+        const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+        const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
+        const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
+        SupCoop16 sup;
+        sup.c = c;
+        SupCoop16::load_one(sup.va, A, c);
+        SupCoop16::load_one(sup.vb, B, c);
+        manifold_t m;
+        collide_mpr_t(A, B, M.contact_offset, m, sup);
+        if (c == 0 && m.count > 0) {
+          const int off = pool_alloc(Lg, 1);
+          if (off >= 0) {
+            reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = 1;
+            reinterpret_cast<int*>(Lg)[S16_NP_OFF + idx] = off;
+            float* hn = Lg + S16_NP_HN + 3 * idx;
+            hn[0] = m.n.x; hn[1] = m.n.y; hn[2] = m.n.z;
+            *reinterpret_cast<float4*>(Lg + S16_NP_POOL + 4 * off) = float4{m.x[0].x, m.x[0].y, m.x[0].z, m.sep[0]};
+          }
+        }
+      }
+      PH(25);
+      // ---- stage C: box-box pairs by 16-lane groups, round-robin over the wave's list
+      if (!bb_lane) {
+        for (int t = g; t < TB; t += S16_ENVS_PER_BLOCK) {
+          int ge = 0;
+#pragma unroll
+          for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= bcum[j] ? 1 : 0;
+          const int k = t - bcum[ge];
+          float* Lg = sm + ge * S16_ENV_FLOATS;
+          const int idx = reinterpret_cast<const unsigned char*>(Lg + S16_NP_BL)[k];
+          const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
+          const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
+          float* out = L + S16_NP_BOUT;
+          collide_box_box_coop(A, B, M.contact_offset, L + S16_NP_BSCR, out, c, g);
+          const int cnt = __float_as_int(out[0]);  // (one wave: the LDS writes of the group's lanes are complete)
+          if (cnt > 0) {
+            int off = 0;
+            if (c == 0) off = pool_alloc(Lg, cnt);
+            off = gbci(off, 0);
+            if (off >= 0) {
+              if (c == 0) {
+                reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = cnt;
+                reinterpret_cast<int*>(Lg)[S16_NP_OFF + idx] = off;
+              }
+              if (c < 3) Lg[S16_NP_HN + 3 * idx + c] = out[1 + c];
+              if (c < cnt) *reinterpret_cast<float4*>(Lg + S16_NP_POOL + 4 * (off + c)) = float4{out[4 + 4 * c], out[5 + 4 * c], out[6 + 4 * c], out[7 + 4 * c]};
+            }
+          }
+        }
+      }
+      if (__any(pool_over) && pool_over && live) S.overflow[e] = 1;  // (recorded for the group's own env: a reported condition either way)
+      __syncthreads();
+      PH(24);
+      // ---- contact patches (include/mssim.h, MSSIM_PATCH_COS): manifolds of one body pair with normals inside a
+      // cone of the first of them are one patch, cut to its 4 most significant points. Lane c looks after the
+      // manifolds c, c + 16, ..: (1) body-pair key, (2) anchor = first manifold of the same key within the cone,
+      // (3) the anchor's lane selects the patch's points when there are more than 4, (4) records are written in
+      // pair order from what survives.
+      {
+        int* const cnt_ = reinterpret_cast<int*>(L + S16_NP_CNT);
+        const int* const off_ = reinterpret_cast<const int*>(L + S16_NP_OFF);
+        int* const keep_ = reinterpret_cast<int*>(L + S16_NP_KEEP);
+        int* const key_ = reinterpret_cast<int*>(L + S16_NP_KEY);
+        const int* const hit_ = reinterpret_cast<const int*>(L + S16_NP_HIT);
+        for (int i = c; i < nh; i += 16) {
+          const int pk = hit_[i];
+          const unsigned pa = __float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 14]), pb = __float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]);
+          key_[i] = (int)(((pa >> 10) & 31u) | (((pb >> 10) & 31u) << 8));
         }
         __syncthreads();
-        if (has && m.count > 0) {
+        bool any_big = false;
+        for (int i = c; i < nh; i += 16) {
+          int anchor = i;
+          const int ci = cnt_[i];
+          if (ci > 0) {
+            const int ky = key_[i];
+            const f3 ni = f3{L[S16_NP_HN + 3 * i], L[S16_NP_HN + 3 * i + 1], L[S16_NP_HN + 3 * i + 2]};
+            for (int k = 0; k < i; k++) {
+              if (cnt_[k] > 0 && key_[k] == ky && dot(f3{L[S16_NP_HN + 3 * k], L[S16_NP_HN + 3 * k + 1], L[S16_NP_HN + 3 * k + 2]}, ni) >= MSSIM_PATCH_COS) { anchor = k; break; }
+            }
+          }
+          keep_[i] = (anchor << 4) | ((1 << ci) - 1);
+        }
+        __syncthreads();
+        for (int a = c; a < nh; a += 16) {
+          if ((keep_[a] >> 4) != a || cnt_[a] == 0) continue;
+          int total = 0;
+          for (int i = a; i < nh; i++) total += (keep_[i] >> 4) == a ? cnt_[i] : 0;
+          if (total <= 4) continue;
+          any_big = true;
+          const f3 na = f3{L[S16_NP_HN + 3 * a], L[S16_NP_HN + 3 * a + 1], L[S16_NP_HN + 3 * a + 2]};
+          // point id = manifold * 4 + point; "first candidate wins" in (manifold, point) order, as the oracle
+          auto scan = [&](auto&& f) __attribute__((always_inline)) {
+            for (int i = a; i < nh; i++) {
+              if ((keep_[i] >> 4) != a) continue;
+              const int cn = cnt_[i], of = off_[i];
+              for (int q = 0; q < cn; q++) f(4 * i + q, *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (of + q)));
+            }
+          };
+          int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+          float best = 3e38f;
+          f3 p0 = f3{0, 0, 0}, p1 = f3{0, 0, 0};
+          scan([&](int id, float4 P) { if (P.w < best) { best = P.w; i0 = id; p0 = f3{P.x, P.y, P.z}; } });
+          best = -1.f;
+          scan([&](int id, float4 P) {
+            const f3 d = f3{P.x, P.y, P.z} - p0;
+            const float v = dot(d, d);
+            if (id != i0 && v > best) { best = v; i1 = id; p1 = f3{P.x, P.y, P.z}; }
+          });
+          const f3 ed = p1 - p0;
+          best = -1.f;
+          float sgn2 = 0.f;
+          scan([&](int id, float4 P) {
+            const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
+            if (id != i0 && id != i1 && fabsf(ar) > best) { best = fabsf(ar); i2 = id; sgn2 = ar; }
+          });
+          best = 0.f;
+          scan([&](int id, float4 P) {
+            const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
+            const float v = sgn2 >= 0.f ? -ar : ar;
+            if (id != i0 && id != i1 && id != i2 && v > best) { best = v; i3 = id; }
+          });
+          for (int i = a; i < nh; i++) {
+            if ((keep_[i] >> 4) != a) continue;
+            int mk = 0;
+            if ((i0 >> 2) == i) mk |= 1 << (i0 & 3);
+            if ((i1 >> 2) == i) mk |= 1 << (i1 & 3);
+            if ((i2 >> 2) == i) mk |= 1 << (i2 & 3);
+            if (i3 >= 0 && (i3 >> 2) == i) mk |= 1 << (i3 & 3);
+            keep_[i] = (a << 4) | mk;
+          }
+        }
+        PH_ADD(9, __any(any_big) ? 1 : 0);
+        __syncthreads();
+        // records, in pair order
+        int tot = 0;
+        for (int i = c; i < nh; i += 16) {
+          const int mk = keep_[i] & 15;
+          tot += __popc(mk);
+          if (mk == 0) continue;
           int off = 0;
-          for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(Lg)[S16_NP_CNT + j];
+          for (int j = 0; j < i; j++) off += __popc(keep_[j] & 15);
+          const int pk = hit_[i];
           const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
-          const float mu = 0.5f * (Lg[S16_NP_SHP + S16_SHP * sa + 15] + Lg[S16_NP_SHP + S16_SHP * sb + 15]);
-          const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
-                                   (slot_lane_mask(L, (int)((__float_as_uint(Lg[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16));
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (k < m.count && off + k < MAXC) {
-              float* r = Lg + S16_REC + S16_REC_LEN * (off + k);
-              r[0] = m.n.x; r[1] = m.n.y; r[2] = m.n.z;
-              r[3] = m.x[k].x; r[4] = m.x[k].y; r[5] = m.x[k].z;
-              r[6] = m.sep[k] - M.rest_offset;
+          const float mu = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
+          const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
+                                   (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16));
+          const f3 nn = f3{L[S16_NP_HN + 3 * i], L[S16_NP_HN + 3 * i + 1], L[S16_NP_HN + 3 * i + 2]};
+          const int of = off_[i];
+          for (int q = 0; q < 4; q++) {
+            if (!((mk >> q) & 1)) continue;
+            if (off < MAXC) {
+              const float4 P = *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (of + q));
+              float* r = L + S16_REC + S16_REC_LEN * off;
+              r[0] = nn.x; r[1] = nn.y; r[2] = nn.z;
+              r[3] = P.x; r[4] = P.y; r[5] = P.z;
+              r[6] = P.w - M.rest_offset;
               r[7] = __int_as_float(pk & 0xFFFF);
               r[8] = __int_as_float(bodies);
               r[9] = mu;
             }
-        }
-        __syncthreads();
-      }
-      // the staged box-box manifolds go to their slots (all manifold sizes are known now)
-      if (bb_coop) {
-        for (int k = c; k < nbl; k += 16) {
-          const int idx = reinterpret_cast<const int*>(L)[S16_NP_BL + k];
-          const float* o = L + S16_NP_BS + 20 * k;
-          const int cnt = __float_as_int(o[0]);
-          if (cnt > 0) {
-            int off = 0;
-            for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
-            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
-            const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
-            const float mu = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
-            const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
-                                     (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16));
-            for (int q = 0; q < cnt; q++)
-              if (off + q < MAXC) {
-                float* r = L + S16_REC + S16_REC_LEN * (off + q);
-                r[0] = o[1]; r[1] = o[2]; r[2] = o[3];
-                r[3] = o[4 + 4 * q]; r[4] = o[5 + 4 * q]; r[5] = o[6 + 4 * q];
-                r[6] = o[7 + 4 * q] - M.rest_offset;
-                r[7] = __int_as_float(pk & 0xFFFF);
-                r[8] = __int_as_float(bodies);
-                r[9] = mu;
-              }
+            off++;
           }
         }
-      }
-      // the staged MPR contacts go to their slots (all manifold sizes are known now)
-      for (int k = c; k < nml; k += 16) {
-        const int idx = reinterpret_cast<const int*>(L)[S16_NP_ML + k];
-        if (reinterpret_cast<const int*>(L)[S16_NP_CNT + idx] > 0) {
-          int off = 0;
-          for (int j = 0; j < idx; j++) off += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
-          if (off < MAXC) {
-            const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
-            const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
-            const float* o = L + S16_NP_MS + 7 * k;
-            float* r = L + S16_REC + S16_REC_LEN * off;
-#pragma unroll
-            for (int q = 0; q < 6; q++) r[q] = o[q];
-            r[6] = o[6] - M.rest_offset;
-            r[7] = __int_as_float(pk & 0xFFFF);
-            r[8] = __int_as_float((int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
-                                        (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16)));
-            r[9] = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
-          }
-        }
-      }
-      __syncthreads();
-      PH(24);
-      {
-        int tot = 0;
-        for (int j = c; j < nh; j += 16) tot += reinterpret_cast<const int*>(L)[S16_NP_CNT + j];
         tot += __shfl_xor(tot, 8, 16); tot += __shfl_xor(tot, 4, 16); tot += __shfl_xor(tot, 2, 16); tot += __shfl_xor(tot, 1, 16);
         if (tot > MAXC) { if (live && c == 0) S.overflow[e] = 1; tot = MAXC; }
         nc = tot;
       }
-      __syncthreads();
-    } else {
-      // ---- split path: copy this env's manifolds (k_narrow output, pair order) into LDS records
-      int ncontact = 0;
-      for (int w = 0; w < M.n_words; w++) {
-        unsigned bits = S.hit_mask[(size_t)w * N + e];
-        while (__any(bits != 0u)) {
-          const bool act = bits != 0u;
-          const int bit = act ? (__ffs(bits) - 1) : 0;
-          bits = act ? (bits & (bits - 1u)) : 0u;
-          const int p = act ? (w * 32 + bit) : 0;
-          const int cnt = act ? S.pair_cnt[(size_t)p * N + e] : 0;
-          const float* pd = S.pair_data + (size_t)(19 * p) * N + e;
-          if (act && live && c < 3) SOA(S.pair_imp, 3 * p + c) = 0.f;
-          const int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
-          const int bodies = (int)(slot_lane_mask(L, pose_slot(M.shape_kind[sa], M.shape_index[sa]), n) |
-                                   (slot_lane_mask(L, pose_slot(M.shape_kind[sb], M.shape_index[sb]), n) << 16));
-          const float mu = 0.5f * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
-          for (int k = 0; k < 4; k++) {
-            const bool ck = act && k < cnt;
-            if (ck && ncontact >= MAXC && live && c == 0) S.overflow[e] = 1;
-            if (ck && ncontact < MAXC) {
-              if (c < 10) {
-                float val;
-                if (c < 3) val = pd[(size_t)c * N];
-                else if (c < 7) val = pd[(size_t)(3 + 4 * k + (c - 3)) * N];
-                else val = c == 7 ? __int_as_float(p) : (c == 8 ? __int_as_float(bodies) : mu);
-                L[S16_REC + S16_REC_LEN * ncontact + c] = val;
-              }
-              ncontact++;
-            }
-          }
-        }
-      }
-      nc = ncontact;
       __syncthreads();
     }
     PH(21);
@@ -1635,7 +1688,6 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     }
   }
 
-  if (!FUSED && live) for (int w = c; w < M.n_words; w += 16) S.hit_mask[(size_t)w * N + e] = 0u;
   (void)nrow_con;
   PH(7);
   // ================================================================ copy-out + task epilogue of this env

@@ -464,7 +464,7 @@ class BaseEnv(gym.Env):
 
     # ------------------------------------------------------------------ step
     def step(self, action: Union[None, np.ndarray, torch.Tensor, Dict]):
-        self._fused_truncated = None
+        self._fused_truncated = self._fused_terminated = None
         self._fused_epilogue_next = self._use_fused_callers and self._fused_ok()
         action = self._step_action(action)
         self._fused_epilogue_next = False
@@ -472,8 +472,10 @@ class BaseEnv(gym.Env):
         fused = self._fused_step_outputs(action) if self._use_fused_callers else None
         if fused is not None:
             obs, reward, info = fused
-            # `success` is a fresh tensor of this step and there is no `fail`: no copies needed
-            return obs, reward, info["success"], self._no_truncation(), info
+            # `terminated` is the epilogue's own copy of `success` (the reference returns a clone, sapien_env.py:959:
+            # ManiSkillVectorEnv(ignore_terminations=True) clears it in place and must not clear info["success"])
+            terminated = self._fused_terminated.view(torch.bool) if self._fused_terminated is not None else info["success"].clone()
+            return obs, reward, terminated, self._no_truncation(), info
         self._elapsed_steps += 1
         info = self.get_info()
         obs = self.get_obs(info)
@@ -526,6 +528,9 @@ class BaseEnv(gym.Env):
             if self.num_envs == 1 and unbatched:
                 action = common.batch(action)
             if self._fused_action_ready(action):
+                # (the torch path asserts this in BaseController._preprocess_action; the kernels index the action unchecked)
+                assert action.shape == (self.num_envs, self.single_action_space.shape[0]), (
+                    f"action of shape {tuple(action.shape)} for an action space of shape ({self.num_envs}, {self.single_action_space.shape[0]})")
                 # one launch instead of the controller's ~10 torch ops + 2 applies (same arithmetic); without
                 # hooks between set_action and the substeps the map runs at the head of the step's own launch
                 if self._no_step_hooks():
@@ -597,9 +602,40 @@ class BaseEnv(gym.Env):
         self._fused_truncated = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         return self._fused_truncated.data_ptr(), int(self._time_limit)
 
+    _fused_terminated = None
+
     def _fused_ok(self) -> bool:
-        """will `_fused_step_outputs` produce this step's outputs? (tasks with a native epilogue override both)"""
+        """will `_fused_step_outputs` produce this step's outputs? Asked every step; the task's answer
+        (`_fused_task_ok`) is cached per controller object and hidden-object state: a control-mode switch can add
+        controller state to the observation, and the epilogue reads the raw pose rows, which a hidden object has moved
+        away (Actor.hide_visual)."""
+        ctrl = self.agent.controller if self.agent is not None else None
+        hidden = any(getattr(o, "hidden", False) for o in self._hidden_objects)
+        key = (id(self.scene), id(ctrl), getattr(self.agent, "control_mode", None), hidden)
+        if self.__dict__.get("_fused_ok_key") != key:
+            self._fused_ok_key, self._fused_ok_val = key, (not hidden) and bool(self._fused_task_ok())
+        return self._fused_ok_val
+
+    def _fused_task_ok(self) -> bool:
+        """tasks with a native epilogue: is it equivalent to the torch path for this configuration?"""
         return False
+
+    def _fused_bind_counters(self, task, advance: bool) -> torch.Tensor:
+        """per-step pointers of a native task struct: the step counter (incremented in place + copied out), the time
+        limit flag and the `terminated` copy. Returns the tensor that becomes info["elapsed_steps"].
+        `advance=False` (reset): outputs of the current state, the counter stays where it is."""
+        if advance:
+            es = torch.empty_like(self._elapsed_steps)
+            task.elapsed_steps, task.elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
+            task.truncated_out, task.time_limit = self._fused_time_limit_out()
+            self._fused_terminated = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+            task.terminated_out = self._fused_terminated.data_ptr()
+        else:
+            es = self._elapsed_steps.clone()
+            task.elapsed_steps = task.elapsed_out = task.truncated_out = task.terminated_out = None
+            task.time_limit = 0
+            self._fused_terminated = None
+        return es
 
     def _fused_step_outputs(self, action, advance: bool = True):
         """tasks may return (obs, reward, info) computed by a fused native kernel; None = torch path.

@@ -40,7 +40,6 @@ class PushCubeEnv(BaseEnv):
         super()._load_agent(options, sapien.Pose(p=[-0.615, 0, 0]))
 
     def _load_scene(self, options: dict):
-        self._fused_ok_cache = None
         self._fused_state = None
         self.table_scene = TableSceneBuilder(env=self, robot_init_qpos_noise=self.robot_init_qpos_noise)
         self.table_scene.build()
@@ -91,16 +90,13 @@ class PushCubeEnv(BaseEnv):
         return self.compute_dense_reward(obs=obs, action=action, info=info) / 3.0
 
     # ---- fused evaluate + obs + reward (one native launch; identical results, tests/test_gpu_env.py) ----
-    def _fused_ok(self) -> bool:
-        ok = getattr(self, "_fused_ok_cache", None)
-        if ok is None:
-            cls = type(self)
-            same = all(
-                getattr(cls, m) is getattr(PushCubeEnv, m)
-                for m in ("evaluate", "_get_obs_extra", "compute_dense_reward", "compute_normalized_dense_reward", "_get_obs_agent", "get_obs", "get_info", "get_reward")
-            )
-            ok = same and self._obs_mode == "state" and self._reward_mode in ("dense", "normalized_dense") and len(self.agent.controller.get_state()) == 0
-            self._fused_ok_cache = ok
+    def _fused_task_ok(self) -> bool:
+        cls = type(self)
+        same = all(
+            getattr(cls, m) is getattr(PushCubeEnv, m)
+            for m in ("evaluate", "_get_obs_extra", "compute_dense_reward", "compute_normalized_dense_reward", "_get_obs_agent", "get_obs", "get_info", "get_reward")
+        )
+        ok = same and self._obs_mode == "state" and self._reward_mode in ("dense", "normalized_dense") and len(self.agent.controller.get_state()) == 0
         return ok
 
     def _fused_step_outputs(self, action, advance: bool = True):
@@ -119,13 +115,6 @@ class PushCubeEnv(BaseEnv):
         obs = torch.empty((N, D), dtype=torch.float32, device=self.device)
         reward = torch.empty((N,), dtype=torch.float32, device=self.device)
         flags = torch.empty((N, 1), dtype=torch.uint8, device=self.device)
-        if advance:
-            es = torch.empty_like(self._elapsed_steps)
-            st["task"].elapsed_steps, st["task"].elapsed_out = self._elapsed_steps.data_ptr(), es.data_ptr()
-            st["task"].truncated_out, st["task"].time_limit = self._fused_time_limit_out()
-        else:  # reset(): outputs of the current state, the step counter stays where it is
-            es = self._elapsed_steps.clone()
-            st["task"].elapsed_steps = st["task"].elapsed_out = st["task"].truncated_out = None
-            st["task"].time_limit = 0
+        es = self._fused_bind_counters(st["task"], advance)
         px.task_push_outputs(st["task"], obs, reward, flags)
         return obs, reward, dict(elapsed_steps=es, success=flags.view(torch.bool)[:, 0])

@@ -13,7 +13,7 @@ import numpy as np
 from . import PACKAGE_DIR
 from .model.compile import CompiledModel
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NATIVE_LIB_PATH = os.environ.get("MSSIM_LIB") or os.path.join(PACKAGE_DIR, "_native", "libmssim.so")  # MSSIM_LIB: debug builds of the same HIP library
 
 # apply / fetch selector bits (include/mssim.h)
@@ -131,20 +131,20 @@ class PickTask(C.Structure):
     _fields_ = [
         ("tcp_row", C.c_int32), ("obj_row", C.c_int32), ("goal_row", C.c_int32), ("finger1_row", C.c_int32), ("finger2_row", C.c_int32),
         ("n_static_dofs", C.c_int32), ("goal_thresh", C.c_float), ("static_thresh", C.c_float), ("min_force", C.c_float),
-        ("max_angle_deg", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p), ("truncated_out", C.c_void_p), ("time_limit", C.c_int32),
+        ("max_angle_deg", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p), ("truncated_out", C.c_void_p), ("time_limit", C.c_int32), ("terminated_out", C.c_void_p),
     ]
 
 
 class PushTask(C.Structure):
     _fields_ = [("tcp_row", C.c_int32), ("obj_row", C.c_int32), ("goal_row", C.c_int32), ("goal_radius", C.c_float),
-                ("cube_half_size", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p), ("truncated_out", C.c_void_p), ("time_limit", C.c_int32)]
+                ("cube_half_size", C.c_float), ("reward_scale", C.c_float), ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p), ("truncated_out", C.c_void_p), ("time_limit", C.c_int32), ("terminated_out", C.c_void_p)]
 
 
 class PegTask(C.Structure):
     _fields_ = [("tcp_row", C.c_int32), ("peg_row", C.c_int32), ("box_row", C.c_int32), ("finger1_row", C.c_int32), ("finger2_row", C.c_int32),
                 ("min_force", C.c_float), ("max_angle_deg", C.c_float), ("reward_scale", C.c_float),
                 ("peg_half_sizes", C.c_void_p), ("box_hole_offsets", C.c_void_p), ("box_hole_radii", C.c_void_p),
-                ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p), ("truncated_out", C.c_void_p), ("time_limit", C.c_int32)]
+                ("elapsed_steps", C.c_void_p), ("elapsed_out", C.c_void_p), ("truncated_out", C.c_void_p), ("time_limit", C.c_int32), ("terminated_out", C.c_void_p)]
 
 
 class NativeError(RuntimeError):

@@ -43,7 +43,7 @@ typedef M3<Real> Mat;
 
 namespace {
 
-const int MAXC = 48;  // contact points per env fed to the solver
+const int MAXC = MSSIM_MAX_CONTACTS;  // contact points per env fed to the solver (after the patch reduction)
 std::string g_create_error;
 
 struct SpatialV { Vec w, v; };           // motion: angular, linear (of the point at the origin O)
@@ -89,6 +89,7 @@ struct EnvState {
   std::vector<Vec> pair_impulse;
   std::vector<int> pair_count;
   int overflow = 0;
+  int raw_points = 0;  // manifold points of the last substep before the patch reduction
 };
 
 template <typename T> std::vector<T> cp(const T* p, size_t n) { return p ? std::vector<T>(p, p + n) : std::vector<T>(n); }
@@ -192,11 +193,82 @@ inline void shape_bound_body(const Model& M, int s, int e, Vec& c, Real& r) {
   }
 }
 
+// body of a shape as one id: all world-fixed shapes are one body (0), the articulation base 1, its moving bodies
+// 2.., free bodies, kinematic bodies
+inline int body_id(int kind, int index) {
+  switch (kind) {
+    case MSSIM_BODY_ART: return 2 + index;  // index -1 = base
+    case MSSIM_BODY_FREE: return 2 + MSSIM_MAX_DOF + index;
+    case MSSIM_BODY_KIN: return 2 + MSSIM_MAX_DOF + MSSIM_MAX_FREE + index;
+    default: return 0;
+  }
+}
+
+// Contact patches (include/mssim.h, MSSIM_PATCH_COS): `man` = the manifolds of this env in pair order (first contact,
+// count, normal, body pair), `raw` their points. A manifold's anchor is the first manifold of the same body pair
+// whose normal lies within the patch cone of its own (itself if none earlier does); the points of all manifolds
+// with one anchor form a patch. A patch with more than 4 points keeps: the deepest point, the point farthest from
+// it, and the points of largest area on either side of that edge (measured about the anchor's normal) -- first
+// candidate wins ties, as in the box-box manifold. keep[i] = 1 for the surviving raw contacts.
+struct RawManifold { int first, count, key; Vec n; };
+void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Contact>& raw, std::vector<char>& keep) {
+  const int nm = (int)man.size();
+  keep.assign(raw.size(), 1);
+  std::vector<int> anchor(nm);
+  for (int i = 0; i < nm; i++) {
+    anchor[i] = i;
+    for (int k = 0; k < i; k++)
+      if (man[k].key == man[i].key && dot(man[k].n, man[i].n) >= Real(MSSIM_PATCH_COS)) { anchor[i] = k; break; }
+  }
+  for (int a = 0; a < nm; a++) {
+    std::vector<int> pts;  // raw contact indices of the patch, in (manifold, point) order
+    for (int i = a; i < nm; i++)
+      if (anchor[i] == a)
+        for (int k = 0; k < man[i].count; k++) pts.push_back(man[i].first + k);
+    const int n = (int)pts.size();
+    if (n <= 4) continue;
+    const Vec na = man[a].n;
+    int i0 = 0;
+    for (int i = 1; i < n; i++)
+      if (raw[pts[i]].sep < raw[pts[i0]].sep) i0 = i;
+    const Vec p0 = raw[pts[i0]].x;
+    int i1 = -1;
+    Real best = Real(-1);
+    for (int i = 0; i < n; i++) {
+      if (i == i0) continue;
+      const Vec d = raw[pts[i]].x - p0;
+      const Real v = dot(d, d);
+      if (v > best) { best = v; i1 = i; }
+    }
+    const Vec ed = raw[pts[i1]].x - p0;
+    int i2 = -1;
+    best = Real(-1);
+    Real sgn2 = 0;
+    for (int i = 0; i < n; i++) {
+      if (i == i0 || i == i1) continue;
+      const Real ar = dot(cross(ed, raw[pts[i]].x - p0), na);
+      if (std::fabs(ar) > best) { best = std::fabs(ar); i2 = i; sgn2 = ar; }
+    }
+    int i3 = -1;
+    best = Real(0);
+    for (int i = 0; i < n; i++) {
+      if (i == i0 || i == i1 || i == i2) continue;
+      const Real ar = dot(cross(ed, raw[pts[i]].x - p0), na);
+      const Real v = sgn2 >= 0 ? -ar : ar;
+      if (v > best) { best = v; i3 = i; }
+    }
+    for (int i = 0; i < n; i++) keep[pts[i]] = (i == i0 || i == i1 || i == i2 || i == i3) ? 1 : 0;
+  }
+}
+
 void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) {
   out.clear();
   E.pair_count.assign(M.n_pair, 0);
   std::vector<Shape<Real>> sh(M.n_shape);
   for (int s = 0; s < M.n_shape; s++) sh[s] = make_shape(M, E, s, e);
+  std::vector<Contact> raw;
+  std::vector<RawManifold> man;
+  int hits = 0;  // pairs that survive the cull (the kernels' hit list holds MSSIM_MAX_HITS of them)
   for (int p = 0; p < M.n_pair; p++) {
     int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
     const Shape<Real>&A = sh[sa], &B = sh[sb];
@@ -217,18 +289,30 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
     }
     Manifold<Real> m;
     collide(A, B, M.contact_offset, m);
-    E.pair_count[p] = m.count;
+    if (m.count <= 0) continue;
+    hits++;
+    if ((int)raw.size() + m.count > MSSIM_MAX_RAW_POINTS) { E.overflow = 1; break; }
     Real mu = Real(0.5) * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
+    man.push_back({(int)raw.size(), m.count, body_id(M.shape_kind[sa], M.shape_index[sa]) * 64 + body_id(M.shape_kind[sb], M.shape_index[sb]), m.n});
     for (int k = 0; k < m.count; k++) {
-      if ((int)out.size() >= MAXC) { E.overflow = 1; break; }
       Contact c;
       c.pair = p;
       c.ka = M.shape_kind[sa]; c.ia = M.shape_index[sa];
       c.kb = M.shape_kind[sb]; c.ib = M.shape_index[sb];
       c.x = m.x[k]; c.n = m.n; c.sep = m.sep[k] - M.rest_offset; c.mu = mu;
       c.lam[0] = c.lam[1] = c.lam[2] = 0;
-      out.push_back(c);
+      raw.push_back(c);
     }
+  }
+  (void)hits;
+  E.raw_points = (int)raw.size();
+  std::vector<char> keep;
+  reduce_patches(man, raw, keep);
+  for (size_t i = 0; i < raw.size(); i++) {
+    if (!keep[i]) continue;
+    if ((int)out.size() >= MAXC) { E.overflow = 1; break; }
+    out.push_back(raw[i]);
+    E.pair_count[raw[i].pair]++;
   }
 }
 
@@ -820,6 +904,9 @@ int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_
         const Vec& v = h->env[e].pair_impulse[p];
         put(3 * p, e, v.x); put(3 * p + 1, e, v.y); put(3 * p + 2, e, v.z);
       }
+  } else if (s == "raw_contact_count") {  // (oracle only: test construction aid)
+    items = 1;
+    for (int e = 0; e < N; e++) put(0, e, h->env[e].raw_points);
   } else if (s == "overflow") {
     items = 1;
     for (int e = 0; e < N; e++) put(0, e, h->env[e].overflow);

@@ -50,7 +50,7 @@ def test_peg_insertion_per_env_geometry():
     ec.check_peg_insertion(BACKEND, "cuda")
 
 
-@pytest.mark.parametrize("env_id", ["PickCube-v1", "PegInsertionSide-v1"])
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1"])
 def test_env_rollout_matches_oracle_backend(env_id):
     """same seed, same actions: obs / reward of the HIP env track the oracle-backed env for the first
     control steps (contact-light PickCube start states), within 1e-3 (positions / angles)."""
@@ -309,4 +309,132 @@ def test_abusive_rollouts_stay_bounded(env_id, control_mode):
         elif i % 10 == 0:
             env.reset(options=dict(env_idx=torch.nonzero(torch.rand(N, device="cuda", generator=g) < 0.02).flatten()))
     assert int(bad) == 0 and float(worst) < 1e3, (int(bad), float(worst))
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1"])
+def test_ignore_terminations_keeps_success_in_info(env_id):
+    """`terminated` is a copy of info["success"] (reference: envs/sapien_env.py:959): ManiSkillVectorEnv with
+    ignore_terminations=True clears `terminations` in place (vector/wrappers/gymnasium.py:128-134) and must leave
+    info["success"], episode["success_at_end"] and final_info["success"] alone"""
+    import gymnasium as gym
+
+    from maniskill_amd.vector.wrappers.gymnasium import ManiSkillVectorEnv
+
+    N = 16
+    env = gym.make(env_id, num_envs=N, sim_backend=BACKEND, max_episode_steps=3)
+    venv = ManiSkillVectorEnv(env, auto_reset=True, ignore_terminations=True, record_metrics=True)
+    base = venv.base_env
+    venv.reset(seed=1)
+    assert base._use_fused_callers and base._fused_ok()
+    # put the object on the goal with the robot at rest: success from the first step on
+    if env_id == "PickCube-v1":
+        base.cube.set_pose(base.goal_site.pose)
+    else:
+        p = base.goal_region.pose.raw_pose.clone()
+        p[:, 2] = base.cube_half_size
+        from maniskill_amd.utils.structs.pose import Pose
+
+        base.obj.set_pose(Pose.create(p))
+    base.scene._gpu_apply_all()
+    base.scene.px.gpu_update_articulation_kinematics()
+    base.scene._gpu_fetch_all()
+    zero = torch.zeros(N, 8, device="cuda")
+    zero[:, -1] = 1.0  # keep the gripper open
+    seen_final = False
+    for step in range(3):
+        obs, rew, term, trunc, info = venv.step(zero)
+        assert not term.any()
+        if "final_info" in info:
+            seen_final = True
+            assert info["final_info"]["success"].float().mean() > 0.8
+            assert torch.equal(info["final_info"]["episode"]["success_at_end"], info["final_info"]["success"])
+        else:
+            assert info["success"].float().mean() > 0.8, (step, info["success"])
+            assert torch.equal(info["episode"]["success_at_end"], info["success"])
+            assert info["episode"]["success_once"].float().mean() > 0.8
+    assert seen_final
+    venv.close()
+
+
+def test_fused_step_rejects_a_wrong_action_shape():
+    """the torch path asserts action.shape == (num_envs, action_dim) (agents/controllers/base_controller.py:120-133);
+    the native action map must not index past a narrower action or silently accept a wider one"""
+    import gymnasium as gym
+
+    from maniskill_amd.native import NativeError
+
+    N = 8
+    env = gym.make("PickCube-v1", num_envs=N, sim_backend=BACKEND)
+    env.reset(seed=0)
+    env.step(torch.zeros(N, 8, device="cuda"))
+    for bad in (7, 9):
+        with pytest.raises(AssertionError):
+            env.step(torch.zeros(N, bad, device="cuda"))
+    # below the env layer: the C ABI itself reports it
+    px = env.unwrapped.scene.px
+    with pytest.raises(NativeError):
+        px.step_action(torch.zeros(N, 7, device="cuda"), 5)
+    env.step(torch.zeros(N, 8, device="cuda"))
+    env.close()
+
+
+def test_fused_epilogue_follows_controller_switches_and_hidden_objects():
+    """the task's native epilogue is only used while it is equivalent to the torch path: a switch to a controller with
+    state in the observation, or a hidden goal site (whose raw pose row is parked far away), turn it off"""
+    import gymnasium as gym
+
+    N = 8
+    env = gym.make("PickCube-v1", num_envs=N, sim_backend=BACKEND)
+    base = env.unwrapped
+    env.reset(seed=0)
+    obs, *_ = env.step(torch.zeros(N, 8, device="cuda"))
+    assert base._fused_ok() and obs.shape == (N, 42)
+    goal = base.goal_site.pose.p.clone()
+    base.goal_site.hide_visual()
+    assert not base._fused_ok()
+    obs, *_ = env.step(torch.zeros(N, 8, device="cuda"))
+    assert torch.allclose(obs[:, 26:29], goal)  # goal_pos from before_hide_pose, not the +99999 row
+    base.goal_site.show_visual()
+    assert base._fused_ok()
+    obs, *_ = env.step(dict(control_mode="pd_joint_target_delta_pos", action=torch.zeros(N, 8, device="cuda")))
+    assert not base._fused_ok()
+    assert obs.shape[1] > 42  # the controller's target qpos is part of the proprioception now
+    env.close()
+
+
+def test_peg_insertion_has_no_contact_overflow():
+    """BASELINE config 3 (PegInsertionSide-v1, 2048 envs): 600 random control steps without one env above the contact
+    capacity (round 1: ~28 % of the envs above it). The finger boxes against the boxes of the hole produce up to 100+
+    raw manifold points per env; the contact patches of a body pair (include/mssim.h MSSIM_PATCH_COS) keep 4 each."""
+    import gymnasium as gym
+
+    N = 2048
+    env = gym.make("PegInsertionSide-v1", num_envs=N, sim_backend=BACKEND)
+    env.reset(seed=0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    px = env.unwrapped.scene.px
+    for i in range(1, 601):
+        obs, rew, *_ = env.step(2 * torch.rand(N, 8, device="cuda", generator=g) - 1)
+        if i % 100 == 0:
+            env.reset()
+    assert torch.isfinite(obs).all()
+    assert px.overflow_count() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("control_mode", ["pd_ee_delta_pos", "pd_ee_delta_pose"])
+def test_ee_modes_contact_overflow_is_rare(control_mode):
+    """random end-effector pushes jam the arm into the table (fingers, hand and links on the table at once): fewer than
+    0.5 % of the envs may ever exceed the contact capacity over 1000 control steps (round 1: 5-8 %)"""
+    import gymnasium as gym
+
+    N = 4096
+    env = gym.make("PickCube-v1", num_envs=N, sim_backend=BACKEND, control_mode=control_mode)
+    adim = env.unwrapped.single_action_space.shape[0]
+    env.reset(seed=0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for i in range(1000):
+        env.step(2 * torch.rand(N, adim, device="cuda", generator=g) - 1)
+    assert env.unwrapped.scene.px.overflow_count() < N // 200
     env.close()

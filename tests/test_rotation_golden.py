@@ -3,16 +3,30 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from maniskill_amd.utils.geometry import rotation_conversions as rc
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rotation_golden.npz"))
-t = lambda k: torch.from_numpy(G[k])
+# the golden vectors are the only reference-generated fixture of the path: they are checked on CPU tensors here and
+# on the MI355X (`cuda` tensors, the device every struct getter of the product returns) under the gpu mark
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+_dev = "cpu"
+t = lambda k: torch.from_numpy(G[k]).to(_dev)
+
+
+@pytest.fixture(autouse=True, params=DEVICES)
+def on_device(request):
+    global _dev
+    _dev = request.param
+    yield
+    _dev = "cpu"
 
 
 def close(a, k, atol=1e-6):
-    np.testing.assert_allclose(a.numpy(), G[k], atol=atol, rtol=1e-5)
+    assert a.device.type == _dev
+    np.testing.assert_allclose(a.cpu().numpy(), G[k], atol=atol, rtol=1e-5)
 
 
 def test_quaternion_ops_match_reference():
@@ -35,6 +49,8 @@ def test_matrix_conversions_match_reference():
 
 
 def test_yaw_only_random_quaternions_equal_the_generic_route():
+    if _dev != "cpu":
+        pytest.skip("device variant: tests/test_gpu_env.py")
     """the yaw-only fast path of random_quaternions is the generic euler -> matrix -> quaternion route, bit for bit"""
     import numpy as np
     import torch
