@@ -62,10 +62,21 @@ extern "C" {
  * the per-body-pair persistent-manifold cap of PCM-style narrowphases (types.py:44 enable_pcm). A manifold joins the
  * patch of the FIRST manifold (pair order) of its body pair whose normal is within MSSIM_PATCH_COS of its own. */
 #define MSSIM_PATCH_COS 0.985f     /* cos of the patch cone half angle (~10 degrees)          */
+/* The four selection scans take the FIRST candidate (pair order, then point order) within a tolerance of the
+ * extremum: flat contacts put many points at equal depth / distance / area, and a bare "first extremum" would be decided
+ * by rounding noise (a different point set in f32 and f64, and from one substep to the next). */
+#define MSSIM_PATCH_TIE_SEP 1e-5f  /* separations within 10 micrometres of the deepest count as equal */
+#define MSSIM_PATCH_TIE_REL 1e-3f  /* squared distances / areas within 0.1 % of the largest count as equal */
 #define MSSIM_MAX_CONTACTS 48      /* contact points per env fed to the solver, after the patch reduction */
 #define MSSIM_MAX_HITS 64          /* shape pairs per env that survive the cull               */
 #define MSSIM_MAX_RAW_POINTS 128   /* manifold points per env before the patch reduction      */
 
+enum {
+  MSSIM_OVERFLOW_HITS = 1,     /* more than MSSIM_MAX_HITS shape pairs survived the cull            */
+  MSSIM_OVERFLOW_CONVEX = 2,   /* more generic convex (MPR) pairs than the kernel's per-env list      */
+  MSSIM_OVERFLOW_RAW = 4,      /* more than MSSIM_MAX_RAW_POINTS manifold points before the reduction */
+  MSSIM_OVERFLOW_CONTACTS = 8  /* more than MSSIM_MAX_CONTACTS contact points after the reduction     */
+};
 /* joint types of the moving articulation bodies (fixed joints are folded at compile time) */
 enum { MSSIM_JOINT_REVOLUTE = 0, MSSIM_JOINT_PRISMATIC = 1 };
 /* drive modes, articulation_joint.py:184-201 (`set_drive_properties(..., mode)`) */
@@ -248,8 +259,9 @@ int MSSIM_FN(set_drive_properties)(mssim_handle h, const float* dof_drive);
  * (13 per body), "kin" (7 per body), "root" (7), "bodypose" (7 per moving body),
  * "contact_count" (per pair, as float), "overflow" (1).  Returns number of items or <0. */
 int MSSIM_FN(read_internal)(mssim_handle h, const char* name, float* out, int32_t max_items, void* stream);
-/* capacity overflow must be a reported condition (SURVEY 8b error conventions): number of envs
- * whose solver row capacity was exceeded since the last call (synchronises the stream). */
+/* capacity overflow must be a reported condition (SURVEY 8b error conventions): number of envs in which a capacity
+ * was exceeded since the last call (synchronises the stream). read_internal("overflow") gives the reason per env as a
+ * bit set of MSSIM_OVERFLOW_* (cleared by overflow_count). */
 int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
 /* ---- fused callers of the step: what the reference does with ~10 + ~100 tiny
  * torch kernels per control step around px.step(), as one launch each. Results are identical to

@@ -1427,7 +1427,7 @@ int mssim_overflow_count(mssim_handle h, void* stream) {
   if (hipMemcpy(host.data(), h->S.overflow, sizeof(int) * h->N, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   (void)hipMemset(h->S.overflow, 0, sizeof(int) * h->N);
   int c = 0;
-  for (int v : host) c += v;
+  for (int v : host) c += v != 0;
   return c;
 }
 

@@ -74,10 +74,10 @@
 #define S16_NP_KEY (S16_NP_SCR + 792)     // [64] body pair of the manifold
 #define S16_NP_ALLOC (S16_NP_SCR + 856)   // [1] points handed out from the pool
 #define S16_NP_BOUT (S16_NP_SCR + 860)    // [20] manifold of the group's current cooperative box-box pair
-#define S16_NP_ML (S16_U + 1648)  // [16 bytes] hit indices of this env's MPR (generic convex) pairs
-#define S16_NP_BL (S16_U + 1652)  // [64 bytes] hit indices of this env's box-box pairs
+#define S16_NP_ML (S16_U + 1648)  // [64 bytes] hit indices of this env's MPR (generic convex) pairs
+#define S16_NP_BL (S16_U + 1664)  // [64 bytes] hit indices of this env's box-box pairs
 #define S16_MAX_BBC 16            // box-box pairs per wave up to which they are worked on by 16-lane groups
-#define S16_MAX_MPR 16
+#define S16_MAX_MPR 64            // (= every hit: an arm folded onto itself and jammed into the table has 20+ hull pairs in range)
 static_assert(S16_NP_BOUT + 20 <= S16_NP_SCR + 896, "narrowphase staging exceeds the scratch area");
 static_assert(S16_NP_BL + 16 <= S16_REC, "narrowphase lists run into the contact records");
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         nh = nh2 < S16_MAX_HIT ? nh2 : S16_MAX_HIT;
       }
       __syncthreads();
-      if (__any(hit_over) && hit_over && live) S.overflow[e] = 1;
+      if (__any(hit_over) && hit_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_HITS);
       PH(23);
       // ---- classification: generic convex pairs (MPR) and box-box pairs of this env (byte lists of hit indices)
       int nml = 0;  // MPR pairs of this env
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           if (is_bb) bl[nbl + __popc(b16 & ((1u << c) - 1u))] = (unsigned char)idx;
           nbl += __popc(b16);
         }
-        if (__any(over) && over && live) S.overflow[e] = 1;
+        if (__any(over) && over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONVEX);
         nml = nml < S16_MAX_MPR ? nml : S16_MAX_MPR;
       }
       // wave totals: all hits, MPR tasks, box-box tasks
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
         }
       }
-      if (__any(pool_over) && pool_over && live) S.overflow[e] = 1;  // (recorded for the group's own env: a reported condition either way)
+      if (__any(pool_over) && pool_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_RAW);  // (recorded for the group's own env: a reported condition either way)
       __syncthreads();
       PH(24);
       // ---- contact patches (include/mssim.h, MSSIM_PATCH_COS): manifolds of one body pair with normals inside a
@@ -920,29 +920,42 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
               for (int q = 0; q < cn; q++) f(4 * i + q, *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (of + q)));
             }
           };
+          // every scan: the extremum, then the first candidate within the tie tolerance of it (include/mssim.h)
           int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
           float best = 3e38f;
           f3 p0 = f3{0, 0, 0}, p1 = f3{0, 0, 0};
-          scan([&](int id, float4 P) { if (P.w < best) { best = P.w; i0 = id; p0 = f3{P.x, P.y, P.z}; } });
+          scan([&](int, float4 P) { best = fminf(best, P.w); });
+          scan([&](int id, float4 P) { if (i0 < 0 && P.w <= best + MSSIM_PATCH_TIE_SEP) { i0 = id; p0 = f3{P.x, P.y, P.z}; } });
           best = -1.f;
           scan([&](int id, float4 P) {
             const f3 d = f3{P.x, P.y, P.z} - p0;
-            const float v = dot(d, d);
-            if (id != i0 && v > best) { best = v; i1 = id; p1 = f3{P.x, P.y, P.z}; }
+            if (id != i0) best = fmaxf(best, dot(d, d));
+          });
+          scan([&](int id, float4 P) {
+            const f3 d = f3{P.x, P.y, P.z} - p0;
+            if (i1 < 0 && id != i0 && dot(d, d) >= best - MSSIM_PATCH_TIE_REL * best) { i1 = id; p1 = f3{P.x, P.y, P.z}; }
           });
           const f3 ed = p1 - p0;
           best = -1.f;
+          scan([&](int id, float4 P) {
+            if (id != i0 && id != i1) best = fmaxf(best, fabsf(dot(cross(ed, f3{P.x, P.y, P.z} - p0), na)));
+          });
           float sgn2 = 0.f;
           scan([&](int id, float4 P) {
             const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
-            if (id != i0 && id != i1 && fabsf(ar) > best) { best = fabsf(ar); i2 = id; sgn2 = ar; }
+            if (i2 < 0 && id != i0 && id != i1 && fabsf(ar) >= best - MSSIM_PATCH_TIE_REL * best) { i2 = id; sgn2 = ar; }
           });
           best = 0.f;
           scan([&](int id, float4 P) {
             const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
-            const float v = sgn2 >= 0.f ? -ar : ar;
-            if (id != i0 && id != i1 && id != i2 && v > best) { best = v; i3 = id; }
+            if (id != i0 && id != i1 && id != i2) best = fmaxf(best, sgn2 >= 0.f ? -ar : ar);
           });
+          if (best > 0.f)
+            scan([&](int id, float4 P) {
+              const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
+              const float v = sgn2 >= 0.f ? -ar : ar;
+              if (i3 < 0 && id != i0 && id != i1 && id != i2 && v >= best - MSSIM_PATCH_TIE_REL * best) i3 = id;
+            });
           for (int i = a; i < nh; i++) {
             if ((keep_[i] >> 4) != a) continue;
             int mk = 0;
@@ -986,7 +999,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
         }
         tot += __shfl_xor(tot, 8, 16); tot += __shfl_xor(tot, 4, 16); tot += __shfl_xor(tot, 2, 16); tot += __shfl_xor(tot, 1, 16);
-        if (tot > MAXC) { if (live && c == 0) S.overflow[e] = 1; tot = MAXC; }
+        if (tot > MAXC) { if (live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONTACTS); tot = MAXC; }
         nc = tot;
       }
       __syncthreads();

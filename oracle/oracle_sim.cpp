@@ -228,35 +228,28 @@ void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Conta
     const int n = (int)pts.size();
     if (n <= 4) continue;
     const Vec na = man[a].n;
-    int i0 = 0;
-    for (int i = 1; i < n; i++)
-      if (raw[pts[i]].sep < raw[pts[i0]].sep) i0 = i;
+    // every scan: the extremum, then the first candidate within the tie tolerance of it (include/mssim.h)
+    Real best = raw[pts[0]].sep;
+    for (int i = 1; i < n; i++) best = std::min(best, raw[pts[i]].sep);
+    int i0 = -1;
+    for (int i = 0; i < n && i0 < 0; i++)
+      if (raw[pts[i]].sep <= best + Real(MSSIM_PATCH_TIE_SEP)) i0 = i;
     const Vec p0 = raw[pts[i0]].x;
-    int i1 = -1;
-    Real best = Real(-1);
-    for (int i = 0; i < n; i++) {
-      if (i == i0) continue;
-      const Vec d = raw[pts[i]].x - p0;
-      const Real v = dot(d, d);
-      if (v > best) { best = v; i1 = i; }
-    }
+    auto first_near_max = [&](auto&& value, auto&& allowed, Real floor_) {
+      Real mx = floor_;
+      for (int i = 0; i < n; i++)
+        if (allowed(i)) mx = std::max(mx, value(i));
+      if (!(mx > floor_)) return -1;
+      for (int i = 0; i < n; i++)
+        if (allowed(i) && value(i) >= mx - Real(MSSIM_PATCH_TIE_REL) * mx) return i;
+      return -1;
+    };
+    const int i1 = first_near_max([&](int i) { const Vec d = raw[pts[i]].x - p0; return dot(d, d); }, [&](int i) { return i != i0; }, Real(-1));
     const Vec ed = raw[pts[i1]].x - p0;
-    int i2 = -1;
-    best = Real(-1);
-    Real sgn2 = 0;
-    for (int i = 0; i < n; i++) {
-      if (i == i0 || i == i1) continue;
-      const Real ar = dot(cross(ed, raw[pts[i]].x - p0), na);
-      if (std::fabs(ar) > best) { best = std::fabs(ar); i2 = i; sgn2 = ar; }
-    }
-    int i3 = -1;
-    best = Real(0);
-    for (int i = 0; i < n; i++) {
-      if (i == i0 || i == i1 || i == i2) continue;
-      const Real ar = dot(cross(ed, raw[pts[i]].x - p0), na);
-      const Real v = sgn2 >= 0 ? -ar : ar;
-      if (v > best) { best = v; i3 = i; }
-    }
+    auto area = [&](int i) { return dot(cross(ed, raw[pts[i]].x - p0), na); };
+    const int i2 = first_near_max([&](int i) { return std::fabs(area(i)); }, [&](int i) { return i != i0 && i != i1; }, Real(-1));
+    const Real sgn2 = area(i2);
+    const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, Real(0));
     for (int i = 0; i < n; i++) keep[pts[i]] = (i == i0 || i == i1 || i == i2 || i == i3) ? 1 : 0;
   }
 }
@@ -291,7 +284,7 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
     collide(A, B, M.contact_offset, m);
     if (m.count <= 0) continue;
     hits++;
-    if ((int)raw.size() + m.count > MSSIM_MAX_RAW_POINTS) { E.overflow = 1; break; }
+    if ((int)raw.size() + m.count > MSSIM_MAX_RAW_POINTS) { E.overflow |= MSSIM_OVERFLOW_RAW; break; }
     Real mu = Real(0.5) * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
     man.push_back({(int)raw.size(), m.count, body_id(M.shape_kind[sa], M.shape_index[sa]) * 64 + body_id(M.shape_kind[sb], M.shape_index[sb]), m.n});
     for (int k = 0; k < m.count; k++) {
@@ -310,7 +303,7 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
   reduce_patches(man, raw, keep);
   for (size_t i = 0; i < raw.size(); i++) {
     if (!keep[i]) continue;
-    if ((int)out.size() >= MAXC) { E.overflow = 1; break; }
+    if ((int)out.size() >= MAXC) { E.overflow |= MSSIM_OVERFLOW_CONTACTS; break; }
     out.push_back(raw[i]);
     E.pair_count[raw[i].pair]++;
   }
@@ -962,7 +955,7 @@ int mssim_ref_profile_read(mssim_handle, float* ms, int32_t* cnt) { ms[0] = ms[1
 
 int mssim_ref_overflow_count(mssim_handle h, void*) {
   int c = 0;
-  for (auto& E : h->env) { c += E.overflow; E.overflow = 0; }
+  for (auto& E : h->env) { c += E.overflow != 0; E.overflow = 0; }
   return c;
 }
 
