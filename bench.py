@@ -40,21 +40,46 @@ import torch  # noqa: E402
 
 ALG_BYTES_PER_ENV_STEP = 1332  # 192 B read + 1140 B written per env-step (f32)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round1", "pmc_summary.json")  # separate --pmc passes, see scripts/summarize_pmc.py
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, a wave64 VALU instruction issues over 2 cycles of a SIMD-32 at 2.4 GHz
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2
+PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")  # separate --pmc passes of this same command, scripts/collect_profiles.py
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-    same command (counters cannot be collected from inside the process); None if not collected"""
+def kernel_source_sha():
+    """identity of the kernels a counter summary belongs to: sha256 over the HIP sources + the ABI header (the same on
+    this box and wherever the counters were collected; a rebuilt .so is not byte-stable)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "maniskill_amd", "csrc")
+    for p in sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, "include", "mssim.h")]:
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kernel_key):
+    """(HBM bytes, wave-VALU instructions) per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (counters cannot be collected from inside the process). Both None unless the summaries were collected on exactly
+    the kernel sources that are running now -- a stale number is not reported."""
+    traffic = valu = None
     try:
-        with open(PMC_SUMMARY) as f:
-            kernels = json.load(f)["kernels"]
-        for name, v in kernels.items():  # template arguments vary (k_solve16<true, 9>): match by prefix
-            if name.startswith(kernel_key):
-                return v["hbm_bytes_per_launch_raw"]
-        return None
+        with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha") == kernel_source_sha():
+            for name, v in d["kernels"].items():  # template arguments vary (k_solve16<9, 1>): match by prefix
+                if name.startswith(kernel_key):
+                    traffic = v["hbm_bytes_per_launch_raw"]
     except Exception:
-        return None
+        pass
+    try:
+        with open(os.path.join(PROFILE_DIR, "sq_counters.json")) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha") == kernel_source_sha():
+            valu = d["counters"]["SQ_INSTS_VALU"]["per_launch"]
+    except Exception:
+        pass
+    return traffic, valu
 
 
 
@@ -104,20 +129,38 @@ def cpu_baseline(seconds_budget=20.0):
     dt = time.perf_counter() - t0
     env.close()
     cores = int(os.environ.get("OMP_NUM_THREADS", HOST_CORES))
-    return dict(
+    out = dict(
         value=round(k * n / dt, 1),
         unit="env-steps/s",
         cores=cores,
         kind="port",
         sample=f"PickCube-v1 env.step loop, {n} envs x {k} control steps (5 substeps), in-repo f32 CPU oracle (OpenMP over envs) behind the same env layer",
     )
+    out["config1"] = cpu_config1()
+    return out
+
+
+def cpu_config1(steps=2500):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case (gpu_sim.py:71-85): 4 worker processes x 1 env
+    of PushCube-v1, state obs, step-only -- on the in-repo CPU restatement (the reference's SAPIEN CPU PhysX is absent).
+    Child processes of scripts/cpu_config1.py; they never open the GPU."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_config1.py"), str(steps), "4"], capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return dict(value=d["env_steps_per_s"], unit="env-steps/s", cores=d["processes"], kind="port",
+                    sample=f"PushCube-v1 (panda_wristcam), 4 processes x 1 env x {steps} control steps (5 substeps), in-repo f32 CPU oracle, one thread per process")
+    except Exception as ex:
+        return dict(value=None, unit="env-steps/s", cores=0, kind="port", sample=f"unavailable: {type(ex).__name__}: {ex}")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000, help="timed control steps (the reference harness times 1000, gpu_sim.py:96-106)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed control steps before the timed region (the reference: reset, 1 step, reset, gpu_sim.py:91-93)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--control-freq", type=int, default=20, help="sim_freq is 100: 20 -> 5 substeps (reference default), 25 -> 4")
     ap.add_argument("--env-id", default="PickCube-v1")
@@ -135,16 +178,22 @@ def main():
 
     from maniskill_amd import native
 
-    if not os.path.exists(native.NATIVE_LIB_PATH) and int(os.environ.get("LOCAL_RANK", 0)) == 0:
+    # rank 0 (re)builds a missing or stale library (hipcc is on the GPU box too; the build moves the finished file into
+    # place, so nobody dlopens a partial one), the other ranks wait for its marker before they load it
+    marker = os.path.join(os.path.dirname(native.NATIVE_LIB_PATH), f".built.{os.environ.get('MASTER_PORT', '0')}.{os.getppid()}")
+    if int(os.environ.get("LOCAL_RANK", 0)) == 0:
         import __graft_entry__
 
-        __graft_entry__.build()  # fresh checkout: hipcc is on the GPU box too
-    for _ in range(600):  # other ranks wait for rank 0's build
-        if os.path.exists(native.NATIVE_LIB_PATH):
-            break
-        time.sleep(0.5)
+        __graft_entry__.build()
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            open(marker, "w").close()
+    else:
+        for _ in range(1200):
+            if os.path.exists(marker):
+                break
+            time.sleep(0.5)
 
-    from maniskill_amd.distributed import RolloutGather, shard_seeds, world_info
+    from maniskill_amd.distributed import RolloutGather, set_env_index_offset, shard_seeds, world_info
 
     rank, local_rank, world = world_info()
     if world != args.gpus:
@@ -165,29 +214,45 @@ def main():
     substeps = 100 // args.control_freq
     global_seeds = [2022 + i for i in range(n * world)]
     torch.manual_seed(2022 + rank)  # reproducible action stream (A/B comparisons between builds)
+    set_env_index_offset(rank * n)  # this rank holds envs [rank * n, (rank + 1) * n) of the global run
     env = gym.make(args.env_id, num_envs=n, sim_backend=f"cuda:{local_rank}", sim_config=dict(control_freq=args.control_freq))
     base = env.unwrapped
     seeds = shard_seeds(global_seeds, rank, world)
     obs, _ = env.reset(seed=seeds)
-    gather = RolloutGather(n, obs.shape[1], dev, chunk=args.gather_every) if (world > 1 and args.gather and not args.no_gather) else None
-    for _ in range(args.warmup):
-        o, r, te, tr, _ = env.step(2 * torch.rand((n, 8), device=dev) - 1)
-        if gather is not None:
-            gather.add(o, r, te | tr)
-    if gather is not None:
-        gather.flush()
-        gather.result()
-    env.reset(seed=seeds)
+    # N > 1: two timed regions of K steps each, back to back -- (1) the env path as it is (no collective: `value`),
+    # (2) the centralised-learner exchange of BASELINE config 4 on top (RCCL all-gather of obs / reward / done over xGMI
+    # in rollout chunks: `gathered`). `--gather` makes (2) the headline instead; `--no-gather` skips (2).
+    gather = RolloutGather(n, obs.shape[1], dev, chunk=args.gather_every) if (world > 1 and not args.no_gather) else None
+
+    def warmup(g):
+        for _ in range(args.warmup):
+            o, r, te, tr, _ = env.step(2 * torch.rand((n, 8), device=dev) - 1)
+            if g is not None:
+                g.add(o, r, te | tr)
+        if g is not None:
+            g.flush()
+            g.result()
+        env.reset(seed=seeds)
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     px = base.scene.px
+    warmup(None)
     px.profile_enable(True)
-    elapsed = timed_steps(env, args.steps, gather, barrier)
+    elapsed = max_over_ranks(timed_steps(env, args.steps, None, barrier))
     prof = px.profile_read()
     px.profile_enable(False)
     overflow = px.overflow_count()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed_gathered = None
+    if gather is not None:
+        warmup(gather)
+        elapsed_gathered = max_over_ranks(timed_steps(env, args.steps, gather, barrier))
+        if args.gather:
+            elapsed, elapsed_gathered = elapsed_gathered, elapsed
 
     if rank == 0:
         total_envs = n * world
@@ -195,15 +260,11 @@ def main():
         solve_ms, solve_n = prof["solve"]
         narrow_ms, narrow_n = prof["narrow"]
         avg_solve_s = (solve_ms / max(solve_n, 1)) * 1e-3
-        fused = narrow_n == 0 and solve_n == args.steps  # k_solve16<FUSED>: one launch = n envs x one control step
-        alg_bytes_per_launch = ALG_BYTES_PER_ENV_STEP * n / (1 if fused else substeps)
-        if fused:
-            kernel_name, kernel_key = f"k_solve16<FUSED, NDOF, TASK> (whole env.step in one launch: action map, {substeps} substeps incl. narrowphase, copy-out, task epilogue; 16 lanes/env)", "k_solve16<true"
-        elif (px.model.n_dof + 6 * px.model.n_free) <= 16 and os.environ.get("MSSIM_SOLVER") != "lane":
-            kernel_name, kernel_key = "k_solve16 (one substep, 16 lanes/env; narrowphase in k_narrow)", "k_solve16<false"
-        else:
-            kernel_name, kernel_key = "k_solve (one env per lane)", "k_solve"
+        assert solve_n == args.steps and narrow_n == 0, (solve_n, narrow_n)  # one launch = n envs x one control step
+        alg_bytes_per_launch = ALG_BYTES_PER_ENV_STEP * n
+        kernel_name, kernel_key = f"k_solve16<NDOF, TASK> (whole env.step in one launch: action map, {substeps} substeps incl. narrowphase + contact patches, copy-out, task epilogue; 16 lanes/env)", "k_solve16<"
         achieved = alg_bytes_per_launch / avg_solve_s / 1e9 if avg_solve_s > 0 else 0.0
+        traffic, valu_insts = committed_counters(kernel_key)
         out = {
             "metric": "env-steps/sec (whole node), PickCube-v1 state-obs 4096 envs/GPU",
             "value": round(value, 1),
@@ -222,7 +283,7 @@ def main():
                 "15+1 solver iterations, random actions 2*U-1, no resets inside the timed region",
                 "envs_per_gpu": n,
                 "substeps": substeps,
-                "parallelism": f"env-sharded x{world}, no collective on the env path" + (f"; centralised-learner mode: one packed RCCL all-gather of obs/reward/done per {args.gather_every} control steps (asynchronous, overlaps the next chunk)" if gather is not None else ""),
+                "parallelism": f"env-sharded x{world}" + (", headline = centralised-learner mode (all-gather inside the timed region)" if (args.gather and gather is not None) else ", no collective on the env path"),
                 "solver_overflow_envs": overflow,
             },
             "roofline": {
@@ -232,13 +293,31 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(kernel_key),
+                "traffic": traffic,
+                "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in profiles/round2/pmc_summary.json, reported only for kernel sources {kernel_source_sha()}",
                 "avg_kernel_ms": round(avg_solve_s * 1e3, 4),
                 "launches": solve_n,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "narrowphase_avg_kernel_ms": None if fused else round(narrow_ms / max(narrow_n, 1), 4),
+            },
+            # the bound that applies (neither HBM nor MFMA): vector-instruction issue
+            "roofline_valu": {
+                "bound": "valu-issue",
+                "achieved": None if valu_insts is None or avg_solve_s <= 0 else round(valu_insts / avg_solve_s / 1e12, 4),
+                "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e12,
+                "unit": "T wave-instructions/s",
+                "frac": None if valu_insts is None or avg_solve_s <= 0 else valu_insts / avg_solve_s / VALU_PEAK_WAVE_INSTS_PER_S,
+                "wave_valu_instructions_per_launch": valu_insts,
+                "source": "SQ_INSTS_VALU from profiles/round2/sq_counters.json (same source-hash rule) / HIP-event kernel time of this run",
             },
         }
+        if elapsed_gathered is not None:
+            other = "no collective" if args.gather else f"one packed RCCL all-gather of obs / reward / done per {args.gather_every} control steps (asynchronous, overlaps the next chunk), inside the timed region"
+            out["gathered" if not args.gather else "ungathered"] = {
+                "value": round(args.steps * total_envs / elapsed_gathered, 1),
+                "unit": "env-steps/s",
+                "ms_per_step": round(elapsed_gathered / args.steps * 1e3, 4),
+                "what": f"second timed region of {args.steps} steps in the same run: {other}",
+            }
         if world == 1 and not args.no_cpu_baseline:
             env.close()
             try:

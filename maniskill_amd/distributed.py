@@ -31,6 +31,23 @@ def shard_seeds(global_seeds: List[int], rank: int, world: int) -> List[int]:
     return list(global_seeds[a:b])
 
 
+# first global env index of the envs constructed in this process (0 = unsharded). BaseEnv's constructor performs its
+# own reset with the seeds 2022 + i (mani_skill/envs/sapien_env.py:303-309), and tasks such as PegInsertionSide build
+# per-env geometry from those seeds: a shard has to count i from its global offset to build the SAME envs the
+# single-process run of the global N builds.
+_ENV_INDEX_OFFSET = 0
+
+
+def set_env_index_offset(offset: int):
+    """call before gym.make on a rank that holds envs [offset, offset + num_envs) of a larger sharded run"""
+    global _ENV_INDEX_OFFSET
+    _ENV_INDEX_OFFSET = int(offset)
+
+
+def env_index_offset() -> int:
+    return _ENV_INDEX_OFFSET
+
+
 class StepGather:
     """All-gather of the step outputs (obs [n,D] f32, reward [n] f32, done [n] bool) of every rank.
 

@@ -137,9 +137,12 @@ class BaseEnv(gym.Env):
         self._sensors = dict()
 
         self._main_seed = None
-        self._set_main_rng([2022 + i for i in range(self.num_envs)])
+        from maniskill_amd.distributed import env_index_offset
+
+        first = 2022 + env_index_offset()  # (a shard of a multi-GPU run counts its envs from its global offset)
+        self._set_main_rng([first + i for i in range(self.num_envs)])
         self._elapsed_steps = torch.zeros(self.num_envs, device=self.device, dtype=torch.int32)
-        obs, _ = self.reset(seed=[2022 + i for i in range(self.num_envs)], options=dict(reconfigure=True))
+        obs, _ = self.reset(seed=[first + i for i in range(self.num_envs)], options=dict(reconfigure=True))
 
         self._init_raw_obs = common.to_cpu_tensor(obs)
         self._init_raw_state = common.to_cpu_tensor(self.get_state_dict())
@@ -389,7 +392,16 @@ class BaseEnv(gym.Env):
             self._reconfig_counter -= 1
         if self.agent is not None:
             self.agent.reset()
-        if seed is not None or self._enhanced_determinism:
+        if self._enhanced_determinism:
+            # every env draws from its own torch stream (seeded with its episode seed), as it does from its own numpy
+            # stream: env e gets the same episode in any batch, shard or partial reset
+            from maniskill_amd.envs.utils.randomization.per_env_torch import PerEnvTorchRNG
+
+            with torch.random.fork_rng():
+                torch.manual_seed(int(self._episode_seed[0]))
+                with PerEnvTorchRNG(self._episode_seed[common.to_numpy(env_idx)]):
+                    self._initialize_episode(env_idx, options)
+        elif seed is not None:
             with torch.random.fork_rng():
                 torch.manual_seed(int(self._episode_seed[0]))
                 self._initialize_episode(env_idx, options)

@@ -137,7 +137,10 @@ class PegInsertionSideEnv(BaseEnv):
             self.box.set_pose(Pose.create_from_pq(pos, quat))
 
             qpos = np.array([0.0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, -np.pi / 4, 0.04, 0.04])
-            qpos = self._episode_rng.normal(0, 0.02, (b, len(qpos))) + qpos
+            if self._enhanced_determinism:  # per-env streams (as TableSceneBuilder.initialize): env e draws the same in any batch / shard
+                qpos = self._batched_episode_rng[env_idx].normal(0, 0.02, len(qpos)) + qpos
+            else:
+                qpos = self._episode_rng.normal(0, 0.02, (b, len(qpos))) + qpos
             qpos[:, -2:] = 0.04
             self.agent.robot.set_qpos(qpos)
             self.agent.robot.set_pose(sapien.Pose([-0.615, 0, 0]))

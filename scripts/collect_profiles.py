@@ -5,7 +5,9 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out")
-dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "round1")
+dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "round2")
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha
 os.makedirs(dst, exist_ok=True)
 
 
@@ -45,7 +47,7 @@ for d in ("pmc_ic", "pmc_sq"):
     for k, (n, v) in agg.items():
         out[k] = dict(launches=n, per_launch=v / n)
 if out:
-    json.dump(dict(note="rocprofv3 --pmc, control-step kernel k_solve16<true, 9, TASK> (whole env.step), PickCube-v1 4096 envs, bench.py --steps 20 "
+    json.dump(dict(kernel_source_sha=kernel_source_sha(), note="rocprofv3 --pmc, control-step kernel k_solve16<9, TASK> (whole env.step), PickCube-v1 4096 envs, bench.py --steps 20 "
                         "--warmup 3; two passes (ICACHE+INSTS, SQ cycles); SQ_*_CYCLES / SQ_WAIT_* are quad-cycles summed over waves", counters=out),
               open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
 
@@ -54,7 +56,7 @@ p = os.path.join(src, "bench.json.log")
 if os.path.exists(p):
     d = json.loads([l for l in open(p) if l.startswith("{")][-1])
     ks = json.load(open(os.path.join(dst, "pmc_summary.json")))["kernels"]
-    key = [k for k in ks if k.startswith("k_solve16<true")]
+    key = [k for k in ks if k.startswith("k_solve16<")]
     if key:
         d["roofline"]["traffic"] = ks[key[0]]["hbm_bytes_per_launch_raw"]
     open(os.path.join(dst, "bench.json.log"), "w").write(json.dumps(d) + "\n")

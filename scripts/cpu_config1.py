@@ -56,5 +56,6 @@ if __name__ == "__main__":
         os.environ[k] = ""
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MSSIM_HOST_CORES", "16")))  # a 1-GPU box shares 16 cores
-    for procs in sorted({4, cores}):
+    counts = [int(a) for a in sys.argv[2:]] or sorted({4, cores})  # explicit process counts: bench.py asks for 4 only
+    for procs in counts:
         run(procs, steps)

@@ -1,13 +1,16 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, as MI355X_MICROARCH.md prescribes)
 -> profiles/<round>/pmc_summary.json with per-launch means for the simulation kernels.
 
-    python scripts/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round1/pmc_summary.json
+    python scripts/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round2/pmc_summary.json
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB. Caveat from the guide: on gfx950 FETCH_SIZE
 reads exactly 1/2 of the bytes of a wide (16 B/lane) coalesced stream and is uncalibrated for other
 access widths; these kernels issue 4-byte strided accesses, so the raw value is kept and the
 possible 2x under-count of the read side is stated next to it.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha
 
 fetch_dir, write_dir, out = sys.argv[1:4]
 res = collections.defaultdict(dict)
@@ -26,5 +29,5 @@ for d, key in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
             res[k]["launches_" + key] = n
 for k, v in res.items():
     v["hbm_bytes_per_launch_raw"] = 1024.0 * (v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0))
-json.dump(dict(note="raw rocprofv3 counters, KB; FETCH_SIZE may under-count reads by up to 2x on gfx950 (see MI355X_MICROARCH.md, HBM)", kernels=res), open(out, "w"), indent=1)
+json.dump(dict(kernel_source_sha=kernel_source_sha(), note="raw rocprofv3 counters, KB; FETCH_SIZE may under-count reads by up to 2x on gfx950 (see MI355X_MICROARCH.md, HBM)", kernels=res), open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -108,3 +108,75 @@ def test_two_rank_sharded_run_equals_single_process(tmp_path):
         obs, rew, *_ = e4.step(a[:4])
         assert torch.allclose(ro[0, i], obs, atol=1e-6) and torch.allclose(rr[0, i], rew, atol=1e-6)
     assert torch.isfinite(ro).all() and not torch.equal(ro[0], ro[1])
+
+
+WORKER_DET = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["MS_ROOT"])
+import torch.distributed as dist
+import maniskill_amd.envs
+import gymnasium as gym
+from maniskill_amd.distributed import StepGather, set_env_index_offset, shard_seeds, world_info
+from tests import oracle_backend as ob
+ob.register("f64", "oracle_f64_env")
+rank, local_rank, world = world_info()
+dist.init_process_group("gloo")
+n = 4
+seeds = shard_seeds([77 + 3 * i for i in range(n * world)], rank, world)
+set_env_index_offset(rank * n)
+env = gym.make(os.environ["MS_ENV"], num_envs=n, sim_backend="oracle_f64_env", enhanced_determinism=True)
+obs, _ = env.reset(seed=seeds)
+g = torch.Generator().manual_seed(1)
+acts = [2 * torch.rand(n * world, 8, generator=g) - 1 for _ in range(4)]
+gather = StepGather(n, obs.shape[1], "cpu")
+O0, _, _ = gather(obs, torch.zeros(n), torch.zeros(n, dtype=torch.bool))
+O0 = O0.clone()
+for i, a in enumerate(acts):
+    obs, rew, te, tr, _ = env.step(a[rank * n:(rank + 1) * n])
+    if i == 1:  # a partial reset in the middle: envs 1 and 2 of every shard start a new episode
+        obs, _ = env.reset(options=dict(env_idx=torch.tensor([1, 2])))
+O, R, D = gather(obs, rew, te | tr)
+if rank == 0:
+    torch.save(dict(obs0=O0, obs=O.clone(), rew=R.clone()), os.environ["MS_OUT"])
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run_det(tmp_path, env_id):
+    out = tmp_path / f"det_{env_id}.pt"
+    script = tmp_path / "worker_det.py"
+    script.write_text(WORKER_DET)
+    env = dict(os.environ, MS_ROOT=ROOT, MS_OUT=str(out), MS_ENV=env_id, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    subprocess.run(cmd, check=True, env=env, timeout=600)
+    return torch.load(out, weights_only=True)
+
+
+def test_sharded_run_is_env_wise_identical_under_enhanced_determinism(tmp_path):
+    """SURVEY.md 8e: env e lives on rank e // (N / G) and is seeded with the e-th entry of the global seed list. With
+    enhanced_determinism every env draws its episode from its own numpy AND torch streams, so BOTH shards of a 2-rank run
+    -- rank 1's envs 4..7 included -- equal the same envs of a single-process run of the global N: reset observations,
+    a partial reset in the middle and 4 control steps."""
+    import maniskill_amd.envs  # noqa: F401
+    import gymnasium as gym
+    from tests import oracle_backend as ob
+
+    ob.register("f64", "oracle_f64_env")
+    for env_id in ("PickCube-v1", "PegInsertionSide-v1"):
+        got = _run_det(tmp_path, env_id)
+        N, n = 8, 4
+        e = gym.make(env_id, num_envs=N, sim_backend="oracle_f64_env", enhanced_determinism=True)
+        obs0, _ = e.reset(seed=[77 + 3 * i for i in range(N)])
+        assert torch.equal(got["obs0"], obs0), (env_id, (got["obs0"] - obs0).abs().max())
+        assert not torch.equal(obs0[:n], obs0[n:])
+        g = torch.Generator().manual_seed(1)
+        acts = [2 * torch.rand(N, 8, generator=g) - 1 for _ in range(4)]
+        for i, a in enumerate(acts):
+            obs, rew, *_ = e.step(a)
+            if i == 1:
+                obs, _ = e.reset(options=dict(env_idx=torch.tensor([1, 2, n + 1, n + 2])))
+        assert torch.equal(got["obs"], obs), (env_id, (got["obs"] - obs).abs().max())
+        assert torch.equal(got["rew"], rew)
+        e.close()
