@@ -140,7 +140,10 @@ typedef struct mssim_model_desc {
   const int32_t* shape_row;      /* [n_shape] rigid_body_data row of the owning body, -1 = none   */
   const float* shape_frame;      /* [n_shape][7] shape frame in the body frame                    */
   const float* shape_param;      /* [n_shape][4] see MSSIM_SHAPE_*                                */
-  const float* shape_material;   /* [n_shape][4] static friction, dynamic friction, restitution, patch_radius */
+  const float* shape_material;   /* [n_shape][4] static friction, dynamic friction, restitution, torsional patch radius
+                                    (max of patch_radius / min_patch_radius, agents/robots/panda/panda.py:24-31): a contact
+                                    patch (MSSIM_PATCH_COS) between shapes with radius r > 0 gets a torsional friction row
+                                    about its normal, bounded by mu * r * (sum of the normal multipliers of the patch) */
   const int32_t* shape_hull;     /* [n_shape][2] hull_offset, hull_count (CONVEX only)            */
   const float* shape_bound;      /* [n_shape][4] bounding sphere: centre in shape frame, radius   */
   int32_t n_hull_verts;

@@ -961,6 +961,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       r[19] = fbits(d->shape_body_kind[s2]);
       r[20] = fbits(d->shape_body_index[s2]);
       r[21] = fbits((d->n_env_shape > 0) ? d->shape_env_slot[s2] : -1);
+      r[22] = d->shape_material[4 * s2 + 3];  // torsional patch radius
     }
     if ((rc = upload(S, sp.data(), sp.size(), &M.shape_pack))) { mssim_destroy(S); return rc; }
     S->h_dof_pack.assign(32 * (size_t)(n > 0 ? n : 1), 0.f);

@@ -59,7 +59,7 @@
 #define S16_ROWLEN 32
 #define S16_ROWS_GLB (3 * (MAXC - S16_REGC - S16_LDSC))  // global scratch rows per env (x S16_ROWLEN floats)
 // narrowphase scratch, overlays the union below the contact records
-#define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 pad
+#define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 torsional-radius
 #define S16_NP_SHP (S16_U)        // [28][20] world shape table
 #define S16_NP_HIT (S16_U + 560)  // [64] surviving pairs: pair | sa << 16 | sb << 24
 #define S16_NP_CNT (S16_U + 624)  // [64] manifold sizes (raw, before the patch reduction)
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // shape-local data of shapes c and c + 16 and the cull pairs of this lane (model constants,
       // fetched per substep rather than held in registers over the whole step)
       pose_t shF[2];
-      float shP[2][3], shBr[2], shMu[2];
+      float shP[2][3], shBr[2], shMu[2], shTr[2];
       f3 shBc[2], shH[2];
       unsigned shPk[2];
       int shSlot[2];
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         for (int k = 0; k < 2; k++) {
           const int s = c + 16 * k;
           shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
-          shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shBc[k] = f3{0, 0, 0}; shH[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
+          shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shTr[k] = 0.f; shBc[k] = f3{0, 0, 0}; shH[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
           if (s < M.n_shape) {
             float r[24];  // the shape's 96-byte constant record
             const float4* rp = reinterpret_cast<const float4*>(M.shape_pack + 24 * s);
@@ -600,6 +600,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
                      : f3{shP[k][1], shP[k][0], shP[k][0]};
             }
             shMu[k] = r[17];
+            shTr[k] = r[22];
             shSlot[k] = pose_slot(__float_as_int(r[19]), __float_as_int(r[20]));
             shPk[k] = (unsigned)ty | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
           }
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           o[10] = bcw.x; o[11] = bcw.y; o[12] = bcw.z; o[13] = shBr[k];
           o[14] = __uint_as_float(shPk[k]);
           o[15] = shMu[k];
-          o[16] = shH[k].x; o[17] = shH[k].y; o[18] = shH[k].z; o[19] = 0.f;
+          o[16] = shH[k].x; o[17] = shH[k].y; o[18] = shH[k].z; o[19] = shTr[k];
         }
       }
       __syncthreads();
@@ -888,7 +889,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         for (int i = c; i < nh; i += 16) {
           const int pk = hit_[i];
           const unsigned pa = __float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 14]), pb = __float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]);
-          key_[i] = (int)(((pa >> 10) & 31u) | (((pb >> 10) & 31u) << 8));
+          // bit 16: the manifold carries a torsional friction row (either shape has a patch radius)
+          const bool tors = fmaxf(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 19], L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 19]) > 0.f;
+          key_[i] = (int)(((pa >> 10) & 31u) | (((pb >> 10) & 31u) << 8)) | (tors ? 1 << 16 : 0);
         }
         __syncthreads();
         bool any_big = false;
@@ -896,10 +899,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           int anchor = i;
           const int ci = cnt_[i];
           if (ci > 0) {
-            const int ky = key_[i];
+            const int ky = key_[i] & 0xFFFF;
             const f3 ni = f3{L[S16_NP_HN + 3 * i], L[S16_NP_HN + 3 * i + 1], L[S16_NP_HN + 3 * i + 2]};
             for (int k = 0; k < i; k++) {
-              if (cnt_[k] > 0 && key_[k] == ky && dot(f3{L[S16_NP_HN + 3 * k], L[S16_NP_HN + 3 * k + 1], L[S16_NP_HN + 3 * k + 2]}, ni) >= MSSIM_PATCH_COS) { anchor = k; break; }
+              if (cnt_[k] > 0 && (key_[k] & 0xFFFF) == ky && dot(f3{L[S16_NP_HN + 3 * k], L[S16_NP_HN + 3 * k + 1], L[S16_NP_HN + 3 * k + 2]}, ni) >= MSSIM_PATCH_COS) { anchor = k; break; }
             }
           }
           keep_[i] = (anchor << 4) | ((1 << ci) - 1);
@@ -907,8 +910,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         __syncthreads();
         for (int a = c; a < nh; a += 16) {
           if ((keep_[a] >> 4) != a || cnt_[a] == 0) continue;
-          int total = 0;
-          for (int i = a; i < nh; i++) total += (keep_[i] >> 4) == a ? cnt_[i] : 0;
+          int total = 0, tflag = 0;
+          for (int i = a; i < nh; i++) {
+            const bool mem = (keep_[i] >> 4) == a;
+            total += mem ? cnt_[i] : 0;
+            tflag |= (mem && cnt_[i] > 0) ? (key_[i] >> 16) & 1 : 0;
+          }
+          key_[a] |= tflag << 17;  // bit 17 (anchors): the patch carries a torsional friction record
           if (total <= 4) continue;
           any_big = true;
           const f3 na = f3{L[S16_NP_HN + 3 * a], L[S16_NP_HN + 3 * a + 1], L[S16_NP_HN + 3 * a + 2]};
@@ -968,14 +976,39 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
         PH_ADD(9, __any(any_big) ? 1 : 0);
         __syncthreads();
-        // records, in pair order
+        // records in solver order: patch by patch (patches in the order of their anchors), inside a patch manifold by
+        // manifold (a manifold belongs to one patch: the points of a shape pair stay together), then the patch's
+        // torsional friction record if one of its shapes carries a patch radius (one solver block each,
+        // include/mssim.h shape_material). The lane of manifold i writes its points, the lane of an anchor the
+        // torsional record of its patch.
         int tot = 0;
         for (int i = c; i < nh; i += 16) {
-          const int mk = keep_[i] & 15;
+          const int wi = keep_[i];
+          const int mk = wi & 15, a = wi >> 4;
+          const bool is_anchor = a == i && cnt_[i] > 0;
           tot += __popc(mk);
-          if (mk == 0) continue;
-          int off = 0;
-          for (int j = 0; j < i; j++) off += __popc(keep_[j] & 15);
+          if (mk == 0 && !is_anchor) continue;
+          // slots before this manifold's points | before the end of its patch; patch-level torsion flags of the earlier patches
+          int off = 0, off_end = 0;
+          bool my_tors = false;
+          float my_tr = 0.f;
+          for (int j = 0; j < nh; j++) {
+            const int wj = keep_[j];
+            const int aj = wj >> 4, nj = __popc(wj & 15);
+            if (aj < a || (aj == a && j < i)) off += nj;
+            if (aj <= a) off_end += nj;
+            if (is_anchor && aj == a && cnt_[j] > 0 && ((key_[j] >> 16) & 1)) {
+              const int pkj = hit_[j];
+              my_tors = true;
+              my_tr = fmaxf(my_tr, fmaxf(L[S16_NP_SHP + S16_SHP * ((pkj >> 16) & 0xFF) + 19], L[S16_NP_SHP + S16_SHP * ((pkj >> 24) & 0xFF) + 19]));
+            }
+          }
+          // torsional records of the patches in front (bit 17 of their anchors' keys)
+          int tors_before = 0;
+          for (int a2 = 0; a2 < a; a2++) tors_before += (key_[a2] >> 17) & 1;
+          off += tors_before;
+          off_end += tors_before;
+          if (is_anchor && my_tors) tot += 1;
           const int pk = hit_[i];
           const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
           const float mu = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
@@ -991,11 +1024,19 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
               r[0] = nn.x; r[1] = nn.y; r[2] = nn.z;
               r[3] = P.x; r[4] = P.y; r[5] = P.z;
               r[6] = P.w - M.rest_offset;
-              r[7] = __int_as_float(pk & 0xFFFF);
+              r[7] = __int_as_float((pk & 0xFFFF) | (a << 16));  // pair | patch
               r[8] = __int_as_float(bodies);
               r[9] = mu;
             }
             off++;
+          }
+          if (is_anchor && my_tors && off_end < MAXC) {
+            float* r = L + S16_REC + S16_REC_LEN * off_end;
+            r[0] = nn.x; r[1] = nn.y; r[2] = nn.z;
+            r[3] = 0.f; r[4] = 0.f; r[5] = 0.f; r[6] = 0.f;
+            r[7] = __int_as_float((pk & 0xFFFF) | (a << 16) | (1 << 30));  // bit 30: torsional record
+            r[8] = __int_as_float(bodies);
+            r[9] = mu * my_tr;
           }
         }
         tot += __shfl_xor(tot, 8, 16); tot += __shfl_xor(tot, 4, 16); tot += __shfl_xor(tot, 2, 16); tot += __shfl_xor(tot, 1, 16);
@@ -1318,9 +1359,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       const f3 nrm = f3{rec[0], rec[1], rec[2]};
       const f3 x = f3{rec[3], rec[4], rec[5]};
       const float sep = rec[6];
-      const int p = __float_as_int(rec[7]);
+      const int pw = __float_as_int(rec[7]);
+      const bool tors = ck && ((pw >> 30) & 1);  // torsional friction block of the patch that ends just before it
+      const int p = pw & 0xFFFF;
+      const bool first = i == 0 || ((__float_as_int(L[S16_REC + S16_REC_LEN * (i - 1) + 7]) ^ pw) & 0x3F0000) != 0;  // first block of its patch
       const int bodies = __float_as_int(rec[8]);
-      const float mu = rec[9];
+      const float mu = tors ? 0.f : rec[9];
       // (one cross product and one normalisation: the helper axis is selected, not the result)
       const bool use_x = fabsf(nrm.x) < 0.57735f;
       const f3 t1 = normalized(cross(nrm, f3{use_x ? 1.f : 0.f, use_x ? 0.f : 1.f, 0.f}));
@@ -1335,8 +1379,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       for (int dk = 0; dk < 3; dk++) {
         const f3 d = dk == 0 ? nrm : (dk == 1 ? t1 : t2);
         const float J = sgn * dot(jaxis_c, sel3(jrot_c, cross(rx, d), d));
-        J3[dk] = ck ? J : 0.f;
+        J3[dk] = (ck && !tors) ? J : 0.f;
       }
+      // torsional block: row 0 = relative angular velocity about the normal (rotation-like components only), rows 1, 2 empty
+      if (tors) J3[0] = jrot_c ? sgn * dot(jaxis_c, nrm) : 0.f;
       // W = A^-1 J^T for the three directions: 16 DPP row rotations of J against the pre-rotated row
       rot_fma3(Irot, J3, W3);
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
@@ -1347,10 +1393,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (c == 0) {
         const float i0 = d0 > 1e-12f ? rcp_f(d0) : 0.f, i1 = d1 > 1e-12f ? rcp_f(d1) : 0.f, i2 = d2 > 1e-12f ? rcp_f(d2) : 0.f;
         float4* cs = reinterpret_cast<float4*>(L + S16_CS + 16 * i);
-        cs[0] = float4{i0, ck ? (sep >= 0.f ? sep * inv_dt : fmaxf(M.erp * sep * inv_dt, -M.max_depen)) : 0.f, ck ? (sep >= 0.f ? sep * inv_dt : 0.f) : 0.f, ck ? mu : 0.f};
+        const bool pt = ck && !tors;
+        cs[0] = float4{i0, pt ? (sep >= 0.f ? sep * inv_dt : fmaxf(M.erp * sep * inv_dt, -M.max_depen)) : 0.f, pt ? (sep >= 0.f ? sep * inv_dt : 0.f) : 0.f, pt ? mu : 0.f};
         cs[1] = float4{i1, g10 * i1, i2, g20 * i2};
         cs[2] = float4{g21 * i2, 0.f, 0.f, 0.f};
-        cs[3] = float4{__int_as_float(p), 0.f, 0.f, 0.f};
+        // torsional bound mu r (0 = contact block) | carry factor of the manifold's normal-multiplier sum (0 = first block)
+        cs[3] = float4{__int_as_float(pw), 0.f, tors ? rec[9] : 0.f, (ck && !first) ? 1.f : 0.f};
       }
     };
     float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
@@ -1405,13 +1453,21 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // (k10 = J1.W0 / d1, k20 = J2.W0 / d2, k21 = J2.W1 / d2) in scalar arithmetic. The dependent chain
     // per contact is jv0 -> nl0 -> nl1 -> nl2 -> v; everything that does not depend on the previous
     // multiplier of the block (a1, a2, the first two W updates) is computed off the chain.
+    // Torsional friction blocks (row 0 = spin about the normal, bounded by +-tmu * the sum of the normal multipliers of
+    // the manifold that ends just before the block) ride the same code: the clamp of row 0 is a median of three with
+    // the bounds [0, inf) for a contact and [-tmu acc, tmu acc] for a torsional block, `acc` the running sum of the
+    // current manifold (restarted by its first block: accmul = 0) -- nothing is added to the dependent chain.
+    float acc_n = 0.f;
     auto con_solve = [&](float J0, float W0, float J1, float W1, float J2, float W2, float& lam0, float& lam1, float& lam2,
-                         float4 s0, float4 sk, float k21, bool use_bias) __attribute__((always_inline)) {
+                         float4 s0, float4 sk, float k21, float tmu, float accmul, bool use_bias) __attribute__((always_inline)) {
       float jv0 = J0 * v_c, jv1 = J1 * v_c, jv2 = J2 * v_c;
       gsum16x3(jv0, jv1, jv2);
       const float a1 = fmaf(-jv1, sk.x, lam1);
       const float a2 = fmaf(-jv2, sk.z, lam2);
-      const float nl0 = fmaxf(fmaf(-(jv0 + (use_bias ? s0.y : s0.z)), s0.x, lam0), 0.f);
+      const bool tors = tmu > 0.f;
+      const float tb = tmu * acc_n;
+      const float nl0 = __builtin_amdgcn_fmed3f(fmaf(-(jv0 + (use_bias ? s0.y : s0.z)), s0.x, lam0), -tb, tors ? tb : 3e38f);
+      acc_n = fmaf(acc_n, accmul, tors ? 0.f : nl0);
       const float dl0 = nl0 - lam0;
       const float h = s0.w * nl0;
       const float nl1 = fminf(fmaxf(fmaf(-sk.y, dl0, a1), -h), h);
@@ -1425,6 +1481,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     struct ConRec {
       float J0, W0, J1, W1, J2, W2;
       float4 s0, sk, kl;  // (1/d0, bias pos, bias vel, mu), (1/d1, k10, 1/d2, k20), (k21, lam0, lam1, lam2)
+      float2 tq;          // (torsional bound factor, carry factor of the manifold's normal-multiplier sum)
     };
     auto con_load = [&](const float* row, int ci, ConRec& R) __attribute__((always_inline)) {
       R.J0 = row[c]; R.W0 = row[16 + c];
@@ -1432,9 +1489,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       R.J2 = row[64 + c]; R.W2 = row[80 + c];
       const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * ci);
       R.s0 = cs[0]; R.sk = cs[1]; R.kl = cs[2];
+      R.tq = *reinterpret_cast<const float2*>(L + S16_CS + 16 * ci + 14);
     };
     auto con_apply = [&](ConRec& R, int ci, bool use_bias) __attribute__((always_inline)) {
-      con_solve(R.J0, R.W0, R.J1, R.W1, R.J2, R.W2, R.kl.y, R.kl.z, R.kl.w, R.s0, R.sk, R.kl.x, use_bias);
+      con_solve(R.J0, R.W0, R.J1, R.W1, R.J2, R.W2, R.kl.y, R.kl.z, R.kl.w, R.s0, R.sk, R.kl.x, R.tq.x, R.tq.y, use_bias);
       if (c == 0) *reinterpret_cast<float4*>(L + S16_CS + 16 * ci + 8) = R.kl;  // (padding blocks rewrite their zeros)
     };
 #ifdef EXP_ITERS
@@ -1474,18 +1532,22 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // (one wave per SIMD: nothing else hides the LDS latency); slot k + 1 always exists in the table
       float4 ns0 = *reinterpret_cast<const float4*>(L + S16_CS), nsk = *reinterpret_cast<const float4*>(L + S16_CS + 4);
       float nk21 = L[S16_CS + 8];
+      float2 ntq = *reinterpret_cast<const float2*>(L + S16_CS + 14);
+      acc_n = 0.f;
 #pragma unroll
       for (int k = 0; k < S16_REGC; k++) {
         if (k < max_creg) {  // wave-uniform
           const float4 s0 = ns0, sk = nsk;
           const float k21 = nk21;
+          const float2 tq = ntq;
           if (k + 1 < S16_REGC) {
             const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * (k + 1));
             ns0 = cs[0]; nsk = cs[1];
             nk21 = L[S16_CS + 16 * (k + 1) + 8];
+            ntq = *reinterpret_cast<const float2*>(L + S16_CS + 16 * (k + 1) + 14);
           }
           float l0 = lamr[k][0], l1 = lamr[k][1], l2 = lamr[k][2];
-          con_solve(Jr[k][0], Wr[k][0], Jr[k][1], Wr[k][1], Jr[k][2], Wr[k][2], l0, l1, l2, s0, sk, k21, use_bias);
+          con_solve(Jr[k][0], Wr[k][0], Jr[k][1], Wr[k][1], Jr[k][2], Wr[k][2], l0, l1, l2, s0, sk, k21, tq.x, tq.y, use_bias);
           lamr[k][0] = l0; lamr[k][1] = l1; lamr[k][2] = l2;
         }
       }
@@ -1519,6 +1581,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const int ci = S16_REGC + S16_LDSC + k;
           const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * ci);
           R.s0 = cs[0]; R.sk = cs[1]; R.kl = cs[2];
+          R.tq = *reinterpret_cast<const float2*>(L + S16_CS + 16 * ci + 14);
           con_apply(R, ci, use_bias);
         };
         ConRec A, B, C;
@@ -1584,7 +1647,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       for (int i = 0; i < nc; i++) {
         const float l0 = L[S16_CS + 16 * i + 9], l1 = L[S16_CS + 16 * i + 10], l2 = L[S16_CS + 16 * i + 11];
         const float* rec = L + S16_REC + S16_REC_LEN * i;
-        const int p = __float_as_int(rec[7]);
+        const int pw = __float_as_int(rec[7]);
+        if ((pw >> 30) & 1) continue;  // torsional block: a pure torque, no part of the pair's force
+        const int p = pw & 0xFFFF;
         const f3 nrm = f3{rec[0], rec[1], rec[2]};
         const f3 t1 = fabsf(nrm.x) < 0.57735f ? normalized(cross(nrm, f3{1, 0, 0})) : normalized(cross(nrm, f3{0, 1, 0}));
         const f3 t2 = cross(nrm, t1);

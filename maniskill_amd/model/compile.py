@@ -430,7 +430,9 @@ class SceneModelBuilder:
             srow.append(s["row"])
             sframe.append(s["frame"])
             sparam.append(r.param())
-            smat.append([r.static_friction, r.dynamic_friction, r.restitution, r.patch_radius])
+            # [3]: torsional patch radius. PhysX scales `patch_radius` with the penetration and never goes below
+            # `min_patch_radius`; the reference sets both (0.1, panda.py:24-31), where the minimum rules: the larger one
+            smat.append([r.static_friction, r.dynamic_friction, r.restitution, max(r.patch_radius, r.min_patch_radius)])
             if r.type == "convex":
                 v = np.asarray(r.vertices, dtype=np.float64)
                 if len(v) > MAX_HULL_VERTS:

@@ -75,6 +75,12 @@ struct Contact {
   Vec x, n;
   Real sep, mu;
   Real lam[3];
+  // > 0 on the LAST contact of a manifold whose shapes carry a torsional patch radius: a torsional friction row about
+  // the normal follows it, bounded by tors_mu * (sum of the normal multipliers of the manifold's contacts, which start
+  // at contact `tors_first`)
+  Real tors_mu;
+  int tors_first;
+  Vec tors_n;  // the patch anchor's normal
 };
 
 struct EnvState {
@@ -211,10 +217,10 @@ inline int body_id(int kind, int index) {
 // it, and the points of largest area on either side of that edge (measured about the anchor's normal) -- first
 // candidate wins ties, as in the box-box manifold. keep[i] = 1 for the surviving raw contacts.
 struct RawManifold { int first, count, key; Vec n; };
-void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Contact>& raw, std::vector<char>& keep) {
+void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Contact>& raw, std::vector<char>& keep, std::vector<int>& anchor) {
   const int nm = (int)man.size();
   keep.assign(raw.size(), 1);
-  std::vector<int> anchor(nm);
+  anchor.assign(nm, 0);
   for (int i = 0; i < nm; i++) {
     anchor[i] = i;
     for (int k = 0; k < i; k++)
@@ -294,18 +300,48 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
       c.kb = M.shape_kind[sb]; c.ib = M.shape_index[sb];
       c.x = m.x[k]; c.n = m.n; c.sep = m.sep[k] - M.rest_offset; c.mu = mu;
       c.lam[0] = c.lam[1] = c.lam[2] = 0;
+      c.tors_mu = 0; c.tors_first = -1; c.tors_n = Vec();
       raw.push_back(c);
     }
   }
   (void)hits;
   E.raw_points = (int)raw.size();
   std::vector<char> keep;
-  reduce_patches(man, raw, keep);
-  for (size_t i = 0; i < raw.size(); i++) {
-    if (!keep[i]) continue;
-    if ((int)out.size() >= MAXC) { E.overflow |= MSSIM_OVERFLOW_CONTACTS; break; }
-    out.push_back(raw[i]);
-    E.pair_count[raw[i].pair]++;
+  std::vector<int> anchor;
+  reduce_patches(man, raw, keep, anchor);
+  // Solver order: patch by patch (patches in the order of their anchors), inside a patch manifold by manifold -- a
+  // manifold belongs to one patch, so the points of a shape pair stay together.
+  // Torsional friction (mani_skill/agents/robots/panda/panda.py:24-31: patch_radius = min_patch_radius = 0.1 on the finger
+  // links; shape_material[3] = the larger of the two): a patch whose shapes carry a radius r > 0 resists spinning about
+  // its (anchor's) normal with a torque of up to mu * r * (its normal force) -- one extra solver row per patch, which
+  // takes one of the MAXC contact slots.
+  int slots = 0;
+  bool full = false;
+  for (int a = 0; a < (int)man.size() && !full; a++) {
+    if (anchor[a] != a) continue;
+    const int first = (int)out.size();
+    Real rt = 0;
+    for (int i = a; i < (int)man.size() && !full; i++) {
+      if (anchor[i] != a) continue;
+      const int p = raw[man[i].first].pair;
+      rt = std::max(rt, (Real)std::max(M.shape_material[4 * M.pair_shape[2 * p] + 3], M.shape_material[4 * M.pair_shape[2 * p + 1] + 3]));
+      for (int k = 0; k < man[i].count && !full; k++) {
+        const int ri = man[i].first + k;
+        if (!keep[ri]) continue;
+        if (slots >= MAXC) { E.overflow |= MSSIM_OVERFLOW_CONTACTS; full = true; break; }
+        out.push_back(raw[ri]);
+        out.back().n = raw[ri].n;
+        slots++;
+        E.pair_count[p]++;
+      }
+    }
+    if (!full && rt > 0 && (int)out.size() > first) {
+      if (slots >= MAXC) { E.overflow |= MSSIM_OVERFLOW_CONTACTS; full = true; break; }
+      slots++;
+      out.back().tors_mu = raw[man[a].first].mu * rt;
+      out.back().tors_first = first;
+      out.back().tors_n = man[a].n;
+    }
   }
 }
 
@@ -339,6 +375,7 @@ struct Row {
   Vec Jl[2], Jw[2], Wl[2], Ww[2];
   Real diag, bias_pos, bias_vel, lo, hi, lam;
   int friction_of;  // index of the normal row bounding this friction row, -1 otherwise
+  std::vector<int> tors_of;  // torsional row: the normal rows of its manifold (bound = mu * sum of their multipliers)
   Real mu;
   int contact, dirk;  // contact index / direction (0 n, 1 t1, 2 t2), -1 for limits
 };
@@ -516,8 +553,10 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     rows.push_back(r);
   }
   const size_t n_limit_rows = rows.size();
+  std::vector<int> contact_row(contacts.size(), -1);  // normal row of every contact
   for (size_t ci = 0; ci < contacts.size(); ci++) {
     Contact& c = contacts[ci];
+    contact_row[ci] = (int)rows.size();
     Vec nrm = c.n;
     Vec t1 = std::fabs(nrm.x) < Real(0.57735) ? normalized(cross(nrm, Vec(1, 0, 0))) : normalized(cross(nrm, Vec(0, 1, 0)));
     Vec t2 = cross(nrm, t1);
@@ -563,6 +602,45 @@ void substep(mssim_sim* S, EnvState& E, int e) {
       }
       rows.push_back(r);
     }
+    if (c.tors_mu > 0) {
+      // torsional friction row of the manifold that ends with this contact: relative angular velocity about the normal
+      Row r;
+      r.Ja.assign(n, 0); r.Wa.assign(n, 0);
+      r.f[0] = r.f[1] = -1;
+      int nfree = 0;
+      bool hasart = false;
+      const int kinds[2] = {c.ka, c.kb}, idx[2] = {c.ia, c.ib};
+      for (int s = 0; s < 2; s++) {
+        Real sign = s == 0 ? Real(1) : Real(-1);
+        if (kinds[s] == MSSIM_BODY_ART && idx[s] >= 0) {
+          for (int i = idx[s]; i >= 0; i = M.dof_parent[i])
+            if (M.dof_type[i] == MSSIM_JOINT_REVOLUTE) r.Ja[i] += sign * dot(c.tors_n, axis_w[i]);
+          hasart = true;
+        } else if (kinds[s] == MSSIM_BODY_FREE) {
+          int b = idx[s];
+          r.f[nfree] = b;
+          r.Jl[nfree] = Vec();
+          r.Jw[nfree] = c.tors_n * sign;
+          r.Wl[nfree] = Vec();
+          r.Ww[nfree] = fIinv[b] * r.Jw[nfree];
+          nfree++;
+        }
+      }
+      Real diag = 0;
+      if (hasart)
+        for (int i = 0; i < n; i++) {
+          Real w = 0;
+          for (int j = 0; j < n; j++) w += Ainv[i * n + j] * r.Ja[j];
+          r.Wa[i] = w;
+          diag += r.Ja[i] * w;
+        }
+      for (int s = 0; s < nfree; s++) diag += dot(r.Jw[s], r.Ww[s]);
+      r.diag = diag;
+      r.lam = 0; r.contact = -2; r.dirk = -1; r.mu = c.tors_mu;
+      r.bias_pos = r.bias_vel = 0; r.lo = r.hi = 0; r.friction_of = -1;
+      for (size_t cj = (size_t)c.tors_first; cj <= ci; cj++) r.tors_of.push_back(contact_row[cj]);
+      rows.push_back(r);
+    }
   }
 
   // 5. PGS
@@ -580,6 +658,11 @@ void substep(mssim_sim* S, EnvState& E, int e) {
         if (r.f[s] >= 0) jv += dot(r.Jl[s], fv[r.f[s]]) + dot(r.Jw[s], fw[r.f[s]]);
       Real lo = r.lo, hi = r.hi;
       if (r.friction_of >= 0) { hi = r.mu * rows[r.friction_of].lam; lo = -hi; }
+      if (!r.tors_of.empty()) {
+        Real nsum = 0;
+        for (int k2 : r.tors_of) nsum += rows[k2].lam;
+        hi = r.mu * nsum; lo = -hi;
+      }
       Real b = use_bias ? r.bias_pos : r.bias_vel;
       Real nl = r.lam - (jv + b) / r.diag;
       nl = nl < lo ? lo : (nl > hi ? hi : nl);

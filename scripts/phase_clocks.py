@@ -24,9 +24,9 @@ env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
 buf = (ctypes.c_ulonglong * 32)()
 names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row build", "PGS", "pair impulses", "writeback+FK",
-         "tail: copy-out + task epilogue", "(unused)", "np: task setup (shapes from LDS)", "np: plane", "np: box-box", "np: coop box-box",
+         "tail: copy-out + task epilogue", "#launches with a patch > 4 points", "np: task setup (shapes from LDS)", "np: plane", "np: box-box (one lane per pair)", "np: stage A rounds (plane / one-lane box-box) + staging",
          "#coop MPR task slots (max over groups)", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
-         "contacts -> LDS records (narrowphase)", "np: shape table", "np: cull", "np: plane/box-box rounds + record writes", "np: coop MPR",
+         "np: contact patches + records", "np: shape table", "np: cull", "np: coop box-box (stage C)", "np: coop MPR (stage B)",
          "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
 for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" % steps, steps)):
     torch.cuda.synchronize()
@@ -36,7 +36,7 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
     tot = sum(buf[i] for i in range(32))
-    launches = k * (1 if os.environ.get('MSSIM_SOLVER', 'fused') == 'fused' else 5)
+    launches = k
     blocks = (N + 3) // 4
     print(f"{env_id} N={N} {phase_name}: {tot / launches / blocks:.0f} cycles per block-launch")
     for i, nm in enumerate(names):

@@ -286,3 +286,63 @@ def test_fast_spinning_thin_body_stays_bounded():
         assert abs(float(s[0, 3:7].norm()) - 1.0) < 1e-4
         assert float(s[0, 10:13].norm()) < 1.5 * 100.0  # the limit bounds what a substep starts from; one explicit step may overshoot a little
     assert float(s[0, :3].sub(torch.tensor([0.0, 0.0, 5.0])).norm()) < 1e-4  # no force: the centre does not move
+
+
+def _sphere_on_ground(patch_radius):
+    b = SceneModelBuilder()
+    b.add_actor(ground_record(altitude=0.0))
+    b.add_actor(ActorRecord("ball", "dynamic", [ShapeRecord("sphere", geom.pose(), radius=0.05, patch_radius=patch_radius, min_patch_radius=patch_radius)],
+                            initial_pose=geom.pose([0, 0, 0.05])))
+    return b.compile()
+
+
+def test_torsional_friction_spins_a_ball_down():
+    """A ball spinning about the vertical on a plane touches it in one point on the spin axis: the tangential friction rows
+    have no lever arm, only the torsional row of a shape with a patch radius r (agents/robots/panda/panda.py:24-31) brakes
+    the spin, at the constant rate mu r m g / I = mu r g / (0.4 R^2) until it stops; without a patch radius it spins on."""
+    R, mu, g = 0.05, 0.3, 9.81
+    for r_patch in (0.0, 0.01):
+        model = _sphere_on_ground(r_patch)
+        px = ob.make_system(model, 1)
+        row = model.row_of("ball")
+        s = px.cuda_rigid_body_data.torch()[row : row + 1]
+        s[:, 12] = 10.0  # spin about z
+        px.gpu_apply_all()
+        px.step(10)
+        px.gpu_fetch_all()
+        w10 = px.cuda_rigid_body_data.torch()[row, 12].item()
+        px.step(60)
+        px.gpu_fetch_all()
+        w70 = px.cuda_rigid_body_data.torch()[row, 12].item()
+        z = px.cuda_rigid_body_data.torch()[row, 2].item()
+        assert abs(z - R) < 1e-3
+        if r_patch == 0.0:
+            assert abs(w10 - 10.0) < 1e-3 and abs(w70 - 10.0) < 1e-2
+        else:
+            alpha = mu * r_patch * g / (0.4 * R * R)  # 29.4 rad/s^2
+            assert abs(w10 - (10.0 - alpha * 0.1)) < 0.05 * alpha * 0.1 + 0.02, w10
+            assert abs(w70) < 1e-3, w70  # stopped (after 0.34 s) and held: the row is bilateral inside its bound
+
+
+def test_contact_patches_cut_a_compound_body_to_four_points():
+    """two boxes of ONE body side by side on the table give 8 manifold points with one normal: the body-pair patch keeps
+    4 (the extreme ones), the body rests exactly as before; a body whose two boxes touch a floor and a wall keeps both
+    patches (normals 90 degrees apart)"""
+    half = np.array([0.02, 0.02, 0.02])
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(ActorRecord("twin", "dynamic", [ShapeRecord("box", geom.pose([-0.03, 0, 0]), half_size=half), ShapeRecord("box", geom.pose([0.03, 0, 0]), half_size=half)],
+                            initial_pose=geom.pose([0, 0, 0.02])))
+    model = b.compile()
+    px = ob.make_system(model, 1)
+    px.step(100)
+    px.gpu_fetch_all()
+    row = model.row_of("twin")
+    s = px.cuda_rigid_body_data.torch()[row]
+    assert abs(s[2].item() - 0.02) < 1e-4 and torch.max(torch.abs(s[7:13])) < 1e-3
+    assert int(px.read_internal("raw_contact_count", 1)[0, 0]) == 8
+    cnt = px.read_internal("contact_count", model.n_pair)
+    assert int(cnt.sum()) == 4
+    # the four survivors span the whole footprint: x from -0.05 to 0.05 (not one box's 4 corners)
+    assert (cnt > 0).sum() == 2
