@@ -50,6 +50,9 @@ extern "C" {
  * current pose (a pseudo-inverse IK step next to a singular arm configuration asks for tens of radians) accelerate
  * the arm until the explicitly integrated velocity-product terms diverge. */
 #define MSSIM_MAX_JOINT_VELOCITY 100.0f
+/* PxSceneDesc::wakeCounterResetValue (PhysX default 20 * 0.02 s): how long the energy of a free body has to stay below
+ * sleep_threshold before it is put to sleep */
+#define MSSIM_WAKE_TIME 0.4f
 #define MSSIM_MAX_DOF 16        /* max articulation degrees of freedom per env            */
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
@@ -164,7 +167,11 @@ typedef struct mssim_model_desc {
   int32_t velocity_iterations;   /* 1                                                             */
   float erp;                     /* fraction of penetration removed per substep by the bias       */
   float max_depenetration_velocity;
-  float sleep_threshold;         /* reserved (0.005)                                              */
+  float sleep_threshold;         /* 0.005 (types.py:39): a free body whose mass-normalised kinetic energy 0.5 (v^2 + w.Iw/m)
+                                    stays below it for MSSIM_WAKE_TIME seconds, without a moving partner in range, goes to
+                                    sleep: zero velocity, out of the solver, its contacts with fixed bodies dropped. It wakes
+                                    when an awake moving body comes into range of one of its shape pairs (cull level), when
+                                    the user writes a different pose / velocity or a force for it (apply). 0 = never sleeps */
 
   /* ---- per-env geometry overrides (ABI v2): same shape types in every env, different sizes /
    *      local poses / inertias -- the reference builds such actors per sub-scene and merges them
@@ -242,6 +249,10 @@ int MSSIM_FN(fetch)(mssim_handle h, uint32_t what, void* stream);
 int MSSIM_FN(defer_fetch)(mssim_handle h, uint32_t what);
 /* px.step() x n_substeps (scene.py:374-375; loop at sapien_env.py:1016-1021).  No host sync. */
 int MSSIM_FN(step)(mssim_handle h, int32_t n_substeps, void* stream);
+/* Wake every sleeping free body (PxRigidDynamic::wakeUp for all of them; see sleep_threshold): the sleep counters are
+ * simulation state that `rigid_body_data` does not carry, so a caller that restores a state and wants the run that
+ * follows to depend on that state alone (BaseEnv.set_state_dict, envs/sapien_env.py:1167-1179) calls this after apply. */
+int MSSIM_FN(wake_all)(mssim_handle h, void* stream);
 /* px.gpu_update_articulation_kinematics() (sapien_env.py:861-865) */
 int MSSIM_FN(update_kinematics)(mssim_handle h, void* stream);
 /* px.gpu_create_contact_pair_impulse_query (scene.py:769-772): body_pairs = [n_pairs][2]

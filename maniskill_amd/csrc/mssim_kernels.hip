@@ -43,7 +43,7 @@ struct DevModel {
   // per-env overrides ([items][N], env fastest); slot < 0 = shared value
   const int *shape_env_slot, *free_env_slot;
   const float *env_shape_frame, *env_shape_param, *env_shape_bound, *env_free_inertial;
-  float gx, gy, gz, dt, contact_offset, rest_offset, erp, max_depen;
+  float gx, gy, gz, dt, contact_offset, rest_offset, erp, max_depen, sleep_threshold;
   int pos_iters, vel_iters;
 };
 
@@ -51,6 +51,7 @@ struct DevState {
   int N;
   float *root, *q, *qd, *qt, *qdt, *qf, *qacc;  // [7][N], [n_dof][N] ...
   float *free_s, *free_force, *kin;             // [n_free*13][N], [n_free*3][N], [n_kin*7][N]
+  float* free_wake;                             // [n_free][N] seconds of low energy left before the body sleeps; <= 0: asleep
   float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
   float* bodyaux;                               // [n_dof*6][N] world joint axis (3) + joint anchor (3)
   int* pair_cnt;                                // [n_pair][N] contact points of the pair in the last substep (after the patch reduction)
@@ -254,7 +255,12 @@ __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) 
   if ((what & MSSIM_RIGID_DATA) && B.rigid_body_data) {
     for (int b = 0; b < M.n_free; b++) {
       const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
+      // a row that differs from what the last fetch wrote wakes the body (include/mssim.h sleep_threshold)
+      bool changed = false;
+      for (int c = 0; c < 13; c++) changed = changed || r[c] != SOA(S.free_s, 13 * b + c);
+      if (!changed) continue;
       for (int c = 0; c < 13; c++) SOA(S.free_s, 13 * b + c) = r[c];
+      SOA(S.free_wake, b) = MSSIM_WAKE_TIME;
     }
     for (int k = 0; k < M.n_kin; k++) {
       const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
@@ -274,6 +280,7 @@ __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) 
     for (int b = 0; b < M.n_free; b++) {
       const float* f = B.rigid_body_force + 4 * ((size_t)(M.n_link + b) * N + e);
       for (int c = 0; c < 3; c++) SOA(S.free_force, 3 * b + c) = f[c];
+      if (f[0] != 0.f || f[1] != 0.f || f[2] != 0.f) SOA(S.free_wake, b) = MSSIM_WAKE_TIME;
     }
 }
 
@@ -750,6 +757,10 @@ __global__ void k_link_jacobian(DevModel M, DevState S, int link, float* __restr
   }
 }
 
+__global__ void k_fill(float* dst, float v, size_t count) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = v;
+}
 __global__ void k_i2f(const int* src, float* dst, size_t count) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < count) dst[i] = (float)src[i];
@@ -997,6 +1008,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   M.gx = d->gravity[0]; M.gy = d->gravity[1]; M.gz = d->gravity[2];
   M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
   M.max_depen = d->max_depenetration_velocity; M.pos_iters = d->position_iterations; M.vel_iters = d->velocity_iterations;
+  M.sleep_threshold = d->sleep_threshold;
   S->panda = (n == 9);
   for (int j = 0; j < n && S->panda; j++)
     if (d->dof_parent[j] != kPandaParent[j] || d->dof_type[j] != kPandaType[j]) S->panda = false;
@@ -1005,7 +1017,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   const size_t N = (size_t)num_envs;
 #define AL(field, count) if ((rc = dalloc(S, (size_t)(count) * N, &D.field))) { mssim_destroy(S); return rc; }
   AL(root, 7) AL(q, n) AL(qd, n) AL(qt, n) AL(qdt, n) AL(qf, n) AL(qacc, n)
-  AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin)
+  AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin) AL(free_wake, d->n_free)
   AL(bodypose, 7 * n) AL(bodyvel, 6 * n) AL(bodyaux, 6 * n)
   AL(pair_cnt, d->n_pair) AL(pair_imp, 3 * d->n_pair)
   if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN, &D.rows))) { mssim_destroy(S); return rc; }
@@ -1016,6 +1028,10 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   std::vector<float> ones(N, 1.0f);
   hipMemcpy(D.root + 3 * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
   for (int b = 0; b < d->n_free; b++) hipMemcpy(D.free_s + (13 * b + 3) * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
+  {
+    std::vector<float> awake(N * (size_t)(d->n_free > 0 ? d->n_free : 1), MSSIM_WAKE_TIME);
+    if (d->n_free > 0) hipMemcpy(D.free_wake, awake.data(), awake.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   for (int k = 0; k < d->n_kin; k++) hipMemcpy(D.kin + (7 * k + 3) * N, ones.data(), N * sizeof(float), hipMemcpyHostToDevice);
   *out = S;
   return 0;
@@ -1086,6 +1102,14 @@ int mssim_fetch(mssim_handle h, uint32_t what, void* stream) {
 static void launch_fk(mssim_handle h, hipStream_t st) {
   if (h->panda) hipLaunchKernelGGL(k_fk<TopoPanda>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
   else hipLaunchKernelGGL(k_fk<TopoDyn>, env_grid(h->N, 64), dim3(64), 0, st, h->M, h->S);
+}
+
+int mssim_wake_all(mssim_handle h, void* stream) {
+  flush_deferred(h, (hipStream_t)stream);
+  const size_t cnt = (size_t)h->M.n_free * h->N;
+  if (cnt > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->S.free_wake, MSSIM_WAKE_TIME, cnt);
+  HIPCHK(h, hipGetLastError());
+  return 0;
 }
 
 int mssim_update_kinematics(mssim_handle h, void* stream) {
@@ -1400,6 +1424,7 @@ int mssim_read_internal(mssim_handle h, const char* name, float* out, int32_t ma
   else if (s == "qd") { src = h->S.qd; items = h->M.n_dof; }
   else if (s == "free") { src = h->S.free_s; items = 13 * h->M.n_free; }
   else if (s == "kin") { src = h->S.kin; items = 7 * h->M.n_kin; }
+  else if (s == "free_wake") { src = h->S.free_wake; items = h->M.n_free; }
   else if (s == "root") { src = h->S.root; items = 7; }
   else if (s == "bodypose") { src = h->S.bodypose; items = 7 * h->M.n_dof; }
   else if (s == "pair_impulse") { src = h->S.pair_imp; items = 3 * h->M.n_pair; }

@@ -49,7 +49,7 @@
 #define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
 #define S16_LIMW (S16_U)       // [16][16] W = A^-1 J^T of the joint-limit rows
 #define S16_CS (S16_U + 256)   // [MAXC][16] block scalars of every contact: 1/d0 bias+ bias- mu | 1/d1 k10 1/d2 k20 | k21 lam0 lam1 lam2 | pair
-#define S16_REGC 16            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
+#define S16_REGC 12            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
 #define S16_LDSC 7             // next contacts: J | W rows in LDS; the rest stream from the per-env global scratch
 #define S16_JWLEN 96           // 3 x (J[16] W[16]) of one contact
 #define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][96]
@@ -528,6 +528,29 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   // free-body velocity component of this lane; pose and the external force live in the pose table / registers
   float vfree_c = freel ? SOA(S.free_s, 13 * fb_id + 7 + fk) : 0.f;
   float fforce_c = (freel && fk < 3) ? SOA(S.free_force, 3 * fb_id + fk) : 0.f;
+  // sleeping (include/mssim.h sleep_threshold): per free body the seconds left before it goes to sleep (<= 0: asleep)
+  // and whether its mass-normalised kinetic energy is below the threshold ("calm"); both group-uniform
+  float fwake[S16_MAX_FREE];
+  bool fcalm[S16_MAX_FREE];
+  // 0.5 (v^2 + w . I w / m) of free body b at pose quaternion q (body-frame inertia about the centre of mass)
+  auto norm_energy = [&](const float* in, f3 v, f3 w, q4 q) __attribute__((always_inline)) {
+    const f3 wl = mtmulv(qmat(q), w);  // w . (R I R^T) w = (R^T w) . I (R^T w)
+    return 0.5f * (dot(v, v) + dot(wl, smulv(s3{in[4], in[5], in[6], in[7], in[8], in[9]}, wl)) * rcp_f(in[0]));
+  };
+#pragma unroll
+  for (int b = 0; b < S16_MAX_FREE; b++) {
+    fwake[b] = 1.f;
+    fcalm[b] = false;
+    if (b < nf) {
+      fwake[b] = SOA(S.free_wake, b);
+      const pose_t P = pose_soa(S.free_s, 13 * b, N, e);
+      const f3 v = f3{SOA(S.free_s, 13 * b + 7), SOA(S.free_s, 13 * b + 8), SOA(S.free_s, 13 * b + 9)};
+      const f3 w = f3{SOA(S.free_s, 13 * b + 10), SOA(S.free_s, 13 * b + 11), SOA(S.free_s, 13 * b + 12)};
+      float in0[10];
+      free_inertial_of(M, N, b, e, in0);
+      fcalm[b] = norm_energy(in0, v, w, P.q) < M.sleep_threshold;
+    }
+  }
   // pose table: root, links, free bodies, kinematic bodies
   {
     reinterpret_cast<unsigned*>(L)[S16_ANC + c] = (art ? M.dof_anc[c] : 0u) | self_c;
@@ -559,6 +582,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     const bool last = sub == n_sub - 1;
     // ================================================================ contacts -> LDS records
     int nc = 0;
+    unsigned fdist = 0u;  // free bodies touched by a disturber in this substep (sleep counters)
     if (FUSED) {
       // shape-local data of shapes c and c + 16 and the cull pairs of this lane (model constants,
       // fetched per substep rather than held in registers over the whole step)
@@ -894,6 +918,38 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           key_[i] = (int)(((pa >> 10) & 31u) | (((pb >> 10) & 31u) << 8)) | (tors ? 1 << 16 : 0);
         }
         __syncthreads();
+        // sleeping free bodies: a "disturber" is an articulation link or a free body that is awake and not calm. A
+        // sleeping body touched by a disturber wakes; the manifolds of a body that stays asleep are dropped; whether a
+        // disturber touched it feeds its sleep counter at the end of the substep.
+        {
+          unsigned dist = 0u;  // bit b: free body b has a manifold with a disturber
+          auto free_of = [&](int slot1) { return (slot1 > S16_PT_FREE && slot1 <= S16_PT_FREE + S16_MAX_FREE) ? slot1 - 1 - S16_PT_FREE : -1; };
+          auto disturber = [&](int slot1) {
+            if (slot1 > S16_PT_LINK && slot1 <= S16_PT_FREE) return true;  // pose slots 1..16: articulation links
+            const int b = free_of(slot1);
+            return b >= 0 && (b == 0 ? (fwake[0] > 0.f && !fcalm[0]) : (fwake[1] > 0.f && !fcalm[1]));
+          };
+          for (int i = c; i < nh; i += 16) {
+            if (cnt_[i] <= 0) continue;
+            const int ky = key_[i];
+            const int s1a = ky & 31, s1b = (ky >> 8) & 31;
+            const int ba = free_of(s1a), bb = free_of(s1b);
+            if (ba >= 0 && disturber(s1b)) dist |= 1u << ba;
+            if (bb >= 0 && disturber(s1a)) dist |= 1u << bb;
+          }
+          dist |= __shfl_xor(dist, 8, 16); dist |= __shfl_xor(dist, 4, 16); dist |= __shfl_xor(dist, 2, 16); dist |= __shfl_xor(dist, 1, 16);
+          fdist = dist;
+#pragma unroll
+          for (int b = 0; b < S16_MAX_FREE; b++)
+            if (b < nf && fwake[b] <= 0.f && ((dist >> b) & 1u)) fwake[b] = MSSIM_WAKE_TIME;
+          for (int i = c; i < nh; i += 16) {
+            const int ky = key_[i];
+            const int ba = free_of(ky & 31), bb = free_of((ky >> 8) & 31);
+            const bool sa_ = ba >= 0 && (ba == 0 ? fwake[0] : fwake[1]) <= 0.f, sb_ = bb >= 0 && (bb == 0 ? fwake[0] : fwake[1]) <= 0.f;
+            if (sa_ || sb_) cnt_[i] = 0;
+          }
+          __syncthreads();
+        }
         bool any_big = false;
         for (int i = c; i < nh; i += 16) {
           int anchor = i;
@@ -1292,16 +1348,17 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       vv = vv * (ld > 0.f ? ld : 0.f);
       ww = ww * (ad > 0.f ? ad : 0.f);
       if (c == 0) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
+      const bool asleep_b = fwake[b] <= 0.f;  // at rest and out of the solver (none of its manifolds was kept)
       if (freel && fb_id == b) {
         mycom = com;
-        v_c = fk < 3 ? comp(vv, fk) : comp(ww, fk - 3);
+        v_c = asleep_b ? 0.f : (fk < 3 ? comp(vv, fk) : comp(ww, fk - 3));
         const f3 irow = fk == 3 ? f3{Ii.xx, Ii.xy, Ii.xz} : (fk == 4 ? f3{Ii.xy, Ii.yy, Ii.yz} : f3{Ii.xz, Ii.yz, Ii.zz});
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           float val = 0.f;
           if (fk < 3) val = k == c ? minv : 0.f;
           else val = k == fbase + 3 ? irow.x : (k == fbase + 4 ? irow.y : (k == fbase + 5 ? irow.z : 0.f));
-          Irow[k] = val;
+          Irow[k] = asleep_b ? 0.f : val;
         }
       }
     }
@@ -1517,6 +1574,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
           f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
           __syncthreads();
+          if (fwake[b] <= 0.f) {  // asleep: the pose stays bit for bit
+            pp = f3{pt[0], pt[1], pt[2]};
+            qq = q4{pt[3], pt[4], pt[5], pt[6]};
+          }
           if (c == 0) lds_pose_store(pt, pose_t{pp, qq});
           if (c == 0 && live && last) {
             SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
@@ -1723,6 +1784,23 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       qd_c = vj;
     }
     vfree_c = freel ? v_c : 0.f;
+    // sleep counters: run down while the body is calm and no disturber touches it, restart otherwise
+#pragma unroll
+    for (int b = 0; b < S16_MAX_FREE; b++) {
+      if (b >= nf) break;
+      const int base = n + 6 * b;
+      const f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)}, ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
+      const float* pt = L + S16_PT + 7 * (S16_PT_FREE + b);
+      const bool calm = norm_energy(fin[b], vv, ww, q4{pt[3], pt[4], pt[5], pt[6]}) < M.sleep_threshold;
+      if (fwake[b] > 0.f) {
+        fwake[b] = (calm && M.sleep_threshold > 0.f && !((fdist >> b) & 1u)) ? fwake[b] - dt : MSSIM_WAKE_TIME;
+        if (fwake[b] <= 0.f) {
+          fwake[b] = 0.f;
+          if (freel && fb_id == b) { vfree_c = 0.f; v_c = 0.f; }
+        }
+      }
+      fcalm[b] = calm;
+    }
     bp_c = nb; aw_c = naw; an_c = nan;
     PH(15);
       // ================================================================ write back (last substep)
@@ -1736,6 +1814,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
         if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
       }
+      if (c < nf && live) SOA(S.free_wake, c) = c == 0 ? fwake[0] : fwake[1];
       // body velocities about O with the new subspaces
       sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
       if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};

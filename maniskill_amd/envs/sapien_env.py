@@ -690,6 +690,9 @@ class BaseEnv(gym.Env):
     def set_state_dict(self, state: Dict, env_idx: torch.Tensor = None):
         self.scene.set_sim_state(state, env_idx)
         self.scene._gpu_apply_all()
+        # a restored state starts awake: what follows depends on the state alone, not on how long the bodies had been at
+        # rest before (PhysX: setGlobalPose wakes the actor)
+        self.scene.px.wake_all()
         self.scene.px.gpu_update_articulation_kinematics()
         self.scene._gpu_fetch_all()
 

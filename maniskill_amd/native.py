@@ -176,6 +176,7 @@ class NativeLib:
         f("fetch", C.c_int, [H, C.c_uint32, C.c_void_p])
         f("step", C.c_int, [H, C.c_int32, C.c_void_p])
         f("update_kinematics", C.c_int, [H, C.c_void_p])
+        f("wake_all", C.c_int, [H, C.c_void_p])
         f("create_pair_query", C.c_int, [H, _I32P, C.c_int32, _I32P])
         f("query_pair_impulses", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
         f("create_body_query", C.c_int, [H, _I32P, C.c_int32, _I32P])
@@ -202,7 +203,7 @@ class NativeLib:
 
     EXPORTS = [
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
-        "update_kinematics", "create_pair_query", "query_pair_impulses", "create_body_query",
+        "update_kinematics", "wake_all", "create_pair_query", "query_pair_impulses", "create_body_query",
         "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map", "set_ee_action_map",
         "apply_action", "step_action", "defer_fetch", "defer_step_action", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
         "profile_read", "last_error",
@@ -273,6 +274,9 @@ class NativeSim:
 
     def step(self, n_substeps=1, stream=None):
         self._check(self.lib.step(self.h, n_substeps, stream), "step")
+
+    def wake_all(self, stream=None):
+        self._check(self.lib.wake_all(self.h, stream), "wake_all")
 
     def update_kinematics(self, stream=None):
         self._check(self.lib.update_kinematics(self.h, stream), "update_kinematics")

@@ -182,6 +182,10 @@ class MssimSystem:
     def gpu_update_articulation_kinematics(self):
         self._sim.update_kinematics(self._stream())
 
+    def wake_all(self):
+        """wake every sleeping free body (their sleep counters are state the buffers do not carry; include/mssim.h)"""
+        self._sim.wake_all(self._stream())
+
     # ------------------------------------------------------------------ apply / fetch
     def _apply(self, what):
         self._sim.apply(what, self._stream())

@@ -66,7 +66,7 @@ struct Model {
   int N = 0, n_env_shape = 0, n_env_free = 0;
   std::vector<int32_t> shape_env_slot, free_env_slot;
   std::vector<float> env_shape_frame, env_shape_param, env_shape_bound, env_free_inertial;
-  Real gravity[3], dt, contact_offset, rest_offset, erp, max_depen;
+  Real gravity[3], dt, contact_offset, rest_offset, erp, max_depen, sleep_threshold;
   int pos_iters, vel_iters;
 };
 
@@ -88,6 +88,8 @@ struct EnvState {
   std::vector<Real> q, qd, qt, qdt, qf, qacc;
   std::vector<Pose<Real>> free_pose;
   std::vector<Vec> free_v, free_w, free_force;
+  std::vector<char> free_calm, free_disturbed;  // energy below the threshold at the start of the substep | touched by a disturber in it
+  std::vector<Real> free_wake;  // seconds of low energy left before the body goes to sleep; <= 0: asleep (include/mssim.h)
   std::vector<Pose<Real>> kin_pose;
   // derived
   std::vector<Pose<Real>> body_pose;  // moving bodies
@@ -305,6 +307,37 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
     }
   }
   (void)hits;
+  // Sleeping free bodies (include/mssim.h sleep_threshold). A "disturber" is an articulation link or a free body that is
+  // awake and not calm (energy above the threshold at the start of the substep). A sleeping body touched by a disturber
+  // (a manifold with points) wakes; the manifolds of a body that stays asleep are dropped (its partners are fixed,
+  // asleep or calm); `free_disturbed` feeds the sleep counters at the end of the substep.
+  {
+    const int nf = M.n_free;
+    auto disturber = [&](int kind, int index) {
+      if (kind == MSSIM_BODY_ART) return index >= 0;
+      if (kind == MSSIM_BODY_FREE) return E.free_wake[index] > 0 && !E.free_calm[index];
+      return false;
+    };
+    E.free_disturbed.assign(nf, 0);
+    for (const RawManifold& mf : man) {
+      const Contact& c = raw[mf.first];
+      if (c.ka == MSSIM_BODY_FREE && disturber(c.kb, c.ib)) E.free_disturbed[c.ia] = 1;
+      if (c.kb == MSSIM_BODY_FREE && disturber(c.ka, c.ia)) E.free_disturbed[c.ib] = 1;
+    }
+    for (int b = 0; b < nf; b++)
+      if (E.free_wake[b] <= 0 && E.free_disturbed[b]) E.free_wake[b] = Real(MSSIM_WAKE_TIME);
+    std::vector<Contact> raw2;
+    std::vector<RawManifold> man2;
+    for (const RawManifold& mf : man) {
+      const Contact& c = raw[mf.first];
+      const bool drop = (c.ka == MSSIM_BODY_FREE && E.free_wake[c.ia] <= 0) || (c.kb == MSSIM_BODY_FREE && E.free_wake[c.ib] <= 0);
+      if (drop) continue;
+      man2.push_back({(int)raw2.size(), mf.count, mf.key, mf.n});
+      for (int k = 0; k < mf.count; k++) raw2.push_back(raw[mf.first + k]);
+    }
+    raw.swap(raw2);
+    man.swap(man2);
+  }
   E.raw_points = (int)raw.size();
   std::vector<char> keep;
   std::vector<int> anchor;
@@ -391,6 +424,22 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   // 1. FK
   std::vector<Vec> axis_w, anchor;
   fk(M, E, &axis_w, &anchor);
+  // free-body inertials; "calm" = mass-normalised kinetic energy below the sleep threshold at the start of the substep
+  std::vector<float> finert(10 * (nf > 0 ? nf : 1));
+  for (int b = 0; b < nf; b++) {
+    const int fslot = M.free_env_slot.empty() ? -1 : M.free_env_slot[b];
+    for (int k = 0; k < 10; k++)
+      finert[10 * b + k] = fslot < 0 ? M.free_inertial[10 * b + k] : M.env_free_inertial[(size_t)(10 * fslot + k) * M.N + e];
+  }
+  auto normalised_energy = [&](int b, const Vec& v, const Vec& w) {
+    const float* in = &finert[10 * b];
+    Mat Rm = qmat(E.free_pose[b].q);
+    Real Iv[6] = {in[4], in[5], in[6], in[7], in[8], in[9]};
+    Mat Iw = mmul(mmul(Rm, sym3(Iv)), mtranspose(Rm));
+    return Real(0.5) * (dot(v, v) + dot(w, Iw * w) / in[0]);
+  };
+  E.free_calm.assign(nf, 0);
+  for (int b = 0; b < nf; b++) E.free_calm[b] = normalised_energy(b, E.free_v[b], E.free_w[b]) < M.sleep_threshold;
   // 2. narrowphase
   std::vector<Contact> contacts;
   narrowphase(M, E, e, contacts);
@@ -503,12 +552,6 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   std::vector<Vec> fv(nf), fw(nf), fcom(nf);
   std::vector<Mat> fIinv(nf);
   std::vector<Real> fminv(nf);
-  std::vector<float> finert(10 * (nf > 0 ? nf : 1));
-  for (int b = 0; b < nf; b++) {
-    const int fslot = M.free_env_slot.empty() ? -1 : M.free_env_slot[b];
-    for (int k = 0; k < 10; k++)
-      finert[10 * b + k] = fslot < 0 ? M.free_inertial[10 * b + k] : M.env_free_inertial[(size_t)(10 * fslot + k) * M.N + e];
-  }
   for (int b = 0; b < nf; b++) {
     const float* in = &finert[10 * b];
     Mat Rm = qmat(E.free_pose[b].q);
@@ -525,6 +568,10 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     Real ld = Real(1) - dt * M.free_damping[2 * b], ad = Real(1) - dt * M.free_damping[2 * b + 1];
     fv[b] = v * (ld > 0 ? ld : Real(0));
     fw[b] = w * (ad > 0 ? ad : Real(0));
+    if (E.free_wake[b] <= 0) {  // asleep: at rest, out of the solver (none of its manifolds was kept)
+      fv[b] = Vec(); fw[b] = Vec();
+      fminv[b] = 0; fIinv[b] = Mat();
+    }
   }
 
   // 4. rows
@@ -702,6 +749,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   }
   for (int b = 0; b < nf; b++) {
     const float* in = &finert[10 * b];
+    if (E.free_wake[b] <= 0) { E.free_force[b] = Vec(); continue; }  // asleep: pose and (zero) velocity stay bit for bit
     Vec com = fcom[b] + fv_pos[b] * dt;
     Quat q = E.free_pose[b].q;
     Vec w = clamp_norm(fw_pos[b], Real(MSSIM_MAX_ANGULAR_VELOCITY));
@@ -713,6 +761,12 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     E.free_v[b] = fv[b];
     E.free_w[b] = fw[b];
     E.free_force[b] = Vec();
+    // sleep counter: runs down while the body is calm and no disturber touches it, restarts otherwise
+    if (E.free_wake[b] > 0) {
+      const bool calm = M.sleep_threshold > 0 && normalised_energy(b, E.free_v[b], E.free_w[b]) < M.sleep_threshold;
+      E.free_wake[b] = (calm && !E.free_disturbed[b]) ? E.free_wake[b] - dt : Real(MSSIM_WAKE_TIME);
+      if (E.free_wake[b] <= 0) { E.free_wake[b] = 0; E.free_v[b] = Vec(); E.free_w[b] = Vec(); }
+    }
   }
   fk(M, E, &axis_w, &anchor);
   body_velocities(M, E, axis_w, anchor, E.qd);
@@ -768,13 +822,14 @@ int mssim_ref_create(const mssim_model_desc* d, int32_t num_envs, int32_t device
   for (int k = 0; k < 3; k++) M.gravity[k] = d->gravity[k];
   M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
   M.max_depen = d->max_depenetration_velocity; M.pos_iters = d->position_iterations; M.vel_iters = d->velocity_iterations;
+  M.sleep_threshold = d->sleep_threshold;
   for (int j = 0; j < n; j++)
     if (M.dof_parent[j] >= j) { g_create_error = "dof_parent must be topologically sorted"; delete S; return 4; }
   S->N = num_envs;
   S->env.resize(num_envs);
   for (auto& E : S->env) {
     E.q.assign(n, 0); E.qd.assign(n, 0); E.qt.assign(n, 0); E.qdt.assign(n, 0); E.qf.assign(n, 0); E.qacc.assign(n, 0);
-    E.free_pose.resize(M.n_free); E.free_v.resize(M.n_free); E.free_w.resize(M.n_free); E.free_force.resize(M.n_free);
+    E.free_pose.resize(M.n_free); E.free_v.resize(M.n_free); E.free_w.resize(M.n_free); E.free_force.resize(M.n_free); E.free_wake.assign(M.n_free, Real(MSSIM_WAKE_TIME)); E.free_calm.assign(M.n_free, 0); E.free_disturbed.assign(M.n_free, 0);
     E.kin_pose.resize(M.n_kin);
     E.pair_impulse.assign(M.n_pair, Vec()); E.pair_count.assign(M.n_pair, 0);
     refresh_kinematics(S, E);
@@ -812,6 +867,14 @@ int mssim_ref_apply(mssim_handle h, uint32_t what, void*) {
     if ((what & MSSIM_RIGID_DATA) && B.rigid_body_data) {
       for (int b = 0; b < M.n_free; b++) {
         const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + b) * N + e);
+        // a row that differs from what the last fetch wrote (the f32 image of the state) wakes the body
+        const Pose<Real>& P0 = E.free_pose[b];
+        const float was[13] = {(float)P0.p.x, (float)P0.p.y, (float)P0.p.z, (float)P0.q.w, (float)P0.q.x, (float)P0.q.y, (float)P0.q.z,
+                               (float)E.free_v[b].x, (float)E.free_v[b].y, (float)E.free_v[b].z, (float)E.free_w[b].x, (float)E.free_w[b].y, (float)E.free_w[b].z};
+        bool changed = false;
+        for (int k = 0; k < 13; k++) changed = changed || r[k] != was[k];
+        if (!changed) continue;
+        E.free_wake[b] = Real(MSSIM_WAKE_TIME);
         E.free_pose[b] = pose7(r);
         E.free_v[b] = Vec(r[7], r[8], r[9]);
         E.free_w[b] = Vec(r[10], r[11], r[12]);
@@ -828,6 +891,7 @@ int mssim_ref_apply(mssim_handle h, uint32_t what, void*) {
       for (int b = 0; b < M.n_free; b++) {
         const float* f = B.rigid_body_force + 4 * ((size_t)(M.n_link + b) * N + e);
         E.free_force[b] = Vec(f[0], f[1], f[2]);
+        if (f[0] != 0 || f[1] != 0 || f[2] != 0) E.free_wake[b] = Real(MSSIM_WAKE_TIME);
       }
   }
   return 0;
@@ -886,6 +950,11 @@ int mssim_ref_step(mssim_handle h, int32_t n_substeps, void*) {
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < N; e++)
     for (int s = 0; s < n_substeps; s++) substep(h, h->env[e], e);
+  return 0;
+}
+
+int mssim_ref_wake_all(mssim_handle h, void*) {
+  for (auto& E : h->env) std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
   return 0;
 }
 
@@ -980,6 +1049,9 @@ int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_
         const Vec& v = h->env[e].pair_impulse[p];
         put(3 * p, e, v.x); put(3 * p + 1, e, v.y); put(3 * p + 2, e, v.z);
       }
+  } else if (s == "free_wake") {
+    items = M.n_free;
+    for (int e = 0; e < N; e++) for (int b = 0; b < items; b++) put(b, e, h->env[e].free_wake[b]);
   } else if (s == "raw_contact_count") {  // (oracle only: test construction aid)
     items = 1;
     for (int e = 0; e < N; e++) put(0, e, h->env[e].raw_points);

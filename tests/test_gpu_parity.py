@@ -319,6 +319,7 @@ def test_patch_reduction_matches_oracle_on_contact_rich_peg_states():
         px.cuda_articulation_qvel.torch()[:] = st["qd"].to(dev)
         px.cuda_articulation_target_qpos.torch()[:] = st["q"].to(dev)
         px.gpu_apply_all()
+        px.wake_all()  # (the oracle env's pegs have been asleep for a while, the fresh HIP system's have not)
         px.step(1)
     a, b = get_state(gpu, model, N), get_state(cpu, model, N)
     raw = cpu.read_internal("raw_contact_count", 1)[0]
@@ -389,9 +390,71 @@ def test_torsional_friction_and_patches_match_oracle_known_answers():
     model = bld.compile()
     gpu, cpu = make_pair(model, 4)
     for px in (gpu, cpu):
-        px.step(50)
+        px.step(30)  # (before the body goes to sleep at 0.4 s)
     a, b = get_state(gpu, model, 4), get_state(cpu, model, 4)
     assert torch.equal(a["cnt"], b["cnt"]) and int(a["cnt"][:, 0].sum()) == 4
     r = model.row_of("twin")
     assert torch.max(torch.abs(a["rb"][r, :, :7] - b["rb"][r, :, :7])) < 2e-5
     assert torch.max(torch.abs(a["rb"][r, :, 2] - 0.02)) < 1e-4
+
+
+def test_sleeping_matches_oracle():
+    """sleep_threshold (include/mssim.h): two cubes at rest go to sleep after 0.4 s on both sides in the same substep, stay
+    frozen bit for bit, one is woken by a new pose and drops onto the other, which wakes when touched; the stack goes
+    back to sleep. Wake counters and states are compared with the oracle along the way."""
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(cube_record())
+    b.add_actor(cube_record(name="cube2", p=(0.3, 0, 0.02)))
+    model = b.compile()
+    N = 8
+    gpu, cpu = make_pair(model, N)
+    r1, r2 = model.row_of("cube"), model.row_of("cube2")
+
+    def both(f):
+        for px in (gpu, cpu):
+            f(px)
+
+    def wake():
+        return gpu.read_internal("free_wake", 2).cpu(), cpu.read_internal("free_wake", 2)
+
+    both(lambda px: px.step(39))
+    wg, wc = wake()
+    assert torch.all(wg > 0) and torch.all(wc > 0)
+    both(lambda px: px.step(3))
+    wg, wc = wake()
+    assert torch.all(wg == 0) and torch.all(wc == 0)
+    both(lambda px: px.gpu_fetch_all())
+    rb = gpu.cuda_rigid_body_data.torch().clone()
+    assert torch.all(rb[r1 * N : (r2 + 1) * N, 7:13] == 0)
+    assert int(gpu.read_internal("contact_count", model.n_pair).sum()) == 0
+    both(lambda px: px.step(50))
+    gpu.gpu_fetch_all()
+    assert torch.equal(gpu.cuda_rigid_body_data.torch(), rb)  # frozen bit for bit
+
+    def lift(px):
+        px.gpu_apply_all()  # (unchanged rows: nobody wakes)
+        t = px.cuda_rigid_body_data.torch()
+        t[r2 * N : (r2 + 1) * N, :3] = torch.tensor([0.0, 0.0, 0.16], device=t.device)
+        px.gpu_apply_all()
+        px.step(5)
+
+    both(lift)
+    wg, wc = wake()
+    assert torch.all(wg[0] == 0) and torch.all(wg[1] > 0) and torch.equal(wg == 0, wc == 0)
+    woke = None
+    for i in range(40):
+        both(lambda px: px.step(1))
+        wg, wc = wake()
+        assert torch.equal(wg > 0, wc > 0), i
+        if torch.all(wg[0] > 0):
+            woke = i
+            break
+    assert woke is not None
+    both(lambda px: px.step(200))
+    a, b_ = get_state(gpu, model, N), get_state(cpu, model, N)
+    wg, wc = wake()
+    assert torch.all(wg == 0) and torch.all(wc == 0)
+    assert torch.max(torch.abs(a["rb"][r1, :, 2] - 0.02)) < 2e-3 and torch.max(torch.abs(a["rb"][r2, :, 2] - 0.06)) < 5e-3
+    assert torch.max(torch.abs(a["rb"][[r1, r2], :, :3] - b_["rb"][[r1, r2], :, :3])) < 2e-3
