@@ -1,33 +1,38 @@
-"""env-steps/s of the BASELINE.json single-GPU configurations, step-only and step+reset (reset every 200
-steps, as the reference's gpu_sim.py:96-106,166-178), one line per configuration."""
+"""env-steps/s of the BASELINE.json single-GPU configurations under the reference harness's protocol: 1000 steps without a
+reset (gpu_sim.py:96-106) and 1000 steps with a reset every 200 (gpu_sim.py:166-178), warm-up reset / step / reset
+(gpu_sim.py:91-93); one JSON line per configuration. The 200-step figure is the first fifth of the same unreset run."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import maniskill_amd.envs  # noqa
 import gymnasium as gym
 
-def run(env_id, N, steps=200, control_mode="pd_joint_delta_pos", **kw):
+def run(env_id, N, steps=1000, control_mode="pd_joint_delta_pos", **kw):
     torch.manual_seed(2022)
     env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode=control_mode, **kw)
     base = env.unwrapped
     adim = base.single_action_space.shape[0]
     env.reset(seed=2022)
-    for _ in range(10):
-        env.step(2 * torch.rand(N, adim, device="cuda") - 1)
+    env.step(2 * torch.rand(N, adim, device="cuda") - 1)
     env.reset(seed=2022)
     torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(steps):
+    dt_200 = None
+    for i in range(steps):
         env.step(2 * torch.rand(N, adim, device="cuda") - 1)
+        if i == 199:
+            torch.cuda.synchronize(); dt_200 = time.perf_counter() - t
     torch.cuda.synchronize(); dt_step = time.perf_counter() - t
+    overflow = base.scene.px.overflow_count()
     env.reset(seed=2022)
     torch.cuda.synchronize(); t = time.perf_counter()
-    for i in range(2 * steps):
+    for i in range(steps):
         env.step(2 * torch.rand(N, adim, device="cuda") - 1)
         if (i + 1) % 200 == 0:
             env.reset()
     torch.cuda.synchronize(); dt_reset = time.perf_counter() - t
-    out = dict(env_id=env_id, num_envs=N, control_mode=control_mode, substeps=base._sim_steps_per_control, step_only=round(N * steps / dt_step), step_reset_every_200=round(N * 2 * steps / dt_reset),
-               ms_per_step=round(dt_step / steps * 1e3, 3), overflow_envs=base.scene.px.overflow_count())
+    out = dict(env_id=env_id, num_envs=N, control_mode=control_mode, substeps=base._sim_steps_per_control, steps=steps, step_only=round(N * steps / dt_step),
+               step_only_first_200=round(N * 200 / dt_200) if dt_200 else None, step_reset_every_200=round(N * steps / dt_reset),
+               ms_per_step=round(dt_step / steps * 1e3, 3), overflow_envs=overflow + base.scene.px.overflow_count())
     print(json.dumps(out), flush=True)
     env.close()
 

@@ -23,33 +23,18 @@ def clean_copy(name, out=None):
         open(os.path.join(dst, out or name), "w").writelines(lines)
 
 
-f = newest("stats/*/*kernel_stats.csv")
+f = newest("stats/*kernel_stats.csv") or newest("stats/*/*kernel_stats.csv")
 if f:
     shutil.copy(f, os.path.join(dst, "bench_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "pmc_summary.json")):
     shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "pmc_summary.json"))
-for name in ("bench_matrix.log", "block_times.log", "cpu_config1.log"):
+for name in ("bench_matrix.log", "block_times.log", "cpu_config1.log", "bench_series.log"):
     clean_copy(name)
 clean_copy("phase_pick.log", "phase_clocks_pickcube.log")
 
-# SQ / instruction-cache counters of the control-step kernel
-out = {}
-for d in ("pmc_ic", "pmc_sq"):
-    f = newest(f"{d}/*/*_counter_collection.csv")
-    if not f:
-        continue
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("void k_solve16"):
-            a = agg[r["Counter_Name"]]
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
-    for k, (n, v) in agg.items():
-        out[k] = dict(launches=n, per_launch=v / n)
-if out:
-    json.dump(dict(kernel_source_sha=kernel_source_sha(), note="rocprofv3 --pmc, control-step kernel k_solve16<9, TASK> (whole env.step), PickCube-v1 4096 envs, bench.py --steps 20 "
-                        "--warmup 3; two passes (ICACHE+INSTS, SQ cycles); SQ_*_CYCLES / SQ_WAIT_* are quad-cycles summed over waves", counters=out),
-              open(os.path.join(dst, "sq_counters.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "sq_counters.json")):
+    shutil.copy(os.path.join(src, "sq_counters.json"), os.path.join(dst, "sq_counters.json"))
+out = json.load(open(os.path.join(dst, "sq_counters.json")))["counters"] if os.path.exists(os.path.join(dst, "sq_counters.json")) else {}
 
 # bench line with the PMC traffic of the dominant kernel
 p = os.path.join(src, "bench.json.log")
