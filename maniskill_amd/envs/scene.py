@@ -188,11 +188,39 @@ class ManiSkillScene:
         )
         self.px.gpu_init(model, self.num_envs)
         self.model = model
+        # builder-time components get their buffer rows (`gpu_pose_index`, structs/base.py:103-110) and are handed to the
+        # system for `px.rigid_dynamic_components / rigid_static_components / articulation_link_components`
+        comps = dict(dynamic=[], static=[], links=[])
         for name, actor in self.actors.items():
             row = model.row_of(name)
             actor._body_row = row if row >= 0 else None
+            comp = getattr(actor, "_px_component", None)
+            if comp is None:  # merged per-env actors (Actor.merge) are registered without a builder
+                comp = physx.PhysxRigidStaticComponent() if actor.px_body_type == "static" else physx.PhysxRigidDynamicComponent()
+                if actor.px_body_type == "kinematic":
+                    comp.kinematic = True
+                comp.name = name
+                actor._px_component = comp
+            comp.entity = actor
+            if row >= 0:
+                comp.gpu_pose_index = row * self.num_envs
+                comp.gpu_index = (row - model.n_link) * self.num_envs
+                comps["dynamic"].append(comp)
+            else:
+                comps["static"].append(comp)
         for art in self.articulations.values():
             assert [l.name for l in art.links] == model.link_names
+            by_name = {}
+            for i, link in enumerate(art.links):
+                parent = getattr(getattr(link, "joint", None), "parent_link", None)
+                c = physx.PhysxArticulationLinkComponent(by_name.get(getattr(parent, "name", None)))
+                c.name, c.entity, c.index, c.articulation, c.joint = link.name, link, i, art, getattr(link, "joint", None)
+                c.gpu_pose_index = i * self.num_envs
+                by_name[link.name] = c
+                link._px_component = c
+                comps["links"].append(c)
+        comps["dynamic"].sort(key=lambda c: c.gpu_pose_index)  # cuda_rigid_body_data row order
+        self.px._components = comps
         self._gpu_sim_initialized = True
         # per-env initial poses given at build time
         for actor in self.actors.values():
@@ -246,6 +274,11 @@ class ManiSkillScene:
 
     def get_pairwise_contact_forces(self, obj1, obj2) -> torch.Tensor:
         return self.get_pairwise_contact_impulses(obj1, obj2) / self.px.timestep
+
+    def get_contacts(self, env_index: int = 0):
+        """`px.get_contacts()` (the reference uses it on the CPU backend only, utils/sapien_utils.py:215-260): the body
+        pairs of one env that exchanged a contact impulse in the last substep"""
+        return self.px.get_contacts(env_index)
 
     # ------------------------------------------------------------------ state registry (scene.py:819-892)
     def add_to_state_dict_registry(self, obj: Union[Actor, Articulation]):

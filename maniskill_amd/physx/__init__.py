@@ -18,6 +18,23 @@ simulated independently of the others).
 import copy
 from typing import Sequence
 
+from .components import (  # noqa: F401  (builder-time component surface)
+    PhysxArticulationLinkComponent,
+    PhysxCollisionShape,
+    PhysxCollisionShapeBox,
+    PhysxCollisionShapeCapsule,
+    PhysxCollisionShapeConvexMesh,
+    PhysxCollisionShapeCylinder,
+    PhysxCollisionShapePlane,
+    PhysxCollisionShapeSphere,
+    PhysxCollisionShapeTriangleMesh,
+    PhysxContact,
+    PhysxContactPoint,
+    PhysxMaterial,
+    PhysxRigidDynamicComponent,
+    PhysxRigidStaticComponent,
+)
+
 _GPU_ENABLED = False
 _DEFAULTS = dict(
     gpu_memory=dict(

@@ -363,14 +363,65 @@ class MssimSystem:
     def get_scene_offset(self, scene) -> np.ndarray:
         return self.__dict__.get("_scene_offsets", {}).get(id(scene), np.zeros(3, dtype=np.float32))
 
+    # introspection: the builder-time component objects, filled in by ManiSkillScene._setup; below the env
+    # layer (no builders) the lists are made from the compiled model's body names
+    def _component_lists(self):
+        comps = getattr(self, "_components", None)
+        if comps is None and self.model is not None:
+            from . import PhysxArticulationLinkComponent, PhysxRigidDynamicComponent, PhysxRigidStaticComponent
+
+            comps = dict(dynamic=[], static=[], links=[])
+            for i, name in enumerate(self.model.link_names):
+                c = PhysxArticulationLinkComponent()
+                c.name, c.index, c.gpu_pose_index = name, i, i * self.num_envs
+                comps["links"].append(c)
+            for k, name in enumerate(list(self.model.free_names) + list(self.model.kin_names)):
+                c = PhysxRigidDynamicComponent()
+                c.name, c.kinematic = name, k >= self.model.n_free
+                c.gpu_pose_index, c.gpu_index = (self.model.n_link + k) * self.num_envs, k * self.num_envs
+                comps["dynamic"].append(c)
+            for name in self.model.static_names:
+                c = PhysxRigidStaticComponent()
+                c.name = name
+                comps["static"].append(c)
+            self._components = comps
+        return comps or dict(dynamic=[], static=[], links=[])
+
     @property
     def rigid_dynamic_components(self):
-        """names of the dynamic / kinematic free bodies, in row order (the reference lists component objects)"""
-        return list(self.model.free_names) + list(self.model.kin_names) if self.model is not None else []
+        """dynamic and kinematic bodies, in `cuda_rigid_body_data` row order"""
+        return list(self._component_lists()["dynamic"])
+
+    @property
+    def rigid_static_components(self):
+        return list(self._component_lists()["static"])
 
     @property
     def articulation_link_components(self):
-        return list(self.model.link_names) if self.model is not None else []
+        return list(self._component_lists()["links"])
+
+    def get_contacts(self, env_index: int = 0):
+        """body pairs of env `env_index` with a contact in the last substep -> [PhysxContact] (the reference's CPU-only
+        `px.get_contacts()`, utils/sapien_utils.py:215-260). One aggregate point per shape pair: impulse on bodies[0]
+        (the core exports per-pair impulses, include/mssim.h). Synchronises."""
+        from . import PhysxContact, PhysxContactPoint
+
+        m = self.model
+        cnt = self.read_internal("contact_count", max(m.n_pair, 1))[:, env_index].cpu().numpy()
+        imp = self.read_internal("pair_impulse", max(3 * m.n_pair, 1))[:, env_index].cpu().numpy().reshape(-1, 3)
+        lists = self._component_lists()
+        by_row = {}
+        for c in lists["links"] + lists["dynamic"]:
+            by_row[c.gpu_pose_index // max(self.num_envs, 1)] = c
+        world = lists["static"][0] if lists["static"] else None
+        out = []
+        pair_shape, shape_row = m.arrays["pair_shape"], m.arrays["shape_row"]
+        for p in range(m.n_pair):
+            if cnt[p] <= 0:
+                continue
+            ra, rb = int(shape_row[int(pair_shape[p][0])]), int(shape_row[int(pair_shape[p][1])])
+            out.append(PhysxContact(by_row.get(ra, world), by_row.get(rb, world), [PhysxContactPoint(impulse=imp[p].copy())]))
+        return out
 
     def sync_poses_gpu_to_cpu(self):
         """viewer hook of the reference (copies poses into the CPU entities for rendering); there are no CPU

@@ -9,26 +9,13 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 import torch
 
-from maniskill_amd.model import geom, mesh
-from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+from maniskill_amd.model import geom
+from maniskill_amd.model.compile import ShapeRecord
+from maniskill_amd.physx import components as pxc
+from maniskill_amd.physx.components import PhysxMaterial  # noqa: F401  (historic import path)
 from maniskill_amd.utils import common
 from maniskill_amd.utils.structs.actor import Actor
-from maniskill_amd.utils.structs.pose import Pose, to_sapien_pose
-
-
-class PhysxMaterial:
-    def __init__(self, static_friction=0.3, dynamic_friction=0.3, restitution=0.0):
-        self.static_friction, self.dynamic_friction, self.restitution = float(static_friction), float(dynamic_friction), float(restitution)
-
-
-def _pose7(pose) -> np.ndarray:
-    if pose is None:
-        return geom.pose()
-    if isinstance(pose, Pose):
-        raw = common.to_numpy(pose.raw_pose)
-        assert raw.shape[0] == 1, "shape poses must be unbatched"
-        return geom.pose(raw[0, :3], raw[0, 3:])
-    return geom.pose(np.asarray(pose.p, dtype=np.float64), np.asarray(pose.q, dtype=np.float64))
+from maniskill_amd.utils.structs.pose import Pose
 
 
 class ActorBuilder:
@@ -38,7 +25,7 @@ class ActorBuilder:
         self.initial_pose = None
         self.physx_body_type = "dynamic"
         self.collision_groups = [1, 1, 0, 0]
-        self.shapes: List[ShapeRecord] = []
+        self.collision_shapes: List[pxc.PhysxCollisionShape] = []  # in the order of the add_*_collision calls
         self.scene_idxs = None
         self._mass = None
         self._cmass_local_pose = None
@@ -80,46 +67,60 @@ class ActorBuilder:
         self._mass, self._cmass_local_pose, self._inertia = float(mass), cmass_local_pose, np.asarray(inertia, dtype=np.float64)
         return self
 
-    def _material(self, material):
-        m = material if material is not None else self.scene.default_material
-        return float(m.static_friction), float(m.dynamic_friction), float(m.restitution)
+    @property
+    def shapes(self) -> List[ShapeRecord]:
+        """the recorded shapes as model-compiler records"""
+        return [s.to_record() for s in self.collision_shapes]
 
-    def _add(self, type_, pose, material, density, patch_radius, min_patch_radius, **kw):
-        sf, df, rest = self._material(material)
-        self.shapes.append(
-            ShapeRecord(
-                type_,
-                _pose7(pose),
-                static_friction=sf,
-                dynamic_friction=df,
-                restitution=rest,
-                patch_radius=patch_radius,
-                min_patch_radius=min_patch_radius,
-                density=density,
-                **kw,
-            )
-        )
+    def _attach(self, shape: pxc.PhysxCollisionShape, pose, density, patch_radius, min_patch_radius):
+        """every add_*_collision call ends here: the shape object gets what the reference sets on it just before
+        `component.attach(shape)` (actor_builder.py:152-159)"""
+        shape.local_pose = pose
+        shape.set_density(density)
+        shape.set_patch_radius(patch_radius)
+        shape.set_min_patch_radius(min_patch_radius)
+        self.collision_shapes.append(shape)
         return self
+
+    def _mat(self, material):
+        return material if material is not None else self.scene.default_material
 
     # -- collision shapes (sapien.ActorBuilder names) ------------------------------------
     def add_plane_collision(self, pose=None, material=None, patch_radius=0, min_patch_radius=0):
-        return self._add("plane", pose, material, 0.0, patch_radius, min_patch_radius)
+        return self._attach(pxc.PhysxCollisionShapePlane(self._mat(material)), pose, 0.0, patch_radius, min_patch_radius)
 
     def add_box_collision(self, pose=None, half_size=(1, 1, 1), material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
-        return self._add("box", pose, material, density, patch_radius, min_patch_radius, half_size=np.asarray(half_size, dtype=np.float64))
+        return self._attach(pxc.PhysxCollisionShapeBox(half_size, self._mat(material)), pose, density, patch_radius, min_patch_radius)
 
     def add_sphere_collision(self, pose=None, radius=1, material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
-        return self._add("sphere", pose, material, density, patch_radius, min_patch_radius, radius=float(radius))
+        return self._attach(pxc.PhysxCollisionShapeSphere(radius, self._mat(material)), pose, density, patch_radius, min_patch_radius)
 
     def add_capsule_collision(self, pose=None, radius=1, half_length=1, material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
-        return self._add("capsule", pose, material, density, patch_radius, min_patch_radius, radius=float(radius), half_length=float(half_length))
+        return self._attach(pxc.PhysxCollisionShapeCapsule(radius, half_length, self._mat(material)), pose, density, patch_radius, min_patch_radius)
 
     def add_cylinder_collision(self, pose=None, radius=1, half_length=1, material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
-        return self._add("cylinder", pose, material, density, patch_radius, min_patch_radius, radius=float(radius), half_length=float(half_length))
+        return self._attach(pxc.PhysxCollisionShapeCylinder(radius, half_length, self._mat(material)), pose, density, patch_radius, min_patch_radius)
 
     def add_convex_collision_from_file(self, filename, pose=None, scale=(1, 1, 1), material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
-        verts = mesh.cook_convex_mesh(str(filename), tuple(scale))
-        return self._add("convex", pose, material, density, patch_radius, min_patch_radius, vertices=verts)
+        return self._attach(pxc.PhysxCollisionShapeConvexMesh(filename, scale, self._mat(material)), pose, density, patch_radius, min_patch_radius)
+
+    def build_physx_component(self, link_parent=None):
+        """the body as a `physx` component with its shapes attached (reference: actor_builder.py:57-163); `build`
+        registers exactly what this component describes"""
+        if self.physx_body_type == "static":
+            comp = pxc.PhysxRigidStaticComponent()
+        elif self.physx_body_type in ("dynamic", "kinematic"):
+            comp = pxc.PhysxRigidDynamicComponent()
+            comp.kinematic = self.physx_body_type == "kinematic"
+            comp.linear_damping, comp.angular_damping = self.linear_damping, self.angular_damping
+            if self._mass is not None and not comp.kinematic:
+                comp.mass, comp.cmass_local_pose, comp.inertia = self._mass, self._cmass_local_pose, self._inertia
+        else:
+            raise Exception(f"invalid physx body type [{self.physx_body_type}]")
+        for shape in self.collision_shapes:
+            shape.set_collision_groups(self.collision_groups)
+            comp.attach(shape)
+        return comp
 
     def add_multiple_convex_collisions_from_file(self, *a, **kw):
         raise NotImplementedError("convex decomposition is not available in this build (SURVEY.md 8f rank 4)")
@@ -150,13 +151,13 @@ class ActorBuilder:
         assert self.name is not None and self.name != "" and self.name not in self.scene.actors, (
             "built actors in ManiSkill must have unique names and cannot be None or empty strings"
         )
-        for s in self.shapes:
-            s.collision_groups = tuple(self.collision_groups)
+        comp = self.build_physx_component()
+        comp.name = self.name
         init = Pose.create(self.initial_pose if self.initial_pose is not None else Pose.create_from_pq(), device=self.scene.device)
         if self.scene_idxs is not None and len(self.scene_idxs) != self.scene.num_envs:
             # fragment: lives in a subset of envs until merged
-            frag = Actor(self.scene, self.name, self.physx_body_type, init, has_collision_shapes=len(self.shapes) > 0)
-            frag._fragment = dict(scene_idxs=list(self.scene_idxs), shapes=list(self.shapes), linear_damping=self.linear_damping,
+            frag = Actor(self.scene, self.name, self.physx_body_type, init, has_collision_shapes=len(self.collision_shapes) > 0)
+            frag._fragment = dict(scene_idxs=list(self.scene_idxs), shapes=self.shapes, linear_damping=self.linear_damping,
                                   angular_damping=self.angular_damping)
             self.scene._fragments[self.name] = frag
             return frag
@@ -164,22 +165,12 @@ class ActorBuilder:
         if raw.shape[0] != 1:
             # per-env initial poses: the model keeps env 0's pose; the rest are written after gpu_init
             pass
-        rec = ActorRecord(
-            self.name,
-            self.physx_body_type,
-            list(self.shapes),
-            initial_pose=geom.pose(raw[0, :3], raw[0, 3:]),
-            linear_damping=self.linear_damping,
-            angular_damping=self.angular_damping,
-        )
-        if self._mass is not None:
-            rec.mass = self._mass
-            rec.com = None if self._cmass_local_pose is None else np.asarray(self._cmass_local_pose.p, dtype=np.float64)
-            rec.inertia = np.diag(self._inertia) if self._inertia is not None and np.ndim(self._inertia) == 1 else self._inertia
+        rec = comp.to_record(self.name, geom.pose(raw[0, :3], raw[0, 3:]))
         mass = 0.0
         if self.physx_body_type == "dynamic":
-            mass = rec.mass if rec.mass is not None else sum(s.mass_properties()[0] for s in self.shapes)
-        actor = Actor(self.scene, self.name, self.physx_body_type, init, has_collision_shapes=len(self.shapes) > 0, mass=mass)
+            mass = rec.mass if rec.mass is not None else sum(sr.mass_properties()[0] for sr in rec.shapes)
+        actor = Actor(self.scene, self.name, self.physx_body_type, init, has_collision_shapes=len(rec.shapes) > 0, mass=mass)
+        actor._px_component = comp
         self.scene._register_actor(actor, rec)
         return actor
 
