@@ -1,101 +1,101 @@
-"""PD joint position (+ delta, target-delta, mimic) controller -- counterpart of
-mani_skill/agents/controllers/pd_joint_pos.py:14-131."""
+"""PD joint position controllers: absolute, delta, target-delta, mimic, optionally interpolated over the substeps.
+Behavioural counterpart of mani_skill/agents/controllers/pd_joint_pos.py:14-131, built on joint_drive.py."""
 from dataclasses import dataclass
 from typing import Sequence, Union
 
 import numpy as np
-import torch
 from gymnasium import spaces
 
 from .base_controller import BaseController, ControllerConfig
+from .joint_drive import TARGET_RULES, TargetTrack, apply_joint_gains, fused_joint_columns
 
 
 class PDJointPosController(BaseController):
     config: "PDJointPosControllerConfig"
-    _start_qpos = None
-    _target_qpos = None
 
-    def _get_joint_limits(self):
-        qlimits = self.articulation.get_qlimits()[0, self.active_joint_indices.long()].cpu().numpy()
-        if self.config.lower is not None:
-            qlimits[:, 0] = self.config.lower
-        if self.config.upper is not None:
-            qlimits[:, 1] = self.config.upper
-        return qlimits
+    # ---- spaces / gains ---------------------------------------------------------------------------------------------
+    def _get_joint_limits(self) -> np.ndarray:
+        """[n_joints, 2]: the articulation's limits, overridden by the config's `lower` / `upper` where given"""
+        lim = self.articulation.get_qlimits()[0, self.active_joint_indices.long()].cpu().numpy()
+        for col, override in enumerate((self.config.lower, self.config.upper)):
+            if override is not None:
+                lim[:, col] = override
+        return lim
 
     def _initialize_action_space(self):
-        lim = self._get_joint_limits()
-        self.single_action_space = spaces.Box(lim[:, 0], lim[:, 1], dtype=np.float32)
+        low, high = self._get_joint_limits().T
+        self.single_action_space = spaces.Box(low, high, dtype=np.float32)
 
     def set_drive_property(self):
-        n = len(self.joints)
-        k = np.broadcast_to(self.config.stiffness, n)
-        d = np.broadcast_to(self.config.damping, n)
-        f = np.broadcast_to(self.config.force_limit, n)
-        fr = np.broadcast_to(self.config.friction, n)
-        for i, joint in enumerate(self.joints):
-            mode = self.config.drive_mode if isinstance(self.config.drive_mode, str) else self.config.drive_mode[i]
-            joint.set_drive_properties(k[i], d[i], force_limit=f[i], mode=mode)
-            joint.set_friction(fr[i])
+        c = self.config
+        apply_joint_gains(self.joints, stiffness=c.stiffness, damping=c.damping, force_limit=c.force_limit, friction=c.friction, drive_mode=c.drive_mode)
+
+    # ---- targets ----------------------------------------------------------------------------------------------------
+    @property
+    def _track(self) -> TargetTrack:
+        t = self.__dict__.get("_track_obj")
+        if t is None:
+            t = self.__dict__["_track_obj"] = TargetTrack()
+        return t
+
+    # (the names the subclasses -- pd_ee_pose, pd_joint_pos_vel -- and the tests read and write)
+    @property
+    def _start_qpos(self):
+        return self._track.start
+
+    @_start_qpos.setter
+    def _start_qpos(self, v):
+        self._track.start = v
+
+    @property
+    def _target_qpos(self):
+        return self._track.target
+
+    @_target_qpos.setter
+    def _target_qpos(self, v):
+        self._track.target = v
 
     def reset(self):
         super().reset()
         self._step = 0
-        if self._start_qpos is None or self.scene._reset_mask_all:
-            self._start_qpos = self.qpos.clone()
-            self._target_qpos = self.qpos.clone()
-        else:
-            m = self.scene._reset_idx
-            self._start_qpos[m] = self.qpos[m].clone()
-            self._target_qpos[m] = self.qpos[m].clone()
+        self._track.capture(self.qpos, None if self.scene._reset_mask_all else self.scene._reset_idx)
 
     def set_drive_targets(self, targets):
         self.articulation.set_joint_drive_targets(targets, self.joints, self.active_joint_indices)
 
     def set_action(self, action):
         action = self._preprocess_action(action)
+        c, track = self.config, self._track
         self._step = 0
-        # `qpos` is a view of the sim buffer here (the reference gets a gathered copy)
-        self._start_qpos = self.qpos.clone() if self.config.interpolate else self.qpos
-        if self.config.use_delta:
-            if self.config.use_target:
-                self._target_qpos = self._target_qpos + action
-            else:
-                self._target_qpos = self._start_qpos + action
+        # (`qpos` is a view of the simulation buffer: a copy is only needed when the start is used again in later substeps)
+        track.start = self.qpos.clone() if c.interpolate else self.qpos
+        track.target = TARGET_RULES[(bool(c.use_delta), bool(c.use_target))](action, track.start, track.target)
+        if c.interpolate:
+            self._step_size = (track.target - track.start) / self._sim_steps
         else:
-            self._target_qpos = torch.broadcast_to(action, self._start_qpos.shape).clone()
-        if self.config.interpolate:
-            self._step_size = (self._target_qpos - self._start_qpos) / self._sim_steps
-        else:
-            self.set_drive_targets(self._target_qpos)
+            self.set_drive_targets(track.target)
 
     def before_simulation_step(self):
         self._step += 1
         if self.config.interpolate:
-            self.set_drive_targets(self._start_qpos + self._step_size * self._step)
+            self.set_drive_targets(self._track.start + self._step_size * self._step)
             self.articulation.px.gpu_apply_articulation_target_position()
 
+    # ---- native action map / state ------------------------------------------------------------------------------------
     def fused_action_spec(self):
-        """[(dof, local action column, low, high, flags)] for the fused native action kernel, or None
-        when this controller keeps state across steps (use_target) or updates targets per substep"""
+        """rows for the fused native action kernel, or None when this controller keeps state across steps (use_target)
+        or updates targets per substep (interpolate)"""
         if self.config.use_target or self.config.interpolate:
             return None
-        nact = self.single_action_space.shape[0]
-        out = []
-        for i, dof in enumerate(self.active_joint_indices.tolist()):
-            col = i if nact == len(self.joints) else 0  # mimic controllers broadcast one column
-            lo = float(self.action_space_low[col]) if self._normalize_action else 0.0
-            hi = float(self.action_space_high[col]) if self._normalize_action else 0.0
-            flags = (1 if self.config.use_delta else 0) | (2 if self._normalize_action else 0)
-            out.append((dof, col, lo, hi, flags))
-        return out
+        return fused_joint_columns(self.active_joint_indices, self.single_action_space.shape[0], self.action_space_low, self.action_space_high,
+                                   self._normalize_action, 1 if self.config.use_delta else 0)
 
     def get_state(self) -> dict:
-        return {"target_qpos": self._target_qpos} if self.config.use_target else {}
+        return {"target_qpos": self._track.target} if self.config.use_target else {}
 
     def set_state(self, state: dict):
         if self.config.use_target:
-            self._target_qpos = state["target_qpos"]
+            self._track.target = state["target_qpos"]
 
 
 @dataclass
@@ -115,10 +115,12 @@ class PDJointPosControllerConfig(ControllerConfig):
 
 
 class PDJointPosMimicController(PDJointPosController):
+    """one action column drives every joint of the group (the Panda's two fingers)"""
+
     def _get_joint_limits(self):
         lim = super()._get_joint_limits()
-        assert np.allclose(lim[0:-1] - lim[1:], 0), "Mimic joints should have the same limit"
-        return lim[0:1]
+        assert np.allclose(lim, lim[:1]), "Mimic joints should have the same limit"
+        return lim[:1]
 
 
 class PDJointPosMimicControllerConfig(PDJointPosControllerConfig):

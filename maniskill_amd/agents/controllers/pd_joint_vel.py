@@ -1,4 +1,5 @@
-"""PD joint velocity controller (counterpart of mani_skill/agents/controllers/pd_joint_vel.py)."""
+"""PD joint velocity controller: the action is the drives' velocity target (zero stiffness).
+Behavioural counterpart of mani_skill/agents/controllers/pd_joint_vel.py, built on joint_drive.py."""
 from dataclasses import dataclass
 from typing import Sequence, Union
 
@@ -6,38 +7,26 @@ import numpy as np
 from gymnasium import spaces
 
 from .base_controller import BaseController, ControllerConfig
+from .joint_drive import apply_joint_gains, fused_joint_columns
 
 
 class PDJointVelController(BaseController):
     config: "PDJointVelControllerConfig"
 
     def _initialize_action_space(self):
-        n = len(self.joints)
-        low = np.float32(np.broadcast_to(self.config.lower, n))
-        high = np.float32(np.broadcast_to(self.config.upper, n))
-        self.single_action_space = spaces.Box(low, high, dtype=np.float32)
+        bounds = [np.broadcast_to(b, len(self.joints)).astype(np.float32) for b in (self.config.lower, self.config.upper)]
+        self.single_action_space = spaces.Box(*bounds, dtype=np.float32)
 
     def set_drive_property(self):
-        n = len(self.joints)
-        d = np.broadcast_to(self.config.damping, n)
-        f = np.broadcast_to(self.config.force_limit, n)
-        fr = np.broadcast_to(self.config.friction, n)
-        for i, joint in enumerate(self.joints):
-            joint.set_drive_properties(0, d[i], force_limit=f[i], mode=self.config.drive_mode)
-            joint.set_friction(fr[i])
+        c = self.config
+        apply_joint_gains(self.joints, stiffness=0.0, damping=c.damping, force_limit=c.force_limit, friction=c.friction, drive_mode=c.drive_mode)
 
     def set_action(self, action):
-        action = self._preprocess_action(action)
-        self.articulation.set_joint_drive_velocity_targets(action, self.joints, self.active_joint_indices)
+        self.articulation.set_joint_drive_velocity_targets(self._preprocess_action(action), self.joints, self.active_joint_indices)
 
     def fused_action_spec(self):
-        """[(dof, local action column, low, high, flags)] for the native action map: flag 8 = velocity target"""
-        out = []
-        for i, dof in enumerate(self.active_joint_indices.tolist()):
-            lo = float(self.action_space_low[i]) if self._normalize_action else 0.0
-            hi = float(self.action_space_high[i]) if self._normalize_action else 0.0
-            out.append((dof, i, lo, hi, 8 | (2 if self._normalize_action else 0)))
-        return out
+        """rows for the native action map: flag 8 = the value is the joint's velocity drive target"""
+        return fused_joint_columns(self.active_joint_indices, len(self.joints), self.action_space_low, self.action_space_high, self._normalize_action, 8)
 
 
 @dataclass

@@ -357,41 +357,67 @@ class BaseEnv(gym.Env):
         self._clear()
 
     def reset(self, seed: Union[None, int, List[int]] = None, options: Union[None, dict] = None):
-        if options is None:
-            options = dict()
-        reconfigure = options.get("reconfigure", False)
-        reconfigure = reconfigure or (self._reconfig_counter == 0 and self.reconfiguration_freq != 0)
-        partial = "env_idx" in options
-        if partial:
-            env_idx = common.to_tensor(options["env_idx"], device=self.device).long()
-            if len(env_idx) != self.num_envs and reconfigure:
-                raise RuntimeError("Cannot do a partial reset and reconfigure the environment. You must do one or the other.")
-            if len(env_idx) == 0 and not reconfigure:  # nothing to reset: the current observation, no episode is touched
-                info = self.get_info()
-                obs = self.get_obs(info)
-                info["reconfigure"] = False
-                return obs, info
-        else:
-            env_idx = torch.arange(0, self.num_envs, device=self.device)
+        """full reset, or a partial one (`options["env_idx"]`); `options["reconfigure"]` rebuilds the scene first.
+        Phases: request -> seeding (+ optional reconfiguration) -> physics state of the selected envs -> outputs.
+        Behavioural contract: mani_skill/envs/sapien_env.py:776-879."""
+        options = {} if options is None else options
+        env_idx, partial, reconfigure = self._reset_request(options)
+        if env_idx is None:  # an empty partial reset: the current observation, no episode is touched
+            info = self.get_info()
+            info["reconfigure"] = False
+            return self.get_obs(info), info
+        self._seed_reset(seed, env_idx, reconfigure, options)
+        self._reset_selected_envs(seed, env_idx, partial, options)
+        obs, info = self._reset_outputs()
+        info["reconfigure"] = reconfigure
+        return obs, info
 
+    def _reset_request(self, options: dict):
+        """-> (env indices to reset or None for "nothing to do", partial?, reconfigure?)"""
+        reconfigure = bool(options.get("reconfigure", False)) or (self._reconfig_counter == 0 and self.reconfiguration_freq != 0)
+        if "env_idx" not in options:
+            return torch.arange(0, self.num_envs, device=self.device), False, reconfigure
+        env_idx = common.to_tensor(options["env_idx"], device=self.device).long()
+        if reconfigure and len(env_idx) != self.num_envs:
+            raise RuntimeError("Cannot do a partial reset and reconfigure the environment. You must do one or the other.")
+        if len(env_idx) == 0 and not reconfigure:
+            return None, True, False
+        return env_idx, True, reconfigure
+
+    def _seed_reset(self, seed, env_idx, reconfigure: bool, options: dict):
         self._set_main_rng(seed)
-        if reconfigure:
-            self._set_episode_rng(seed if seed is not None else self._batched_main_rng.randint(2**31), env_idx)
-            with torch.random.fork_rng():
-                torch.manual_seed(seed=int(self._episode_seed[0]))
-                self._reconfigure(options)
-                self._after_reconfigure(options)
-            self._set_episode_rng(self._episode_seed, env_idx)
-        else:
+        if not reconfigure:
             self._set_episode_rng(seed, env_idx)
+            return
+        # a reconfiguration is seeded like an episode (its own torch stream), and the episode that follows starts from
+        # the same seeds again
+        self._set_episode_rng(seed if seed is not None else self._batched_main_rng.randint(2**31), env_idx)
+        with torch.random.fork_rng():
+            torch.manual_seed(seed=int(self._episode_seed[0]))
+            self._reconfigure(options)
+            self._after_reconfigure(options)
+        self._set_episode_rng(self._episode_seed, env_idx)
 
-        self.scene._set_reset_idx(env_idx if partial else None)
+    def _reset_selected_envs(self, seed, env_idx, partial: bool, options: dict):
+        scene = self.scene
+        scene._set_reset_idx(env_idx if partial else None)  # every struct setter below writes the selected envs only
         self._elapsed_steps[env_idx] = 0
         self._clear_sim_state()
         if self.reconfiguration_freq != 0:
             self._reconfig_counter -= 1
         if self.agent is not None:
             self.agent.reset()
+        self._run_initialize_episode(seed, env_idx, options)
+        scene._set_reset_idx(None)
+        scene._gpu_apply_all()
+        scene.px.gpu_update_articulation_kinematics()
+        scene._gpu_fetch_all()
+        if self.agent is not None:
+            self.agent.controller.reset()  # (under the all-envs mask, as the reference: sapien_env.py:857-871)
+
+    def _run_initialize_episode(self, seed, env_idx, options: dict):
+        """`_initialize_episode` under the torch RNG rule of the reset: per-env streams (enhanced determinism), one
+        stream seeded with env 0's episode seed (explicit seed), or the ambient stream"""
         if self._enhanced_determinism:
             # every env draws from its own torch stream (seeded with its episode seed), as it does from its own numpy
             # stream: env e gets the same episode in any batch, shard (SURVEY.md 8e) or partial reset
@@ -407,56 +433,44 @@ class BaseEnv(gym.Env):
                 self._initialize_episode(env_idx, options)
         else:
             self._initialize_episode(env_idx, options)
-        controller_mask = (self.scene._reset_mask, self.scene._reset_mask_all)
-        self.scene._set_reset_idx(None)
-        self.scene._gpu_apply_all()
-        self.scene.px.gpu_update_articulation_kinematics()
-        self.scene._gpu_fetch_all()
 
-        if self.agent is not None:
-            # the reference resets controllers under the all-ones mask (sapien_env.py:857-871)
-            self.agent.controller.reset()
-
+    def _reset_outputs(self):
+        """obs / info of the state the reset produced (the native epilogue without advancing the step counter where the
+        task has one: same values, see the GPU tests)"""
         fused = self._fused_step_outputs(None, advance=False) if (self._use_fused_callers and self._fused_ok()) else None
-        if fused is not None:  # evaluate + obs of the reset state in one native launch (same values, see the GPU tests)
+        if fused is not None:
             obs, _, info = fused
-        else:
-            info = self.get_info()
-            obs = self.get_obs(info)
-        info["reconfigure"] = reconfigure
-        return obs, info
+            return obs, info
+        info = self.get_info()
+        return self.get_obs(info), info
 
+    # RNG rules (reference: sapien_env.py:881-917), expressed through BatchedRNG: a main stream per env, seeded once per
+    # explicit seed; an episode stream per env, reseeded at every reset -- from the given seed(s), or (enhanced
+    # determinism) from the env's own main stream, otherwise left running
     def _set_main_rng(self, seed):
         if seed is None:
             if self._main_seed is not None:
                 return
             seed = np.random.RandomState().randint(2**31, size=(self.num_envs,))
-        if not np.iterable(seed):
-            seed = [seed]
-        self._main_seed = list(seed)
+        seeds = BatchedRNG.expand_seeds(seed, self.num_envs)
+        self._main_seed = seeds.tolist()
         self._main_rng = np.random.RandomState(self._main_seed[0])
-        if len(self._main_seed) == 1 and self.num_envs > 1:
-            self._main_seed = self._main_seed + np.random.RandomState(self._main_seed[0]).randint(2**31, size=(self.num_envs - 1,)).tolist()
-        self._batched_main_rng = BatchedRNG.from_seeds(self._main_seed, backend=self._batched_rng_backend)
+        self._batched_main_rng = BatchedRNG.from_seeds(seeds, backend=self._batched_rng_backend)
 
     def _set_episode_rng(self, seed, env_idx: torch.Tensor):
-        if seed is not None or self._enhanced_determinism:
-            env_idx = common.to_numpy(env_idx)
-            if seed is None:
-                self._episode_seed[env_idx] = self._batched_main_rng[env_idx].randint(2**31)
-            else:
-                if not np.iterable(seed):
-                    seed = [seed]
-                self._episode_seed = common.to_numpy(seed, dtype=np.int64)
-                if len(self._episode_seed) == 1 and self.num_envs > 1:
-                    self._episode_seed = np.concatenate(
-                        (self._episode_seed, np.random.RandomState(self._episode_seed[0]).randint(2**31, size=(self.num_envs - 1,)))
-                    )
-            if seed is not None or self._batched_episode_rng is None:
+        if seed is None and not self._enhanced_determinism:
+            return
+        rows = common.to_numpy(env_idx)
+        if seed is not None:
+            self._episode_seed = BatchedRNG.expand_seeds(seed, self.num_envs)
+            self._batched_episode_rng = BatchedRNG.from_seeds(self._episode_seed, backend=self._batched_rng_backend)
+        else:
+            self._episode_seed[rows] = self._batched_main_rng[rows].randint(2**31)
+            if self._batched_episode_rng is None:
                 self._batched_episode_rng = BatchedRNG.from_seeds(self._episode_seed, backend=self._batched_rng_backend)
             else:
-                self._batched_episode_rng[env_idx] = BatchedRNG.from_seeds(self._episode_seed[env_idx], backend=self._batched_rng_backend)
-            self._episode_rng = self._batched_episode_rng[0]
+                self._batched_episode_rng.reseed(rows, self._episode_seed[rows])
+        self._episode_rng = self._batched_episode_rng[0]
 
     def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
         pass

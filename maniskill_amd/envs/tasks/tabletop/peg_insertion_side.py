@@ -145,29 +145,37 @@ class PegInsertionSideEnv(BaseEnv):
             self.agent.robot.set_qpos(qpos)
             self.agent.robot.set_pose(sapien.Pose([-0.615, 0, 0]))
 
-    # ---- frequently used frames -------------------------------------------------
+    # ---- frequently used frames: a body pose composed with per-env offsets ------------------------------------------
+    # name -> (actor attribute, offset attributes applied left to right; a trailing "~" inverts that offset)
+    _FRAMES = {
+        "peg_head_pose": ("peg", ("peg_head_offsets",)),
+        "box_hole_pose": ("box", ("box_hole_offsets",)),
+        "goal_pose": ("box", ("box_hole_offsets", "peg_head_offsets~")),  # where the peg centre sits when the head is in the hole
+    }
+
+    def _frame(self, name: str) -> Pose:
+        actor, offsets = self._FRAMES[name]
+        pose = getattr(self, actor).pose
+        for off in offsets:
+            o = getattr(self, off.rstrip("~"))
+            pose = pose * (o.inv() if off.endswith("~") else o)
+        return pose
+
+    peg_head_pose = property(lambda self: self._frame("peg_head_pose"))
+    box_hole_pose = property(lambda self: self._frame("box_hole_pose"))
+    goal_pose = property(lambda self: self._frame("goal_pose"))
+
     @property
     def peg_head_pos(self):
+        """(position only: the offset is NOT rotated with the peg -- as the reference's property of this name)"""
         return self.peg.pose.p + self.peg_head_offsets.p
 
-    @property
-    def peg_head_pose(self):
-        return self.peg.pose * self.peg_head_offsets
-
-    @property
-    def box_hole_pose(self):
-        return self.box.pose * self.box_hole_offsets
-
-    @property
-    def goal_pose(self):
-        return self.box.pose * self.box_hole_offsets * self.peg_head_offsets.inv()
-
     def has_peg_inserted(self):
-        """peg head within 0.015 m of the hole centre plane and inside the hole's cross-section"""
-        head_at_hole = (self.box_hole_pose.inv() * self.peg_head_pose).p
-        r = self.box_hole_radii
-        ok = (head_at_hole[:, 0] >= -0.015) & (head_at_hole[:, 1].abs() <= r) & (head_at_hole[:, 2].abs() <= r)
-        return ok, head_at_hole
+        """(inserted?, head position in the hole frame): the head is at most 0.015 m short of the hole centre plane and
+        inside the hole's square cross-section"""
+        head = (self._frame("box_hole_pose").inv() * self._frame("peg_head_pose")).p
+        inside = (head[:, 1:].abs() <= self.box_hole_radii[:, None]).all(dim=1)
+        return inside & (head[:, 0] >= -0.015), head
 
     def evaluate(self):
         success, head_at_hole = self.has_peg_inserted()

@@ -22,6 +22,19 @@ class BatchedRNG:
     def from_rngs(cls, rngs):
         return cls(rngs)
 
+    @staticmethod
+    def expand_seeds(seed, n: int) -> np.ndarray:
+        """the seeding rule of the env (mani_skill/envs/sapien_env.py:881-917): one seed per env; a scalar or a single
+        seed is used for env 0 and the other n - 1 are drawn from `RandomState(that seed)`"""
+        seeds = np.atleast_1d(common.to_numpy(seed)).astype(np.int64)
+        if len(seeds) == 1 and n > 1:
+            seeds = np.concatenate((seeds, np.random.RandomState(int(seeds[0])).randint(2**31, size=(n - 1,))))
+        return seeds
+
+    def reseed(self, idx, seeds):
+        """new streams for the envs in `idx`"""
+        self[idx] = BatchedRNG.from_seeds(seeds)
+
     def __getitem__(self, idx):
         idx = common.to_numpy(idx)
         if np.iterable(idx):

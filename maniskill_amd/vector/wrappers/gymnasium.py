@@ -1,6 +1,12 @@
-"""ManiSkillVectorEnv: gym VectorEnv facade with partial auto-reset and episode metrics
-(counterpart of mani_skill/vector/wrappers/gymnasium.py:16-173)."""
-from typing import Dict, List, Optional, Tuple, Union
+"""ManiSkillVectorEnv: gym VectorEnv facade over one batched env -- episode metrics, `ignore_terminations`, partial
+auto-reset with `final_observation / final_info` (behavioural counterpart of
+mani_skill/vector/wrappers/gymnasium.py:16-173).
+
+The per-step bookkeeping is table driven: `EpisodeMetrics` holds one running tensor per metric and a list of
+(info key, metric name) pairs for the sticky "happened once" flags; `ManiSkillVectorEnv.step` is: step the env, update
+the metrics, mask the terminations, hand finished envs to `_auto_reset`.
+"""
+from typing import List, Optional, Union
 
 import gymnasium as gym
 import torch
@@ -10,6 +16,7 @@ from maniskill_amd.utils.common import torch_clone_dict
 
 
 def _wrapper_attr(env, name):
+    """attribute `name` of the outermost wrapper that defines it (falls back to the base env)"""
     cur = env
     while cur is not None:
         if name in getattr(cur, "__dict__", {}) or hasattr(type(cur), name):
@@ -18,27 +25,60 @@ def _wrapper_attr(env, name):
     return getattr(env.unwrapped, name)
 
 
+class EpisodeMetrics:
+    """running per-env episode statistics reported as `info["episode"]`"""
+
+    ONCE_FLAGS = (("success", "success_once"), ("fail", "fail_once"))  # info key -> sticky flag
+    AT_END = (("success", "success_at_end"), ("fail", "fail_at_end"))  # reported when terminations are ignored
+
+    def __init__(self, num_envs: int, device):
+        self.flags = {name: torch.zeros(num_envs, device=device, dtype=torch.bool) for _, name in self.ONCE_FLAGS}
+        self.returns = torch.zeros(num_envs, device=device, dtype=torch.float32)
+
+    def clear(self, env_idx=None):
+        rows = slice(None) if env_idx is None else env_idx
+        for f in self.flags.values():
+            f[rows] = False
+        self.returns[rows] = 0
+
+    def update(self, reward, info, episode_len, with_end_flags: bool) -> dict:
+        self.returns += reward
+        out = {}
+        for key, name in self.ONCE_FLAGS:
+            if key in info:
+                self.flags[name] = self.flags[name] | info[key]
+                out[name] = self.flags[name].clone()
+        out["return"] = self.returns.clone()
+        out["episode_len"] = episode_len.clone()
+        out["reward"] = out["return"] / out["episode_len"]
+        if with_end_flags:
+            out.update({name: info[key].clone() for key, name in self.AT_END if key in info})
+        return out
+
+
 class ManiSkillVectorEnv(VectorEnv):
     def __init__(self, env, num_envs: int = None, auto_reset: bool = True, ignore_terminations: bool = False, record_metrics: bool = False, **kwargs):
-        if isinstance(env, str):
-            self._env = gym.make(env, num_envs=num_envs, **kwargs)
-        else:
-            self._env = env
-        num_envs = self.base_env.num_envs
-        self.auto_reset = auto_reset
-        self.ignore_terminations = ignore_terminations
-        self.record_metrics = record_metrics
+        self._env = gym.make(env, num_envs=num_envs, **kwargs) if isinstance(env, str) else env
+        self.auto_reset, self.ignore_terminations, self.record_metrics = auto_reset, ignore_terminations, record_metrics
         self.spec = getattr(self._env, "spec", None)
-        super().__init__(num_envs, _wrapper_attr(self._env, "single_observation_space"), _wrapper_attr(self._env, "single_action_space"))
-        if not self.ignore_terminations and auto_reset:
-            assert self.base_env.reconfiguration_freq == 0 or self.base_env.num_envs == 1, (
-                "With partial resets, environment cannot be reconfigured automatically"
-            )
-        if self.record_metrics:
-            dev = self.base_env.device
-            self.success_once = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
-            self.fail_once = torch.zeros(self.num_envs, device=dev, dtype=torch.bool)
-            self.returns = torch.zeros(self.num_envs, device=dev, dtype=torch.float32)
+        base = self.base_env
+        super().__init__(base.num_envs, _wrapper_attr(self._env, "single_observation_space"), _wrapper_attr(self._env, "single_action_space"))
+        if auto_reset and not ignore_terminations:
+            assert base.reconfiguration_freq == 0 or base.num_envs == 1, "With partial resets, environment cannot be reconfigured automatically"
+        self._metrics = EpisodeMetrics(self.num_envs, base.device) if record_metrics else None
+
+    # (the reference exposes the running tensors by these names)
+    @property
+    def success_once(self):
+        return self._metrics.flags["success_once"]
+
+    @property
+    def fail_once(self):
+        return self._metrics.flags["fail_once"]
+
+    @property
+    def returns(self):
+        return self._metrics.returns
 
     @property
     def device(self):
@@ -53,56 +93,30 @@ class ManiSkillVectorEnv(VectorEnv):
         return self.base_env
 
     def reset(self, *, seed: Optional[Union[int, List[int]]] = None, options: Optional[dict] = None):
-        options = dict() if options is None else options
+        options = {} if options is None else options
         obs, info = self._env.reset(seed=seed, options=options)
-        if self.record_metrics:
-            if "env_idx" in options:
-                idx = options["env_idx"]
-                self.success_once[idx] = False
-                self.fail_once[idx] = False
-                self.returns[idx] = 0
-            else:
-                self.success_once[:] = False
-                self.fail_once[:] = False
-                self.returns[:] = 0
+        if self._metrics is not None:
+            self._metrics.clear(options.get("env_idx"))
         return obs, info
+
+    def _auto_reset(self, dones, obs, infos):
+        """finished envs start a new episode now; what the step returned for them moves to `final_*`"""
+        final_obs, final_info = torch_clone_dict(obs), torch_clone_dict(infos)
+        obs, infos = self.reset(options=dict(env_idx=torch.arange(0, self.num_envs, device=self.device)[dones]))
+        infos.update(final_observation=final_obs, final_info=final_info, _final_info=dones, _final_observation=dones, _elapsed_steps=dones)
+        return obs, infos
 
     def step(self, actions):
         obs, rew, terminations, truncations, infos = self._env.step(actions)
-        if self.record_metrics:
-            ep = dict()
-            self.returns += rew
-            if "success" in infos:
-                self.success_once = self.success_once | infos["success"]
-                ep["success_once"] = self.success_once.clone()
-            if "fail" in infos:
-                self.fail_once = self.fail_once | infos["fail"]
-                ep["fail_once"] = self.fail_once.clone()
-            ep["return"] = self.returns.clone()
-            ep["episode_len"] = self.base_env.elapsed_steps.clone()
-            ep["reward"] = ep["return"] / ep["episode_len"]
         if isinstance(terminations, bool):
             terminations = torch.tensor([terminations], device=self.device)
+        if self._metrics is not None:
+            infos["episode"] = self._metrics.update(rew, infos, self.base_env.elapsed_steps, with_end_flags=self.ignore_terminations)
         if self.ignore_terminations:
             terminations[:] = False
-            if self.record_metrics:
-                if "success" in infos:
-                    ep["success_at_end"] = infos["success"].clone()
-                if "fail" in infos:
-                    ep["fail_at_end"] = infos["fail"].clone()
-        if self.record_metrics:
-            infos["episode"] = ep
         dones = torch.logical_or(terminations, truncations)
         if self.auto_reset and bool(dones.any()):
-            final_obs = torch_clone_dict(obs)
-            env_idx = torch.arange(0, self.num_envs, device=self.device)[dones]
-            final_info = torch_clone_dict(infos)
-            obs, infos = self.reset(options=dict(env_idx=env_idx))
-            infos["final_observation"] = final_obs
-            infos["final_info"] = final_info
-            infos["_final_info"] = dones
-            infos["_final_observation"] = dones
-            infos["_elapsed_steps"] = dones
+            obs, infos = self._auto_reset(dones, obs, infos)
         return obs, rew, terminations, truncations, infos
 
     def close(self):
