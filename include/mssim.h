@@ -50,6 +50,25 @@ extern "C" {
  * current pose (a pseudo-inverse IK step next to a singular arm configuration asks for tens of radians) accelerate
  * the arm until the explicitly integrated velocity-product terms diverge. */
 #define MSSIM_MAX_JOINT_VELOCITY 100.0f
+/* Persistent contact manifolds (types.py:44 enable_pcm) for the generic convex pairs (everything that is not plane-X or
+ * box-box, i.e. whatever the one-point MPR query serves): every env keeps MSSIM_PCM_SLOTS manifolds of up to 4 points, each
+ * point stored in the frames of both shapes with the gap it was generated with. Per substep a pair's points are REFRESHED
+ * (moved with their shapes; gap += relative displacement along the normal; dropped when they drift sideways by more than
+ * MSSIM_PCM_DRIFT or open beyond the contact offset) and the full query runs only when the manifold is empty or the
+ * relative pose of the two shapes has changed by more than MSSIM_PCM_MOVE / MSSIM_PCM_ROT_TRACE since the last query; its
+ * point is merged in (replacing a point within MSSIM_PCM_MERGE, else appended; 5 -> 4 by the patch selection rule). A
+ * manifold that starts from nothing is completed at once by three GROWTH queries -- shape A tilted by MSSIM_PCM_TILT about
+ * the manifold, so that the query finds a corner it does not have yet (about a tangent through the single point, then about
+ * the edge of the first two points, either side) -- and one that still has fewer than 3 points gets up to MSSIM_PCM_GROW
+ * more of them, one per substep. A pair that is in range but not in contact keeps an empty slot, so it is not queried
+ * again until it moves. */
+#define MSSIM_PCM_SLOTS 16
+#define MSSIM_PCM_DRIFT 5e-3f       /* m, sideways drift that breaks a cached point (0.25 x contact offset)          */
+#define MSSIM_PCM_MOVE 1e-3f        /* m, relative translation since the last full query that forces a new one       */
+#define MSSIM_PCM_ROT_TRACE 2.9996f /* trace(R_last^T R_now) below this (relative rotation > ~1.15 deg) forces one   */
+#define MSSIM_PCM_TILT 0.05f        /* rad, tilt of shape A in a growth query                                                */
+#define MSSIM_PCM_GROW 6            /* a new manifold with fewer than 3 points is queried again in up to this many substeps  */
+#define MSSIM_PCM_MERGE 2e-3f       /* m, a new point this close (in shape A's frame) to a cached one replaces it    */
 /* PxSceneDesc::wakeCounterResetValue (PhysX default 20 * 0.02 s): how long the energy of a free body has to stay below
  * sleep_threshold before it is put to sleep */
 #define MSSIM_WAKE_TIME 0.4f
@@ -249,8 +268,8 @@ int MSSIM_FN(fetch)(mssim_handle h, uint32_t what, void* stream);
 int MSSIM_FN(defer_fetch)(mssim_handle h, uint32_t what);
 /* px.step() x n_substeps (scene.py:374-375; loop at sapien_env.py:1016-1021).  No host sync. */
 int MSSIM_FN(step)(mssim_handle h, int32_t n_substeps, void* stream);
-/* Wake every sleeping free body (PxRigidDynamic::wakeUp for all of them; see sleep_threshold): the sleep counters are
- * simulation state that `rigid_body_data` does not carry, so a caller that restores a state and wants the run that
+/* Wake every sleeping free body (PxRigidDynamic::wakeUp for all of them; see sleep_threshold) and forget the persistent
+ * contact manifolds: the sleep counters and the manifold cache are simulation state that `rigid_body_data` does not carry, so a caller that restores a state and wants the run that
  * follows to depend on that state alone (BaseEnv.set_state_dict, envs/sapien_env.py:1167-1179) calls this after apply. */
 int MSSIM_FN(wake_all)(mssim_handle h, void* stream);
 /* px.gpu_update_articulation_kinematics() (sapien_env.py:861-865) */

@@ -83,6 +83,18 @@ struct Contact {
   Vec tors_n;  // the patch anchor's normal
 };
 
+// one persistent manifold (include/mssim.h, MSSIM_PCM_*)
+struct PcmSlot {
+  int pair = -1, npts = 0, stamp = 0;
+  Vec relp;      // B's frame origin in A's frame at the last full query
+  Mat relR;      // B's rotation in A's frame at the last full query
+  Vec n_loc;     // normal in A's frame
+  Vec pA[4], pB[4];  // the contact point in A's / B's frame
+  Real sep0[4];      // gap it was generated with
+  bool queried_empty = false;  // the last full query found no contact
+  int grow = 0;                // full queries still owed to a young manifold with fewer than 3 points
+};
+
 struct EnvState {
   Pose<Real> root;
   std::vector<Real> q, qd, qt, qdt, qf, qacc;
@@ -96,6 +108,9 @@ struct EnvState {
   std::vector<SpatialV> body_vel;     // about O = root position
   std::vector<Vec> pair_impulse;
   std::vector<int> pair_count;
+  std::vector<PcmSlot> pcm = std::vector<PcmSlot>(MSSIM_PCM_SLOTS);
+  int pcm_tick = 0;
+  int mpr_queries = 0;  // full convex queries of the last substep (test / diagnostics)
   int overflow = 0;
   int raw_points = 0;  // manifold points of the last substep before the patch reduction
 };
@@ -262,6 +277,181 @@ void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Conta
   }
 }
 
+// the 4 most significant of n <= 8 points (deepest, farthest from it, largest area on either side of that edge about
+// `na`; every scan takes the first candidate within the tie tolerance of the extremum): keep[i] = 1 for the survivors
+void select4(int n, const Vec* x, const Real* sep, const Vec& na, char* keep) {
+  Real best = sep[0];
+  for (int i = 1; i < n; i++) best = std::min(best, sep[i]);
+  int i0 = -1;
+  for (int i = 0; i < n && i0 < 0; i++)
+    if (sep[i] <= best + Real(MSSIM_PATCH_TIE_SEP)) i0 = i;
+  const Vec p0 = x[i0];
+  auto first_near_max = [&](auto&& value, auto&& allowed, Real floor_) {
+    Real mx = floor_;
+    for (int i = 0; i < n; i++)
+      if (allowed(i)) mx = std::max(mx, value(i));
+    if (!(mx > floor_)) return -1;
+    for (int i = 0; i < n; i++)
+      if (allowed(i) && value(i) >= mx - Real(MSSIM_PATCH_TIE_REL) * mx) return i;
+    return -1;
+  };
+  const int i1 = first_near_max([&](int i) { const Vec d = x[i] - p0; return dot(d, d); }, [&](int i) { return i != i0; }, Real(-1));
+  const Vec ed = x[i1] - p0;
+  auto area = [&](int i) { return dot(cross(ed, x[i] - p0), na); };
+  const int i2 = first_near_max([&](int i) { return std::fabs(area(i)); }, [&](int i) { return i != i0 && i != i1; }, Real(-1));
+  const Real sgn2 = area(i2);
+  const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, Real(0));
+  for (int i = 0; i < n; i++) keep[i] = (i == i0 || i == i1 || i == i2 || i == i3) ? 1 : 0;
+}
+
+// generic convex pair through the persistent manifold cache (include/mssim.h, MSSIM_PCM_*)
+void pcm_collide(EnvState& E, int p, const Shape<Real>& A, const Shape<Real>& B, Real offset, Manifold<Real>& m) {
+  m.count = 0;
+  const int tick = E.pcm_tick;
+  PcmSlot* sl = nullptr;
+  for (auto& s : E.pcm)
+    if (s.pair == p) { sl = &s; break; }
+  bool fresh = false;
+  if (!sl) {
+    for (auto& s : E.pcm)
+      if (s.pair < 0) { sl = &s; break; }
+    if (!sl) {  // the least recently used slot, unless every slot was used in this substep
+      for (auto& s : E.pcm)
+        if (s.stamp < tick && (!sl || s.stamp < sl->stamp)) sl = &s;
+    }
+    if (!sl) {  // no slot: the plain one-point query
+      E.mpr_queries++;
+      collide_mpr(A, B, offset, m);
+      return;
+    }
+    fresh = true;
+    sl->pair = p; sl->npts = 0;
+  }
+  sl->stamp = tick;
+  const Vec relp = A.rot.tmul(B.c - A.c);
+  const Mat relR = mmul(mtranspose(A.rot), B.rot);
+  // refresh
+  auto world = [&](int j, Vec& wA, Vec& wB) { wA = A.c + A.rot * sl->pA[j]; wB = B.c + B.rot * sl->pB[j]; };
+  {
+    const Vec nw = A.rot * sl->n_loc;
+    int k = 0;
+    for (int j = 0; j < sl->npts; j++) {
+      Vec wA, wB;
+      world(j, wA, wB);
+      const Vec d = wA - wB;
+      const Real dn = dot(d, nw);
+      const Vec t = d - nw * dn;
+      if (dot(t, t) > Real(MSSIM_PCM_DRIFT) * Real(MSSIM_PCM_DRIFT) || sl->sep0[j] + dn > offset) continue;
+      sl->pA[k] = sl->pA[j]; sl->pB[k] = sl->pB[j]; sl->sep0[k] = sl->sep0[j];
+      k++;
+    }
+    sl->npts = k;
+  }
+  // the full query runs for a new pair, for a pair that has moved since the last one, and for a manifold that lost
+  // all its points (unless the last query of the unmoved pair already found nothing)
+  bool moved = false;
+  if (!fresh) {
+    const Vec dp = relp - sl->relp;
+    Real tr = 0;
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) tr += sl->relR.m[a][b] * relR.m[a][b];
+    moved = dot(dp, dp) > Real(MSSIM_PCM_MOVE) * Real(MSSIM_PCM_MOVE) || tr < Real(MSSIM_PCM_ROT_TRACE);
+  }
+  // a point found by a query on shape A posed as `Aq` joins the manifold: it replaces a cached point within
+  // MSSIM_PCM_MERGE of it, else it is appended; a fifth point makes the patch selection rule pick four
+  auto merge = [&](const Shape<Real>& Aq, const Manifold<Real>& g) {
+    const Vec pA = Aq.rot.tmul(g.x[0] - Aq.c), pB = B.rot.tmul(g.x[0] - B.c);
+    int at = -1;
+    for (int j = 0; j < sl->npts && at < 0; j++) {
+      const Vec d = pA - sl->pA[j];
+      if (dot(d, d) < Real(MSSIM_PCM_MERGE) * Real(MSSIM_PCM_MERGE)) at = j;
+    }
+    if (at < 0) at = sl->npts < 4 ? sl->npts++ : 4;
+    if (at < 4) {
+      sl->pA[at] = pA; sl->pB[at] = pB; sl->sep0[at] = g.sep[0];
+      return;
+    }
+    // 5 candidates -> 4: world points and gaps under the true pose and the manifold's normal, the new point last
+    Vec x[5], qa[5], qb[5]; Real sp[5], s0[5]; char keep[5];
+    const Vec nw = A.rot * sl->n_loc;
+    for (int j = 0; j < 4; j++) { qa[j] = sl->pA[j]; qb[j] = sl->pB[j]; s0[j] = sl->sep0[j]; }
+    qa[4] = pA; qb[4] = pB; s0[4] = g.sep[0];
+    for (int j = 0; j < 5; j++) {
+      const Vec wA = A.c + A.rot * qa[j], wB = B.c + B.rot * qb[j];
+      x[j] = (wA + wB) * Real(0.5);
+      sp[j] = s0[j] + dot(wA - wB, nw);
+    }
+    select4(5, x, sp, nw, keep);
+    int k = 0;
+    for (int j = 0; j < 5; j++)
+      if (keep[j] && k < 4) { sl->pA[k] = qa[j]; sl->pB[k] = qb[j]; sl->sep0[k] = s0[j]; k++; }
+    sl->npts = k;
+  };
+  // A growth query looks for a corner the manifold does not have yet: shape A is tilted by MSSIM_PCM_TILT about the
+  // manifold (about a tangent through its single point; about the line through its first two points; `flip` picks the
+  // side), which pushes the far side of the contact face into B. The point found is stored like any other -- as a
+  // material point of both shapes -- so its gap under the true pose comes out of the refresh.
+  auto growth_query = [&](bool flip) {
+    const Vec nw = A.rot * sl->n_loc;
+    Vec w0, wb0;
+    world(0, w0, wb0);
+    const Vec pivot = (w0 + wb0) * Real(0.5);
+    Vec axis;
+    if (sl->npts >= 2) {
+      Vec w1, wb1;
+      world(1, w1, wb1);
+      axis = normalized((w1 + wb1) * Real(0.5) - pivot);
+    } else {
+      axis = std::fabs(nw.x) < Real(0.57735) ? normalized(cross(nw, Vec(1, 0, 0))) : normalized(cross(nw, Vec(0, 1, 0)));
+    }
+    if (flip) axis = -axis;
+    const Mat Rt = qmat(qaxis_angle(axis, Real(MSSIM_PCM_TILT)));
+    Shape<Real> Aq = A;
+    Aq.rot = mmul(Rt, A.rot);
+    Aq.c = pivot + Rt * (A.c - pivot);
+    Manifold<Real> g;
+    E.mpr_queries++;
+    collide_mpr(Aq, B, offset, g);
+    if (g.count > 0) merge(Aq, g);
+  };
+  const bool growing = !moved && sl->npts > 0 && sl->npts < 3 && sl->grow > 0;  // a young manifold short of a face contact
+  if (fresh || moved || (sl->npts == 0 && !sl->queried_empty)) {
+    E.mpr_queries++;
+    Manifold<Real> g;
+    collide_mpr(A, B, offset, g);
+    sl->relp = relp; sl->relR = relR;
+    sl->queried_empty = g.count == 0;
+    if (g.count == 0) {
+      sl->npts = 0;
+    } else {
+      const Vec n_new = A.rot.tmul(g.n);
+      if (sl->npts > 0 && dot(n_new, sl->n_loc) < Real(MSSIM_PATCH_COS)) sl->npts = 0;  // the contact turned: start over
+      const bool started = sl->npts == 0;
+      sl->n_loc = n_new;
+      merge(A, g);
+      if (started) {
+        // a new manifold is completed at once: three growth queries (tangent, then both sides of the first edge)
+        sl->grow = MSSIM_PCM_GROW;
+        growth_query(false);
+        growth_query(false);
+        growth_query(true);
+      }
+    }
+  } else if (growing) {
+    sl->grow--;
+    growth_query((sl->grow & 1) != 0);
+  }
+  // the manifold as it stands
+  const Vec nw = A.rot * sl->n_loc;
+  m.count = sl->npts;
+  m.n = nw;
+  for (int j = 0; j < sl->npts; j++) {
+    Vec wA, wB;
+    world(j, wA, wB);
+    m.x[j] = (wA + wB) * Real(0.5);
+    m.sep[j] = sl->sep0[j] + dot(wA - wB, nw);
+  }
+}
+
 void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) {
   out.clear();
   E.pair_count.assign(M.n_pair, 0);
@@ -269,6 +459,8 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
   for (int s = 0; s < M.n_shape; s++) sh[s] = make_shape(M, E, s, e);
   std::vector<Contact> raw;
   std::vector<RawManifold> man;
+  E.pcm_tick++;
+  E.mpr_queries = 0;
   int hits = 0;  // pairs that survive the cull (the kernels' hit list holds MSSIM_MAX_HITS of them)
   for (int p = 0; p < M.n_pair; p++) {
     int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
@@ -289,7 +481,8 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
       if (dot(d, d) > rr * rr) continue;
     }
     Manifold<Real> m;
-    collide(A, B, M.contact_offset, m);
+    if (A.type == SH_PLANE || (A.type == SH_BOX && B.type == SH_BOX)) collide(A, B, M.contact_offset, m);
+    else pcm_collide(E, p, A, B, M.contact_offset, m);
     if (m.count <= 0) continue;
     hits++;
     if ((int)raw.size() + m.count > MSSIM_MAX_RAW_POINTS) { E.overflow |= MSSIM_OVERFLOW_RAW; break; }
@@ -954,7 +1147,10 @@ int mssim_ref_step(mssim_handle h, int32_t n_substeps, void*) {
 }
 
 int mssim_ref_wake_all(mssim_handle h, void*) {
-  for (auto& E : h->env) std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
+  for (auto& E : h->env) {
+    std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
+    for (auto& s : E.pcm) s = PcmSlot();
+  }
   return 0;
 }
 
@@ -1049,6 +1245,9 @@ int mssim_ref_read_internal(mssim_handle h, const char* name, float* out, int32_
         const Vec& v = h->env[e].pair_impulse[p];
         put(3 * p, e, v.x); put(3 * p + 1, e, v.y); put(3 * p + 2, e, v.z);
       }
+  } else if (s == "mpr_queries") {  // (oracle only: full convex queries of the last substep)
+    items = 1;
+    for (int e = 0; e < N; e++) put(0, e, h->env[e].mpr_queries);
   } else if (s == "free_wake") {
     items = M.n_free;
     for (int e = 0; e < N; e++) for (int b = 0; b < items; b++) put(b, e, h->env[e].free_wake[b]);

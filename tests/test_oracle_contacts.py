@@ -405,3 +405,55 @@ def test_contact_patches_cut_a_compound_body_to_four_points():
     assert int(cnt.sum()) == 4
     # the four survivors span the whole footprint: x from -0.05 to 0.05 (not one box's 4 corners)
     assert (cnt > 0).sum() == 2
+
+
+def _slab_on_table(as_hull=True):
+    """a 0.2 x 0.12 x 0.04 m slab on the table: as a convex hull (8 vertices -> the generic convex path: one point per
+    MPR query, persistent manifold) or as a box (box-box manifold, 4 points at once)"""
+    half = np.array([0.1, 0.06, 0.02])
+    if as_hull:
+        verts = np.array([[sx * half[0], sy * half[1], sz * half[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+        shape = ShapeRecord("convex", geom.pose(), vertices=verts)
+    else:
+        shape = ShapeRecord("box", geom.pose(), half_size=half)
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(ActorRecord("slab", "dynamic", [shape], initial_pose=geom.pose([0, 0, 0.02])))
+    return b.compile()
+
+
+def test_persistent_manifold_lets_a_hull_rest_without_rocking():
+    """enable_pcm (mani_skill/utils/structs/types.py:44): a convex hull lying on the table gets ONE point per full
+    query; the persistent manifold is completed by three growth queries in the substep in which it starts (4 queries, 4
+    points), after which the slab rests flat like its box twin -- no rocking, no full queries while nothing moves --
+    and goes to sleep"""
+    model = _slab_on_table(True)
+    px = ob.make_system(model, 1)
+    row = model.row_of("slab")
+    counts, queries, tilt = [], [], []
+    for i in range(30):
+        px.step(1)
+        px.gpu_fetch_all()
+        counts.append(int(px.read_internal("contact_count", model.n_pair).sum()))
+        queries.append(int(px.read_internal("mpr_queries", 1)[0, 0]))
+        q = px.cuda_rigid_body_data.torch()[row, 3:7]
+        tilt.append(float(2 * torch.acos(torch.clamp(q[0].abs(), max=1.0))))
+    assert counts[0] == 4 and min(counts) == 4, counts
+    assert queries[0] == 4 and sum(queries[1:]) == 0, queries  # a resting manifold is refreshed, not regenerated
+    assert max(tilt) < np.deg2rad(0.05), np.rad2deg(max(tilt))
+    s = px.cuda_rigid_body_data.torch()[row]
+    assert abs(s[2].item() - 0.02) < 5e-4 and torch.max(torch.abs(s[7:13])) < 5e-3
+    px.step(60)
+    assert px.read_internal("free_wake", 1)[0, 0] == 0  # at rest long enough: asleep
+    # pushed sideways (a force for one substep at a time), the manifold follows: points drift out, new ones come in
+    for _ in range(20):
+        px.cuda_rigid_body_force.torch()[row, 0] = 6.0  # (mu m g = 2.8 N)
+        px.gpu_apply_rigid_dynamic_force()
+        px.step(1)
+    px.step(50)
+    px.gpu_fetch_all()
+    s = px.cuda_rigid_body_data.torch()[row]
+    assert s[0].item() > 0.03 and abs(s[2].item() - 0.02) < 1e-3
+    q = s[3:7]
+    assert float(2 * torch.acos(torch.clamp(q[0].abs(), max=1.0))) < np.deg2rad(3.0)
