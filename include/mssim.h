@@ -57,10 +57,11 @@ extern "C" {
  * MSSIM_PCM_DRIFT or open beyond the contact offset) and the full query runs only when the manifold is empty or the
  * relative pose of the two shapes has changed by more than MSSIM_PCM_MOVE / MSSIM_PCM_ROT_TRACE since the last query; its
  * point is merged in (replacing a point within MSSIM_PCM_MERGE, else appended; 5 -> 4 by the patch selection rule). A
- * manifold that starts from nothing is completed at once by three GROWTH queries -- shape A tilted by MSSIM_PCM_TILT about
- * the manifold, so that the query finds a corner it does not have yet (about a tangent through the single point, then about
- * the edge of the first two points, either side) -- and one that still has fewer than 3 points gets up to MSSIM_PCM_GROW
- * more of them, one per substep. A pair that is in range but not in contact keeps an empty slot, so it is not queried
+ * young manifold with fewer than 3 points whose pair is NOT moving gets up to MSSIM_PCM_GROW GROWTH queries, one per
+ * substep: shape A tilted by MSSIM_PCM_TILT about the manifold, so that the query finds a corner it does not have yet
+ * (about a tangent through the single point, about the edge of the first two points, alternating sides) -- a body that
+ * comes to rest on a face has its 3-4 points after as many substeps; a pair in relative motion costs one query per
+ * substep, as without the cache. A pair that is in range but not in contact keeps an empty slot, so it is not queried
  * again until it moves. */
 #define MSSIM_PCM_SLOTS 16
 #define MSSIM_PCM_DRIFT 5e-3f       /* m, sideways drift that breaks a cached point (0.25 x contact offset)          */
@@ -89,7 +90,7 @@ extern "C" {
  * by rounding noise (a different point set in f32 and f64, and from one substep to the next). */
 #define MSSIM_PATCH_TIE_SEP 1e-5f  /* separations within 10 micrometres of the deepest count as equal */
 #define MSSIM_PATCH_TIE_REL 1e-3f  /* squared distances / areas within 0.1 % of the largest count as equal */
-#define MSSIM_MAX_CONTACTS 48      /* contact points per env fed to the solver, after the patch reduction */
+#define MSSIM_MAX_CONTACTS 52      /* contact points per env fed to the solver, after the patch reduction */
 #define MSSIM_MAX_HITS 64          /* shape pairs per env that survive the cull               */
 #define MSSIM_MAX_RAW_POINTS 128   /* manifold points per env before the patch reduction      */
 

@@ -87,7 +87,7 @@ class PDJointPosController(BaseController):
         or updates targets per substep (interpolate)"""
         if self.config.use_target or self.config.interpolate:
             return None
-        return fused_joint_columns(self.active_joint_indices, self.single_action_space.shape[0], self.action_space_low, self.action_space_high,
+        return fused_joint_columns(self.active_joint_indices, self.single_action_space.shape[0], getattr(self, "action_space_low", None), getattr(self, "action_space_high", None),
                                    self._normalize_action, 1 if self.config.use_delta else 0)
 
     def get_state(self) -> dict:

@@ -26,7 +26,7 @@ class PDJointVelController(BaseController):
 
     def fused_action_spec(self):
         """rows for the native action map: flag 8 = the value is the joint's velocity drive target"""
-        return fused_joint_columns(self.active_joint_indices, len(self.joints), self.action_space_low, self.action_space_high, self._normalize_action, 8)
+        return fused_joint_columns(self.active_joint_indices, len(self.joints), getattr(self, "action_space_low", None), getattr(self, "action_space_high", None), self._normalize_action, 8)
 
 
 @dataclass

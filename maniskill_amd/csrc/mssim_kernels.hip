@@ -26,7 +26,7 @@
 #include "../../include/mssim.h"
 #include "mssim_collide.h"
 
-#define MAXC 48  // contact points per env fed to the solver (overflow is reported, never silent)
+#define MAXC 52  // solver blocks per env: contact points + torsional blocks (overflow is reported, never silent); 4 envs x the LDS tables = 40.0 KB per block, 4 blocks per CU
 
 struct DevModel {
   int n_dof, n_tendon, n_link, n_free, n_kin, n_shape, n_pair;
@@ -52,6 +52,8 @@ struct DevState {
   float *root, *q, *qd, *qt, *qdt, *qf, *qacc;  // [7][N], [n_dof][N] ...
   float *free_s, *free_force, *kin;             // [n_free*13][N], [n_free*3][N], [n_kin*7][N]
   float* free_wake;                             // [n_free][N] seconds of low energy left before the body sleeps; <= 0: asleep
+  float* pcm;                                   // [N][MSSIM_PCM_SLOTS][48] persistent contact manifolds (mssim_solve16.h S16_PCM_LEN)
+  int* pcm_tick;                                // [N] substep counter of the cache
   float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
   float* bodyaux;                               // [n_dof*6][N] world joint axis (3) + joint anchor (3)
   int* pair_cnt;                                // [n_pair][N] contact points of the pair in the last substep (after the patch reduction)
@@ -1023,6 +1025,9 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN, &D.rows))) { mssim_destroy(S); return rc; }
   AL(overflow, 1)
   AL(hit_list, 1 + MAXC)
+  AL(pcm_tick, 1)
+  if ((rc = dalloc(S, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN, &D.pcm))) { mssim_destroy(S); return rc; }
+  HIPCHK(S, hipMemset(D.pcm, 0xFF, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float)));  // pair = -1: every slot empty
 #undef AL
   // identity quaternions
   std::vector<float> ones(N, 1.0f);
@@ -1108,6 +1113,7 @@ int mssim_wake_all(mssim_handle h, void* stream) {
   flush_deferred(h, (hipStream_t)stream);
   const size_t cnt = (size_t)h->M.n_free * h->N;
   if (cnt > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->S.free_wake, MSSIM_WAKE_TIME, cnt);
+  HIPCHK(h, hipMemsetAsync(h->S.pcm, 0xFF, (size_t)h->N * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float), (hipStream_t)stream));  // every slot empty
   HIPCHK(h, hipGetLastError());
   return 0;
 }

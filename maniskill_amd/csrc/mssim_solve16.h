@@ -76,10 +76,12 @@
 #define S16_NP_BOUT (S16_NP_SCR + 860)    // [20] manifold of the group's current cooperative box-box pair
 #define S16_NP_ML (S16_U + 1648)  // [64 bytes] hit indices of this env's MPR (generic convex) pairs
 #define S16_NP_BL (S16_U + 1664)  // [64 bytes] hit indices of this env's box-box pairs
+#define S16_NP_SLOT (S16_U + 1680) // [64 bytes] persistent-manifold slot of each hit (255 none | slot | 0x80 newly assigned)
+#define S16_PCM_LEN 48            // floats per cache slot: pair npts stamp flags | relp(3) - | relR(9) n_loc(3) | 4 x (pA(3) pB(3) gap)
 #define S16_MAX_BBC 16            // box-box pairs per wave up to which they are worked on by 16-lane groups
 #define S16_MAX_MPR 64            // (= every hit: an arm folded onto itself and jammed into the table has 20+ hull pairs in range)
 static_assert(S16_NP_BOUT + 20 <= S16_NP_SCR + 896, "narrowphase staging exceeds the scratch area");
-static_assert(S16_NP_BL + 16 <= S16_REC, "narrowphase lists run into the contact records");
+static_assert(S16_NP_SLOT + 16 <= S16_REC, "narrowphase lists run into the contact records");
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
@@ -488,16 +490,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   // Only what changes over the step stays in registers across the substeps (q, qd, body pose, joint
   // axis / anchor, free-body velocity, applied force); per-env constants are (re)loaded inside the
   // loop after the narrowphase so that they are not live -- and spilled -- while it runs.
-  const pose_t root = pose_soa(S.root, 0, N, e);
-  const f3 O = root.p;
+  const pose_t root0 = pose_soa(S.root, 0, N, e);  // (kept in slot 0 of the LDS pose table, not in registers)
+  const f3 O = root0.p;
   float q_c = 0.f, qd_c = 0.f;
-  pose_t bp_c = root;
-  f3 aw_c = f3{0, 0, 0}, an_c = f3{0, 0, 0};
+  // (the body pose lives in the LDS pose table between its uses; the world joint axis / anchor are recomputed from
+  // the parent's pose after every narrowphase: neither is carried in registers across it)
   if (art) {
     q_c = SOA(S.q, c); qd_c = SOA(S.qd, c);
-    bp_c = pose_soa(S.bodypose, 7 * c, N, e);
-    aw_c = f3{SOA(S.bodyaux, 6 * c), SOA(S.bodyaux, 6 * c + 1), SOA(S.bodyaux, 6 * c + 2)};
-    an_c = f3{SOA(S.bodyaux, 6 * c + 3), SOA(S.bodyaux, 6 * c + 4), SOA(S.bodyaux, 6 * c + 5)};
   }
   // this control step's action -> drive target of joint c (mssim_step_action; same arithmetic as
   // k_apply_action). The target is read back by this lane in every substep.
@@ -530,6 +529,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   float fforce_c = (freel && fk < 3) ? SOA(S.free_force, 3 * fb_id + fk) : 0.f;
   // sleeping (include/mssim.h sleep_threshold): per free body the seconds left before it goes to sleep (<= 0: asleep)
   // and whether its mass-normalised kinetic energy is below the threshold ("calm"); both group-uniform
+  int pcm_tick = S.pcm_tick[e];  // substep counter of the env's persistent-manifold cache (least-recently-used stamps)
   float fwake[S16_MAX_FREE];
   bool fcalm[S16_MAX_FREE];
   // 0.5 (v^2 + w . I w / m) of free body b at pose quaternion q (body-frame inertia about the centre of mass)
@@ -554,33 +554,27 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   // pose table: root, links, free bodies, kinematic bodies
   {
     reinterpret_cast<unsigned*>(L)[S16_ANC + c] = (art ? M.dof_anc[c] : 0u) | self_c;
-    if (c == 0) lds_pose_store(L + S16_PT, root);
-    if (art) lds_pose_store(L + S16_BP + 7 * c, bp_c);
+    if (c == 0) lds_pose_store(L + S16_PT, root0);
+    if (art) lds_pose_store(L + S16_BP + 7 * c, pose_soa(S.bodypose, 7 * c, N, e));
     if (c < nf) lds_pose_store(L + S16_PT + 7 * (S16_PT_FREE + c), pose_soa(S.free_s, 13 * c, N, e));
     if (FUSED && c < M.n_kin) lds_pose_store(L + S16_PT + 7 * (S16_PT_KIN + c), pose_soa(S.kin, 7 * c, N, e));
   }
-  // previous step's hit list (pairs whose dense pair_cnt entry must be cleared if they are no longer
-  // in contact after this step): lane c holds entries c, c + 16, c + 32. Read here, at the start, so
-  // that the two dependent global loads are long done when the impulse phase needs them.
+  // previous step's hit list (pairs whose dense pair_cnt entry must be cleared if they are no longer in contact after
+  // this step): lane c holds entries c, c + 16, c + 32. Read after the narrowphase of the LAST substep: early enough
+  // for the two dependent global loads to be done when the impulse phase needs them, late enough not to be live
+  // across the narrowphase.
   int nold = 0, oldp[3] = {-1, -1, -1};
-  if (FUSED) {
-    nold = S.hit_list[e];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      if (c + 16 * k < nold) oldp[k] = S.hit_list[(size_t)(1 + c + 16 * k) * N + e];
-  }
   __syncthreads();
   PH(0);
 
   float v_c = 0.f;
   int nrow_con = 0;  // contacts of this env in the current substep (group-uniform)
   float lim_lam = 0.f;
-  pose_t nb = bp_c;
-  f3 naw = aw_c, nan = an_c;
 
   for (int sub = 0; sub < n_sub; sub++) {
     const bool last = sub == n_sub - 1;
     // ================================================================ contacts -> LDS records
+    pcm_tick++;
     int nc = 0;
     unsigned fdist = 0u;  // free bodies touched by a disturber in this substep (sleep counters)
     if (FUSED) {
@@ -724,6 +718,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           nh2 += __popc(m16);
         }
         nh = nh2 < S16_MAX_HIT ? nh2 : S16_MAX_HIT;
+        if (!live) nh = 0;  // (a shadow group of the last env produces nothing: its pairs would touch that env's manifold cache twice)
       }
       __syncthreads();
       if (__any(hit_over) && hit_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_HITS);
@@ -835,10 +830,52 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
       __syncthreads();
       PH(13);
-      // ---- stage B: generic convex pairs (MPR). A pair is worked on by one 16-lane group (hull scans shared by
-      // its lanes); the MPR pairs of all 4 envs form one task list that the 4 groups take round-robin, so an env
-      // with many such pairs does not serialise on its own group.
-      for (int t = g; t < TM; t += S16_ENVS_PER_BLOCK) {
+      // ---- stage B: generic convex pairs through the persistent manifold cache (include/mssim.h MSSIM_PCM_*).
+      // B0: every env's own group assigns cache slots to its pairs, in pair order (same pair -> its slot; else the
+      // first empty slot; else the least recently used one not touched in this substep; else none: plain query).
+      // Lane k holds the header word of slot k.
+      {
+        int4 hd = int4{-1, 0, 0, 0};
+        if (live) hd = *reinterpret_cast<const int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN);
+        const int4 hd0 = hd;
+        unsigned char* const slot_of = reinterpret_cast<unsigned char*>(L + S16_NP_SLOT);
+        const unsigned char* const ml = reinterpret_cast<const unsigned char*>(L + S16_NP_ML);
+        auto b16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
+        for (int k = 0; k < nml; k++) {
+          const int idx = ml[k];
+          const int p = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx] & 0xFFFF;
+          unsigned m16 = b16(hd.x == p);
+          bool fresh = false;
+          if (m16 == 0u) {
+            fresh = true;
+            m16 = b16(hd.x < 0);
+            if (m16 == 0u) {
+              int st = hd.z < pcm_tick ? hd.z : 0x7FFFFFFF;
+              int mn = st;
+              mn = min(mn, __builtin_amdgcn_update_dpp(0, mn, 0x128, 0xF, 0xF, false));
+              mn = min(mn, __builtin_amdgcn_update_dpp(0, mn, 0x124, 0xF, 0xF, false));
+              mn = min(mn, __builtin_amdgcn_update_dpp(0, mn, 0x122, 0xF, 0xF, false));
+              mn = min(mn, __builtin_amdgcn_update_dpp(0, mn, 0x121, 0xF, 0xF, false));
+              m16 = mn != 0x7FFFFFFF ? b16(st == mn) : 0u;
+            }
+          }
+          const int si = m16 ? (__ffs(m16) - 1) : -1;
+          if (c == si) {
+            if (fresh) { hd.x = p; hd.y = 0; hd.w = 0; }
+            hd.z = pcm_tick;
+          }
+          if (c == 0) slot_of[idx] = si < 0 ? 255 : (unsigned char)(si | (fresh ? 0x80 : 0));
+        }
+        if (live && (hd.x != hd0.x || hd.y != hd0.y || hd.z != hd0.z || hd.w != hd0.w))
+          *reinterpret_cast<int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN) = hd;
+      }
+      __threadfence_block();  // (the headers are read back below by other groups of this wave, through the CU's L1)
+      __syncthreads();
+      // B: a pair is worked on by one 16-lane group (hull scans shared by its lanes); the pairs of all 4 envs form
+      // one task list that the 4 groups take round-robin. Lanes 0..3 of the group hold the manifold's points.
+      for (int t0 = 0; t0 < TM; t0 += S16_ENVS_PER_BLOCK) {
+        const bool has = t0 + g < TM;
+        const int t = has ? t0 + g : t0;  // (idle groups shadow the round's first pair: valid shapes, no output)
         int ge = 0;
 #pragma unroll
         for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= mcum[j] ? 1 : 0;
@@ -852,16 +889,209 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         sup.c = c;
         SupCoop16::load_one(sup.va, A, c);
         SupCoop16::load_one(sup.vb, B, c);
-        manifold_t m;
-        collide_mpr_t(A, B, M.contact_offset, m, sup);
-        if (c == 0 && m.count > 0) {
-          const int off = pool_alloc(Lg, 1);
-          if (off >= 0) {
-            reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = 1;
-            reinterpret_cast<int*>(Lg)[S16_NP_OFF + idx] = off;
-            float* hn = Lg + S16_NP_HN + 3 * idx;
-            hn[0] = m.n.x; hn[1] = m.n.y; hn[2] = m.n.z;
-            *reinterpret_cast<float4*>(Lg + S16_NP_POOL + 4 * off) = float4{m.x[0].x, m.x[0].y, m.x[0].z, m.sep[0]};
+        const int sbyte = reinterpret_cast<const unsigned char*>(Lg + S16_NP_SLOT)[idx];
+        const bool cached = has && sbyte != 255;
+        const bool fresh = cached && (sbyte & 0x80);
+        float* const slot = S.pcm + ((size_t)(chunk * S16_ENVS_PER_BLOCK + ge) * MSSIM_PCM_SLOTS + (cached ? (sbyte & 15) : 0)) * S16_PCM_LEN;
+        auto b16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
+        // ---- slot -> registers: header in every lane, point c in lane c < 4
+        int npts = 0, grow = 0;
+        bool queried_empty = false;
+        f3 relp0 = f3{0, 0, 0}, nloc = f3{1, 0, 0};
+        float relR0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        f3 pA = f3{0, 0, 0}, pB = f3{0, 0, 0};
+        float s0 = 0.f;
+        if (cached && !fresh) {
+          const int4 h4 = *reinterpret_cast<const int4*>(slot);
+          npts = h4.y; grow = h4.w >> 8; queried_empty = h4.w & 1;
+          const float4 r1 = *reinterpret_cast<const float4*>(slot + 4), r2 = *reinterpret_cast<const float4*>(slot + 8), r3 = *reinterpret_cast<const float4*>(slot + 12),
+                       r4 = *reinterpret_cast<const float4*>(slot + 16);
+          relp0 = f3{r1.x, r1.y, r1.z};
+          relR0[0] = r2.x; relR0[1] = r2.y; relR0[2] = r2.z; relR0[3] = r2.w; relR0[4] = r3.x; relR0[5] = r3.y; relR0[6] = r3.z; relR0[7] = r3.w; relR0[8] = r4.x;
+          nloc = f3{r4.y, r4.z, r4.w};
+          if (c < 4) {
+            const float* pp = slot + 20 + 7 * c;
+            pA = f3{pp[0], pp[1], pp[2]}; pB = f3{pp[3], pp[4], pp[5]}; s0 = pp[6];
+          }
+        }
+        const float offset = M.contact_offset;
+        // ---- refresh: the cached points move with their shapes; sideways drift or an open gap drops a point
+        {
+          const f3 nw = mmulv(A.rot, nloc);
+          const f3 wA = A.c + mmulv(A.rot, pA), wB = B.c + mmulv(B.rot, pB);
+          const f3 d = wA - wB;
+          const float dn = dot(d, nw);
+          const f3 tt = d - nw * dn;
+          const bool ok = c < npts && !(dot(tt, tt) > MSSIM_PCM_DRIFT * MSSIM_PCM_DRIFT || s0 + dn > offset);
+          const unsigned mk = b16(ok) & 15u;
+          // compaction: lane k takes the k-th surviving point
+          int src = 0;
+          {
+            unsigned r = mk;
+            for (int q = 0; q < 4; q++) {
+              const int bit = r ? (__ffs(r) - 1) : 0;
+              if (q == c) src = bit;
+              r &= r - 1u;
+            }
+          }
+          pA = f3{gbc(pA.x, src), gbc(pA.y, src), gbc(pA.z, src)};
+          pB = f3{gbc(pB.x, src), gbc(pB.y, src), gbc(pB.z, src)};
+          s0 = gbc(s0, src);
+          npts = __popc(mk);
+        }
+        bool moved = false;
+        if (cached && !fresh) {
+          const f3 dp = mtmulv(A.rot, B.c - A.c) - relp0;
+          float tr = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) tr += relR0[3 * i + j] * dot(mcol(A.rot, i), mcol(B.rot, j));
+          moved = dot(dp, dp) > MSSIM_PCM_MOVE * MSSIM_PCM_MOVE || tr < MSSIM_PCM_ROT_TRACE;
+        }
+        const float relR0_8 = relR0[8];
+        // a point found by a query with shape A posed as (Rq, cq) joins the manifold
+        auto merge = [&](const m3& Rq, f3 cq, f3 gx, float gsep) __attribute__((always_inline)) {
+          const f3 nA = mtmulv(Rq, gx - cq), nB = mtmulv(B.rot, gx - B.c);
+          const f3 dd = nA - pA;
+          const unsigned dup = b16(c < npts && dot(dd, dd) < MSSIM_PCM_MERGE * MSSIM_PCM_MERGE) & 15u;
+          int at = dup ? (__ffs(dup) - 1) : (npts < 4 ? npts : 4);
+          if (!dup && npts < 4) npts++;
+          if (c == at) { pA = nA; pB = nB; s0 = gsep; }  // (at == 4: lane 4 holds the fifth candidate)
+          if (at < 4) return;
+          // 5 candidates -> 4 by the patch selection rule, on lanes 0..4
+          const f3 nw = mmulv(A.rot, nloc);
+          const f3 wA = A.c + mmulv(A.rot, pA), wB = B.c + mmulv(B.rot, pB);
+          const f3 x = (wA + wB) * 0.5f;
+          const float sp = s0 + dot(wA - wB, nw);
+          const bool in5 = c < 5;
+          float best = in5 ? sp : 3e38f;
+          best = -gmax16(-best);
+          const int i0 = __ffs(b16(in5 && sp <= best + MSSIM_PATCH_TIE_SEP)) - 1;
+          const f3 p0 = f3{gbc(x.x, i0), gbc(x.y, i0), gbc(x.z, i0)};
+          auto first_near_max = [&](float v, bool allowed, float floor_) __attribute__((always_inline)) {
+            const float mx = gmax16(allowed ? v : floor_);
+            if (!(mx > floor_)) return -1;
+            return __ffs(b16(allowed && v >= mx - MSSIM_PATCH_TIE_REL * mx)) - 1;
+          };
+          const f3 d0 = x - p0;
+          const int i1 = first_near_max(dot(d0, d0), in5 && c != i0, -1.f);
+          const f3 ed = f3{gbc(x.x, i1), gbc(x.y, i1), gbc(x.z, i1)} - p0;
+          const float ar = dot(cross(ed, x - p0), nw);
+          const int i2 = first_near_max(fabsf(ar), in5 && c != i0 && c != i1, -1.f);
+          const float sgn2 = gbc(ar, i2);
+          const int i3 = first_near_max(sgn2 >= 0.f ? -ar : ar, in5 && c != i0 && c != i1 && c != i2, 0.f);
+          const unsigned keep = (1u << i0) | (1u << i1) | (1u << i2) | (i3 >= 0 ? 1u << i3 : 0u);
+          int src = 0;
+          {
+            unsigned r = keep;
+            for (int q = 0; q < 4; q++) {
+              const int bit = r ? (__ffs(r) - 1) : 0;
+              if (q == c) src = bit;
+              r &= r - 1u;
+            }
+          }
+          pA = f3{gbc(pA.x, src), gbc(pA.y, src), gbc(pA.z, src)};
+          pB = f3{gbc(pB.x, src), gbc(pB.y, src), gbc(pB.z, src)};
+          s0 = gbc(s0, src);
+          npts = __popc(keep);
+        };
+        // ---- the query of this substep, if any: the full one (new pair, moved pair, or a manifold that lost all its
+        // points), or a growth query for a young manifold short of a face contact whose pair is not moving
+        const bool main_q = has && (!cached || fresh || moved || (npts == 0 && !queried_empty));
+        const bool growing = cached && !main_q && npts > 0 && npts < 3 && grow > 0;
+        if (growing) grow--;
+        int mu_count = 0;  // the uncached pair's one-point result
+        f3 mu_n = f3{0, 0, 0}, mu_x = f3{0, 0, 0};
+        float mu_sep = 0.f;
+        {
+          shape_t Aq = A;
+          if (growing) {
+            // shape A tilted about the manifold: about a tangent through its single point, about the edge of its
+            // first two points otherwise; the side alternates
+            const f3 nw = mmulv(A.rot, nloc);
+            const f3 wA = A.c + mmulv(A.rot, pA), wB = B.c + mmulv(B.rot, pB);
+            const f3 xm = (wA + wB) * 0.5f;
+            const f3 pivot = f3{gbc(xm.x, 0), gbc(xm.y, 0), gbc(xm.z, 0)};
+            f3 axis;
+            if (npts >= 2) axis = normalized(f3{gbc(xm.x, 1), gbc(xm.y, 1), gbc(xm.z, 1)} - pivot);
+            else axis = fabsf(nw.x) < 0.57735f ? normalized(cross(nw, f3{1, 0, 0})) : normalized(cross(nw, f3{0, 1, 0}));
+            if (grow & 1) axis = -axis;
+            const m3 Rt = qmat(qaxis_angle(axis, MSSIM_PCM_TILT));
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              const f3 col = mmulv(Rt, mcol(A.rot, j));
+              Aq.rot.m[0][j] = col.x; Aq.rot.m[1][j] = col.y; Aq.rot.m[2][j] = col.z;
+            }
+            Aq.c = pivot + mmulv(Rt, A.c - pivot);
+          }
+          manifold_t gq;
+          manifold_clear(gq);
+          if (main_q || growing) collide_mpr_t(Aq, B, offset, gq, sup);
+          if (main_q) {
+            if (!cached) {
+              mu_count = gq.count; mu_n = gq.n; mu_x = gq.x[0]; mu_sep = gq.sep[0];
+            } else {
+              queried_empty = gq.count == 0;
+              if (gq.count == 0) {
+                npts = 0;
+              } else {
+                const f3 nnew = mtmulv(A.rot, gq.n);
+                if (npts > 0 && dot(nnew, nloc) < MSSIM_PATCH_COS) npts = 0;  // the contact turned: start over
+                if (npts == 0) grow = MSSIM_PCM_GROW;  // a manifold starts: growth queries are owed to it
+                nloc = nnew;
+                merge(A.rot, A.c, gq.x[0], gq.sep[0]);
+              }
+            }
+          } else if (growing && gq.count > 0) {
+            merge(Aq.rot, Aq.c, gq.x[0], gq.sep[0]);
+          }
+        }
+        // ---- the manifold as it stands -> staging tables of its env; the slot goes back to the cache
+        if (has) {
+          const f3 nw = cached ? mmulv(A.rot, nloc) : mu_n;
+          const f3 wA = A.c + mmulv(A.rot, pA), wB = B.c + mmulv(B.rot, pB);
+          const int cnt = cached ? npts : mu_count;
+          const float4 P = cached ? float4{0.5f * (wA.x + wB.x), 0.5f * (wA.y + wB.y), 0.5f * (wA.z + wB.z), s0 + dot(wA - wB, nw)}
+                                  : float4{mu_x.x, mu_x.y, mu_x.z, mu_sep};
+          if (cnt > 0) {
+            int off = 0;
+            if (c == 0) off = pool_alloc(Lg, cnt);
+            off = gbci(off, 0);
+            if (off >= 0) {
+              if (c == 0) {
+                reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = cnt;
+                reinterpret_cast<int*>(Lg)[S16_NP_OFF + idx] = off;
+                float* hn = Lg + S16_NP_HN + 3 * idx;
+                hn[0] = nw.x; hn[1] = nw.y; hn[2] = nw.z;
+              }
+              if (c < cnt) *reinterpret_cast<float4*>(Lg + S16_NP_POOL + 4 * (off + c)) = P;
+            }
+          }
+          if (cached) {
+            if (c == 0) {
+              int4 h4 = *reinterpret_cast<const int4*>(slot);
+              h4.y = npts; h4.w = (grow << 8) | (queried_empty ? 1 : 0);
+              *reinterpret_cast<int4*>(slot) = h4;
+              float r8 = relR0_8;
+              if (main_q) {  // (the pose the last full query saw)
+                const f3 relp = mtmulv(A.rot, B.c - A.c);
+                float relR[9];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                  for (int j = 0; j < 3; j++) relR[3 * i + j] = dot(mcol(A.rot, i), mcol(B.rot, j));
+                *reinterpret_cast<float4*>(slot + 4) = float4{relp.x, relp.y, relp.z, 0.f};
+                *reinterpret_cast<float4*>(slot + 8) = float4{relR[0], relR[1], relR[2], relR[3]};
+                *reinterpret_cast<float4*>(slot + 12) = float4{relR[4], relR[5], relR[6], relR[7]};
+                r8 = relR[8];
+              }
+              *reinterpret_cast<float4*>(slot + 16) = float4{r8, nloc.x, nloc.y, nloc.z};
+            }
+            if (c < npts) {
+              float* pp = slot + 20 + 7 * c;
+              pp[0] = pA.x; pp[1] = pA.y; pp[2] = pA.z; pp[3] = pB.x; pp[4] = pB.y; pp[5] = pB.z; pp[6] = s0;
+            }
           }
         }
       }
@@ -1101,6 +1331,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
       __syncthreads();
     }
+    if (FUSED && last) {
+      nold = S.hit_list[e];
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (c + 16 * k < nold) oldp[k] = S.hit_list[(size_t)(1 + c + 16 * k) * N + e];
+    }
     PH(21);
 
     // ================================================================ per-env constants of this lane
@@ -1141,6 +1377,18 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     }
 
     // ================================================================ dynamics: RNEA bias + CRBA
+    // body pose from the pose table; world joint axis / anchor from the parent's pose (the arithmetic of the FK below)
+    const pose_t root = lds_pose(L + S16_PT);
+    pose_t bp_c = root;
+    f3 aw_c = f3{0, 0, 0}, an_c = f3{0, 0, 0};
+    if (art) {
+      bp_c = lds_pose(L + S16_BP + 7 * c);
+      pose_t Wp0 = root;
+      if (par_c >= 0) Wp0 = lds_pose(L + S16_BP + 7 * par_c);
+      const pose_t Jw0 = pmul(Wp0, JF_c);
+      aw_c = qrot(Jw0.q, al_c);
+      an_c = Jw0.p;
+    }
     sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
     if (art) S_c = rev_c ? sv6{aw_c, cross(an_c - O, aw_c)} : sv6{f3{0, 0, 0}, aw_c};
     {
@@ -1746,6 +1994,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // (4 rounds cover depth 16); sincos and the products run in all lanes at once instead of a
     // 9-long sequential chain. Same transforms as the sequential product, different association.
     __syncthreads();
+    const pose_t rootf = lds_pose(L + S16_PT);
+    pose_t nb = rootf;
+    f3 naw = f3{0, 0, 0}, nan = f3{0, 0, 0};
     {
       pose_t T = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
       int up = -1;
@@ -1768,10 +2019,10 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
         __syncthreads();
       }
-      nb = pmul(root, T);
+      nb = pmul(rootf, T);
       if (art) lds_pose_store(mine, nb);
       __syncthreads();
-      pose_t Wp = root;
+      pose_t Wp = rootf;
       if (par_c >= 0) Wp = lds_pose(L + S16_BP + 7 * par_c);
       const pose_t Jw = pmul(Wp, JF_c);
       naw = qrot(Jw.q, al_c);
@@ -1801,7 +2052,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
       fcalm[b] = calm;
     }
-    bp_c = nb; aw_c = naw; an_c = nan;
+
     PH(15);
       // ================================================================ write back (last substep)
     if (last) {
@@ -1815,6 +2066,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
       }
       if (c < nf && live) SOA(S.free_wake, c) = c == 0 ? fwake[0] : fwake[1];
+      if (c == 0 && live) S.pcm_tick[e] = pcm_tick;
       // body velocities about O with the new subspaces
       sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
       if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};

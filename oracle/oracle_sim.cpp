@@ -425,16 +425,9 @@ void pcm_collide(EnvState& E, int p, const Shape<Real>& A, const Shape<Real>& B,
     } else {
       const Vec n_new = A.rot.tmul(g.n);
       if (sl->npts > 0 && dot(n_new, sl->n_loc) < Real(MSSIM_PATCH_COS)) sl->npts = 0;  // the contact turned: start over
-      const bool started = sl->npts == 0;
+      if (sl->npts == 0) sl->grow = MSSIM_PCM_GROW;  // a manifold starts: growth queries are owed to it
       sl->n_loc = n_new;
       merge(A, g);
-      if (started) {
-        // a new manifold is completed at once: three growth queries (tangent, then both sides of the first edge)
-        sl->grow = MSSIM_PCM_GROW;
-        growth_query(false);
-        growth_query(false);
-        growth_query(true);
-      }
     }
   } else if (growing) {
     sl->grow--;
@@ -450,6 +443,55 @@ void pcm_collide(EnvState& E, int p, const Shape<Real>& A, const Shape<Real>& B,
     m.x[j] = (wA + wB) * Real(0.5);
     m.sep[j] = sl->sep0[j] + dot(wA - wB, nw);
   }
+}
+
+// oriented box around shape s (axes = the shape frame, centred at its bounding-sphere centre): half extents
+inline Vec shape_obb_half(const Model& M, int s, int e) {
+  const int slot = M.shape_env_slot.empty() ? -1 : M.shape_env_slot[s];
+  float pr[4];
+  for (int k = 0; k < 4; k++) pr[k] = slot < 0 ? M.shape_param[4 * s + k] : M.env_shape_param[(size_t)(4 * slot + k) * M.N + e];
+  Vec h;
+  switch (M.shape_type[s]) {
+    case MSSIM_SHAPE_BOX: h = Vec(pr[0], pr[1], pr[2]); break;
+    case MSSIM_SHAPE_SPHERE: h = Vec(pr[0], pr[0], pr[0]); break;
+    case MSSIM_SHAPE_CAPSULE: h = Vec(pr[1] + pr[0], pr[0], pr[0]); break;
+    case MSSIM_SHAPE_CYLINDER: h = Vec(pr[1], pr[0], pr[0]); break;
+    case MSSIM_SHAPE_CONVEX: {
+      const float* b = &M.shape_bound[4 * s];
+      for (int i = 0; i < M.shape_hull[2 * s + 1]; i++) {
+        const float* v = &M.hull_verts[3 * (size_t)(M.shape_hull[2 * s] + i)];
+        h.x = std::max(h.x, (Real)std::fabs(v[0] - b[0])); h.y = std::max(h.y, (Real)std::fabs(v[1] - b[1])); h.z = std::max(h.z, (Real)std::fabs(v[2] - b[2]));
+      }
+      break;
+    }
+    default: h = Vec(3e30, 3e30, 3e30);
+  }
+  if (slot < 0 && M.shape_type[s] != MSSIM_SHAPE_CONVEX && M.shape_type[s] != MSSIM_SHAPE_PLANE) {
+    // primitives are centred on their frame; the box stays valid if the bound centre is offset
+    h.x += std::fabs(M.shape_bound[4 * s]); h.y += std::fabs(M.shape_bound[4 * s + 1]); h.z += std::fabs(M.shape_bound[4 * s + 2]);
+  }
+  return h;
+}
+
+// separating-axis test of two oriented boxes, radii enlarged by `margin`; true = certainly apart (Gottschalk et al.)
+inline bool obb_separated(const Mat& RA, const Vec& ha, const Mat& RB, const Vec& hb, const Vec& d, Real margin) {
+  Real R[3][3], AR[3][3];
+  const Real t[3] = {dot(RA.col(0), d), dot(RA.col(1), d), dot(RA.col(2), d)};
+  const Real a[3] = {ha.x, ha.y, ha.z}, b[3] = {hb.x, hb.y, hb.z};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { R[i][j] = dot(RA.col(i), RB.col(j)); AR[i][j] = std::fabs(R[i][j]) + Real(1e-6); }
+  for (int i = 0; i < 3; i++)
+    if (std::fabs(t[i]) > a[i] + b[0] * AR[i][0] + b[1] * AR[i][1] + b[2] * AR[i][2] + margin) return true;
+  for (int j = 0; j < 3; j++)
+    if (std::fabs(t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j]) > b[j] + a[0] * AR[0][j] + a[1] * AR[1][j] + a[2] * AR[2][j] + margin) return true;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const Real ra = a[i1] * AR[i2][j] + a[i2] * AR[i1][j];
+      const Real rb = b[j1] * AR[i][j2] + b[j2] * AR[i][j1];
+      if (std::fabs(t[i2] * R[i1][j] - t[i1] * R[i2][j]) > ra + rb + margin) return true;
+    }
+  return false;
 }
 
 void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) {
@@ -479,6 +521,9 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
       Vec d = cb - ca;
       Real rr = ra + rb + M.contact_offset;
       if (dot(d, d) > rr * rr) continue;
+      // second stage, as the kernels: oriented boxes of the two shapes (conservative; it decides which pairs reach
+      // the persistent manifold cache, so both implementations must apply it alike)
+      if (obb_separated(A.rot, shape_obb_half(M, sa, e), B.rot, shape_obb_half(M, sb, e), d, M.contact_offset)) continue;
     }
     Manifold<Real> m;
     if (A.type == SH_PLANE || (A.type == SH_BOX && B.type == SH_BOX)) collide(A, B, M.contact_offset, m);

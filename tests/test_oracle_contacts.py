@@ -425,9 +425,9 @@ def _slab_on_table(as_hull=True):
 
 def test_persistent_manifold_lets_a_hull_rest_without_rocking():
     """enable_pcm (mani_skill/utils/structs/types.py:44): a convex hull lying on the table gets ONE point per full
-    query; the persistent manifold is completed by three growth queries in the substep in which it starts (4 queries, 4
-    points), after which the slab rests flat like its box twin -- no rocking, no full queries while nothing moves --
-    and goes to sleep"""
+    query; while the pair is not moving the persistent manifold is grown by one tilted query per substep (3-4 points after
+    as many substeps), after which the slab rests flat like its box twin -- no rocking, no queries while nothing
+    moves -- and goes to sleep"""
     model = _slab_on_table(True)
     px = ob.make_system(model, 1)
     row = model.row_of("slab")
@@ -439,9 +439,9 @@ def test_persistent_manifold_lets_a_hull_rest_without_rocking():
         queries.append(int(px.read_internal("mpr_queries", 1)[0, 0]))
         q = px.cuda_rigid_body_data.torch()[row, 3:7]
         tilt.append(float(2 * torch.acos(torch.clamp(q[0].abs(), max=1.0))))
-    assert counts[0] == 4 and min(counts) == 4, counts
-    assert queries[0] == 4 and sum(queries[1:]) == 0, queries  # a resting manifold is refreshed, not regenerated
-    assert max(tilt) < np.deg2rad(0.05), np.rad2deg(max(tilt))
+    assert counts[0] == 1 and counts[5] >= 3 and min(counts[5:]) >= 3, counts
+    assert sum(queries[:6]) >= 3 and sum(queries[12:]) == 0, queries  # a resting manifold is refreshed, not regenerated
+    assert max(tilt) < np.deg2rad(2.0) and max(tilt[20:]) < np.deg2rad(0.3), np.rad2deg(tilt)
     s = px.cuda_rigid_body_data.torch()[row]
     assert abs(s[2].item() - 0.02) < 5e-4 and torch.max(torch.abs(s[7:13])) < 5e-3
     px.step(60)
