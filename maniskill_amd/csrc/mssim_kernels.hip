@@ -54,6 +54,7 @@ struct DevState {
   float* free_wake;                             // [n_free][N] seconds of low energy left before the body sleeps; <= 0: asleep
   float* pcm;                                   // [N][MSSIM_PCM_SLOTS][48] persistent contact manifolds (mssim_solve16.h S16_PCM_LEN)
   int* pcm_tick;                                // [N] substep counter of the cache
+  float* warm;                                  // [4 n_pair][N][4] contact multipliers (n, t1, t2) + substep stamp per (pair, manifold slot)
   float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
   float* bodyaux;                               // [n_dof*6][N] world joint axis (3) + joint anchor (3)
   int* pair_cnt;                                // [n_pair][N] contact points of the pair in the last substep (after the patch reduction)
@@ -1028,6 +1029,11 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   AL(pcm_tick, 1)
   if ((rc = dalloc(S, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN, &D.pcm))) { mssim_destroy(S); return rc; }
   HIPCHK(S, hipMemset(D.pcm, 0xFF, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float)));  // pair = -1: every slot empty
+  {
+    const size_t nw = (size_t)4 * (d->n_pair > 0 ? d->n_pair : 1) * N * 4;
+    if ((rc = dalloc(S, nw, &D.warm))) { mssim_destroy(S); return rc; }
+    HIPCHK(S, hipMemset(D.warm, 0xFF, nw * sizeof(float)));  // stamp -1: nothing to start from
+  }
 #undef AL
   // identity quaternions
   std::vector<float> ones(N, 1.0f);
@@ -1114,6 +1120,7 @@ int mssim_wake_all(mssim_handle h, void* stream) {
   const size_t cnt = (size_t)h->M.n_free * h->N;
   if (cnt > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->S.free_wake, MSSIM_WAKE_TIME, cnt);
   HIPCHK(h, hipMemsetAsync(h->S.pcm, 0xFF, (size_t)h->N * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float), (hipStream_t)stream));  // every slot empty
+  HIPCHK(h, hipMemsetAsync(h->S.warm, 0xFF, (size_t)16 * (h->M.n_pair > 0 ? h->M.n_pair : 1) * h->N * sizeof(float), (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
               r[0] = nn.x; r[1] = nn.y; r[2] = nn.z;
               r[3] = P.x; r[4] = P.y; r[5] = P.z;
               r[6] = P.w - M.rest_offset;
-              r[7] = __int_as_float((pk & 0xFFFF) | (a << 16));  // pair | patch
+              r[7] = __int_as_float((pk & 0xFFFF) | (a << 16) | (q << 24));  // pair | patch | manifold slot (warm-start key)
               r[8] = __int_as_float(bodies);
               r[9] = mu;
             }
@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // J3 / W3: this lane's Jacobian and A^-1 J^T entries of the three rows; block scalars go to the LDS
     // table. Padding slots (this env has fewer contacts than the wave's longest) become all-zero blocks:
     // the solver sweeps the maximum over the wave's envs and their updates then move nothing.
-    auto build_contact = [&](int i, bool ck, float (&J3)[3], float (&W3)[3]) __attribute__((always_inline)) {
+    auto build_contact = [&](int i, bool ck, float (&J3)[3], float (&W3)[3], float (&lam3)[3]) __attribute__((always_inline)) {
       const float* rec = L + S16_REC + S16_REC_LEN * (ck ? i : 0);
       const f3 nrm = f3{rec[0], rec[1], rec[2]};
       const f3 x = f3{rec[3], rec[4], rec[5]};
@@ -1690,6 +1690,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (tors) J3[0] = jrot_c ? sgn * dot(jaxis_c, nrm) : 0.f;
       // W = A^-1 J^T for the three directions: 16 DPP row rotations of J against the pre-rotated row
       rot_fma3(Irot, J3, W3);
+      // warm start: the block's initial impulses act on the velocities before the first sweep
+      lam3[0] = L[S16_CS + 16 * i + 9]; lam3[1] = L[S16_CS + 16 * i + 10]; lam3[2] = L[S16_CS + 16 * i + 11];
+      v_c = fmaf(W3[2], lam3[2], fmaf(W3[1], lam3[1], fmaf(W3[0], lam3[0], v_c)));
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
       float d0 = J3[0] * W3[0], d1 = J3[1] * W3[1], d2 = J3[2] * W3[2];
       float g10 = J3[1] * W3[0], g20 = J3[2] * W3[0], g21 = J3[2] * W3[1];
@@ -1701,11 +1704,29 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         const bool pt = ck && !tors;
         cs[0] = float4{i0, pt ? (sep >= 0.f ? sep * inv_dt : fmaxf(M.erp * sep * inv_dt, -M.max_depen)) : 0.f, pt ? (sep >= 0.f ? sep * inv_dt : 0.f) : 0.f, pt ? mu : 0.f};
         cs[1] = float4{i1, g10 * i1, i2, g20 * i2};
-        cs[2] = float4{g21 * i2, 0.f, 0.f, 0.f};
+        L[S16_CS + 16 * i + 8] = g21 * i2;  // (words 9..11: the warm-start multipliers, already in place)
         // torsional bound mu r (0 = contact block) | carry factor of the manifold's normal-multiplier sum (0 = first block)
         cs[3] = float4{__int_as_float(pw), 0.f, tors ? rec[9] : 0.f, (ck && !first) ? 1.f : 0.f};
       }
     };
+    // Warm start (include/mssim.h): the multipliers a (shape pair, manifold slot) carried in the previous substep, one
+    // 16-byte load per contact, all contacts of the env in flight at once; they land in the multiplier words of the block
+    // table (zeros for new contacts, torsional blocks and padding blocks) and are applied as the blocks are built.
+    for (int i = c; i < max_nc; i += 16) {
+      float4 w = float4{0.f, 0.f, 0.f, 0.f};
+      bool ok = false;
+      if (i < nc && live) {
+        const int pw = __float_as_int(L[S16_REC + S16_REC_LEN * i + 7]);
+        if (!((pw >> 30) & 1)) {
+          w = *reinterpret_cast<const float4*>(S.warm + (((size_t)(4 * (pw & 0xFFFF) + ((pw >> 24) & 3))) * N + e) * 4);
+          ok = __float_as_int(w.w) == pcm_tick - 1;
+        }
+      }
+      L[S16_CS + 16 * i + 9] = ok ? w.x : 0.f;
+      L[S16_CS + 16 * i + 10] = ok ? w.y : 0.f;
+      L[S16_CS + 16 * i + 11] = ok ? w.z : 0.f;
+    }
+    __syncthreads();
     float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
     float Jr[S16_REGC][3], Wr[S16_REGC][3], lamr[S16_REGC][3];
 #pragma unroll
@@ -1713,15 +1734,15 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #pragma unroll
       for (int dk = 0; dk < 3; dk++) { Jr[k][dk] = 0.f; Wr[k][dk] = 0.f; lamr[k][dk] = 0.f; }
       if (k < max_nc) {  // wave-uniform
-        float J3[3], W3[3];
-        build_contact(k, k < nc, J3, W3);
+        float J3[3], W3[3], l3[3];
+        build_contact(k, k < nc, J3, W3, l3);
 #pragma unroll
-        for (int dk = 0; dk < 3; dk++) { Jr[k][dk] = J3[dk]; Wr[k][dk] = W3[dk]; }
+        for (int dk = 0; dk < 3; dk++) { Jr[k][dk] = J3[dk]; Wr[k][dk] = W3[dk]; lamr[k][dk] = l3[dk]; }
       }
     }
     for (int i = S16_REGC; i < max_nc; i++) {
-      float J3[3], W3[3];
-      build_contact(i, i < nc, J3, W3);
+      float J3[3], W3[3], l3[3];
+      build_contact(i, i < nc, J3, W3, l3);
       // (LDS and global rows are written by separate code: one pointer for both would be a flat pointer)
       if (i < S16_REGC + S16_LDSC) {
         float* row = L + S16_JW + S16_JWLEN * (i - S16_REGC);
@@ -1936,6 +1957,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (k < nc_reg) { L[S16_CS + 16 * k + 9] = lamr[k][0]; L[S16_CS + 16 * k + 10] = lamr[k][1]; L[S16_CS + 16 * k + 11] = lamr[k][2]; }
     }
     __syncthreads();
+    // the multipliers of this substep, keyed by (shape pair, manifold slot) and stamped: the next substep's warm start
+    for (int i = c; i < nc; i += 16) {
+      const int pw = __float_as_int(L[S16_REC + S16_REC_LEN * i + 7]);
+      if (((pw >> 30) & 1) || !live) continue;
+      *reinterpret_cast<float4*>(S.warm + (((size_t)(4 * (pw & 0xFFFF) + ((pw >> 24) & 3))) * N + e) * 4) =
+          float4{L[S16_CS + 16 * i + 9], L[S16_CS + 16 * i + 10], L[S16_CS + 16 * i + 11], __int_as_float(pcm_tick)};
+    }
     PH(5);
 
     // ================================================================ contact impulses per pair (last substep)

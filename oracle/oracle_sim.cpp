@@ -24,6 +24,7 @@
 //   6. semi-implicit Euler; FK at the new state for the link pose / velocity outputs
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +68,8 @@ struct Model {
   std::vector<int32_t> shape_env_slot, free_env_slot;
   std::vector<float> env_shape_frame, env_shape_param, env_shape_bound, env_free_inertial;
   Real gravity[3], dt, contact_offset, rest_offset, erp, max_depen, sleep_threshold;
+  bool cold = false;  // oracle-only (env var MSSIM_REF_COLD=1): no warm start of the contact multipliers, scripts/tgs_vs_pgs.py
+  bool tgs = false;  // oracle-only experiment (env var MSSIM_REF_TGS=1): position sub-stepping instead of PGS, DESIGN.md section 2
   int pos_iters, vel_iters;
 };
 
@@ -75,6 +78,7 @@ struct Contact {
   Vec x, n;
   Real sep, mu;
   Real lam[3];
+  int slot;  // index of the point in its shape pair's manifold (before the patch reduction): the warm-start key
   // > 0 on the LAST contact of a manifold whose shapes carry a torsional patch radius: a torsional friction row about
   // the normal follows it, bounded by tors_mu * (sum of the normal multipliers of the manifold's contacts, which start
   // at contact `tors_first`)
@@ -107,6 +111,10 @@ struct EnvState {
   std::vector<Pose<Real>> body_pose;  // moving bodies
   std::vector<SpatialV> body_vel;     // about O = root position
   std::vector<Vec> pair_impulse;
+  // warm start (include/mssim.h): multipliers (normal, t1, t2) of manifold point `slot` of shape pair p at [4 p + slot],
+  // valid in the substep after the one that wrote them (stamp = its pcm_tick)
+  struct Warm { Real lam[3]; int stamp; };
+  std::vector<Warm> warm;
   std::vector<int> pair_count;
   std::vector<PcmSlot> pcm = std::vector<PcmSlot>(MSSIM_PCM_SLOTS);
   int pcm_tick = 0;
@@ -540,6 +548,7 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
       c.kb = M.shape_kind[sb]; c.ib = M.shape_index[sb];
       c.x = m.x[k]; c.n = m.n; c.sep = m.sep[k] - M.rest_offset; c.mu = mu;
       c.lam[0] = c.lam[1] = c.lam[2] = 0;
+      c.slot = k;
       c.tors_mu = 0; c.tors_first = -1; c.tors_n = Vec();
       raw.push_back(c);
     }
@@ -930,6 +939,23 @@ void substep(mssim_sim* S, EnvState& E, int e) {
 
   // 5. PGS
   std::vector<Real> v(qds);
+  // Warm start: a contact whose (shape pair, manifold slot) carried multipliers in the PREVIOUS substep starts from
+  // them -- the rows' initial impulses are applied to the velocities before the first sweep. Torsional rows and limit
+  // rows start from zero.
+  if ((int)E.warm.size() != 4 * M.n_pair) E.warm.assign((size_t)4 * M.n_pair, EnvState::Warm{{0, 0, 0}, -1});
+  if (!M.cold)
+    for (size_t ci = 0; ci < contacts.size(); ci++) {
+      const EnvState::Warm& w = E.warm[4 * contacts[ci].pair + contacts[ci].slot];
+      if (w.stamp != E.pcm_tick - 1) continue;
+      for (int d = 0; d < 3; d++) {
+        Row& r = rows[contact_row[ci] + d];
+        const Real dl = w.lam[d];
+        r.lam = dl;
+        for (int i = 0; i < n; i++) v[i] += r.Wa[i] * dl;
+        for (int s2 = 0; s2 < 2; s2++)
+          if (r.f[s2] >= 0) { fv[r.f[s2]] += r.Wl[s2] * dl; fw[r.f[s2]] += r.Ww[s2] * dl; }
+      }
+    }
   // one Gauss-Seidel sweep: the contact rows in pair order, then the joint-limit rows (an articulation's internal
   // constraints are solved after its contacts, as in PhysX: a jammed arm gives way at the contact, not at the limit)
   auto sweep = [&](bool use_bias) {
@@ -960,11 +986,52 @@ void substep(mssim_sim* S, EnvState& E, int e) {
       }
     }
   };
-  for (int it = 0; it < M.pos_iters; it++) sweep(true);
-  std::vector<Real> v_pos(v);
-  std::vector<Vec> fv_pos(fv), fw_pos(fw);
+  std::vector<Real> v_pos;
+  std::vector<Vec> fv_pos, fw_pos;
+  if (!M.tgs) {
+    for (int it = 0; it < M.pos_iters; it++) sweep(true);
+    v_pos = v; fv_pos = fv; fw_pos = fw;
+  } else {
+    // TGS-style position sub-stepping (the experiment behind DESIGN.md's PGS-vs-TGS comparison; never used by the
+    // parity tests): the substep is cut into pos_iters slices of h = dt / pos_iters. Every slice makes ONE Gauss-Seidel
+    // sweep whose position bias is the row's CURRENT gap (the initial gap plus the relative displacement of the earlier
+    // slices) over h, then advances the rows' gaps by h (J v). Positions integrate with the mean of the slice velocities.
+    const int n_it = M.pos_iters > 0 ? M.pos_iters : 1;
+    const Real h = dt / n_it;
+    std::vector<Real> gap(rows.size());
+    for (size_t k = 0; k < rows.size(); k++) {
+      const Row& r = rows[k];
+      // recover the signed gap from the PGS biases: bias_pos = gap / dt (gap >= 0) or erp * gap / dt (capped) otherwise
+      gap[k] = r.bias_vel > 0 || r.bias_pos >= 0 ? r.bias_pos * dt : r.bias_pos * dt / M.erp;
+    }
+    v_pos.assign(n, 0); fv_pos.assign(nf, Vec()); fw_pos.assign(nf, Vec());
+    for (int it = 0; it < n_it; it++) {
+      for (size_t k = 0; k < rows.size(); k++) {
+        Row& r = rows[k];
+        if (r.friction_of >= 0 || !r.tors_of.empty()) continue;
+        r.bias_pos = gap[k] >= 0 ? gap[k] / h : std::max(M.erp * gap[k] / h, -M.max_depen);
+      }
+      sweep(true);
+      for (size_t k = 0; k < rows.size(); k++) {
+        const Row& r = rows[k];
+        if (r.friction_of >= 0 || !r.tors_of.empty() || !(r.diag > Real(1e-12))) continue;
+        Real jv = 0;
+        for (int i = 0; i < n; i++) jv += r.Ja[i] * v[i];
+        for (int s2 = 0; s2 < 2; s2++)
+          if (r.f[s2] >= 0) jv += dot(r.Jl[s2], fv[r.f[s2]]) + dot(r.Jw[s2], fw[r.f[s2]]);
+        gap[k] += h * jv;
+      }
+      for (int i = 0; i < n; i++) v_pos[i] += v[i] / n_it;
+      for (int b = 0; b < nf; b++) { fv_pos[b] += fv[b] * (Real(1) / n_it); fw_pos[b] += fw[b] * (Real(1) / n_it); }
+    }
+  }
   for (int it = 0; it < M.vel_iters; it++) sweep(false);
 
+  for (size_t ci = 0; ci < contacts.size(); ci++) {
+    EnvState::Warm& w = E.warm[4 * contacts[ci].pair + contacts[ci].slot];
+    for (int d = 0; d < 3; d++) w.lam[d] = rows[contact_row[ci] + d].lam;
+    w.stamp = E.pcm_tick;
+  }
   // contact impulses per pair (world frame, on shape A's body)
   E.pair_impulse.assign(M.n_pair, Vec());
   for (const Row& r : rows) {
@@ -1061,6 +1128,8 @@ int mssim_ref_create(const mssim_model_desc* d, int32_t num_envs, int32_t device
   M.dt = d->timestep; M.contact_offset = d->contact_offset; M.rest_offset = d->rest_offset; M.erp = d->erp;
   M.max_depen = d->max_depenetration_velocity; M.pos_iters = d->position_iterations; M.vel_iters = d->velocity_iterations;
   M.sleep_threshold = d->sleep_threshold;
+  { const char* t = getenv("MSSIM_REF_TGS"); M.tgs = t && t[0] == '1'; }
+  { const char* t = getenv("MSSIM_REF_COLD"); M.cold = t && t[0] == '1'; }
   for (int j = 0; j < n; j++)
     if (M.dof_parent[j] >= j) { g_create_error = "dof_parent must be topologically sorted"; delete S; return 4; }
   S->N = num_envs;
@@ -1195,6 +1264,7 @@ int mssim_ref_wake_all(mssim_handle h, void*) {
   for (auto& E : h->env) {
     std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
     for (auto& s : E.pcm) s = PcmSlot();
+    E.warm.clear();
   }
   return 0;
 }

@@ -309,7 +309,9 @@ def test_panda_grasp_holds_cube():
     px.step(50)
     px.gpu_fetch_all()
     fingers = px.cuda_articulation_qpos.torch()[0, 7:]
-    assert torch.all(fingers > 0.015) and torch.all(fingers < 0.0215), fingers
+    # (warm-started multipliers: the saturated 100 N squeeze converges, the pads do not sink into the 20 mm half-width cube;
+    # a cold-started sweep leaves them 3.3 mm inside, scripts/tgs_vs_pgs.py)
+    assert torch.all(fingers > 0.0198) and torch.all(fingers < 0.0203), fingers
     steps = 100
     for i in range(steps):
         a = (i + 1) / steps
