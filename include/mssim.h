@@ -63,6 +63,10 @@ extern "C" {
  * comes to rest on a face has its 3-4 points after as many substeps; a pair in relative motion costs one query per
  * substep, as without the cache. A pair that is in range but not in contact keeps an empty slot, so it is not queried
  * again until it moves. */
+/* The portal refinement of a generic-convex query (MPR) stops when the support plane along the portal normal lies within
+ * this distance of the portal (Bullet's btMprPenetration uses the same 1e-4): the reported gap is accurate to 0.1 mm. A
+ * tenth of it buys nothing the solver can see and costs ~40 % more refinement iterations on tessellated round hulls. */
+#define MSSIM_MPR_TOLERANCE 1e-4f
 #define MSSIM_PCM_SLOTS 16
 #define MSSIM_PCM_DRIFT 5e-3f       /* m, sideways drift that breaks a cached point (0.25 x contact offset)          */
 #define MSSIM_PCM_MOVE 1e-3f        /* m, relative translation since the last full query that forces a new one       */

@@ -473,7 +473,7 @@ MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, mani
   MPR_T0;
   MPR_ADD(4, 1);
   const float margin = offset;
-  const float tol = 1e-5f;
+  const float tol = MSSIM_MPR_TOLERANCE;
   mvert v0, v1, v2, v3, v4;
   v0.a = A.c; v0.b = B.c; v0.v = A.c - B.c;
   if (dot(v0.v, v0.v) < 1e-12f) v0.v = f3{1e-5f, 0.f, 0.f};

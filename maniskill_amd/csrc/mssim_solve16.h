@@ -100,6 +100,9 @@ __device__ unsigned g_phase_blk[2048 * 32];  // per-block deltas of the most rec
     ph_t = (unsigned)clock64();                 \
   } while (0)
 #define PH_ADD(i, v) ph_d[i] += (unsigned)(v)
+#define BT_ADD(i, v)
+#define BT_T0
+#define BT_T(i)
 #define PH_FLUSH                                                                  \
   if (threadIdx.x == 0) {                                                         \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++)                             \
@@ -119,6 +122,9 @@ __device__ unsigned g_phase_blk[2048 * 32];
   const unsigned long long bt_w0 = wall_clock64(), bt_c0 = clock64();
 #define PH(i)
 #define PH_ADD(i, v) ph_d[i] += (unsigned)(v)
+#define BT_ADD(i, v) ph_d[i] += (unsigned)(v)  // (slots that are cycle counts in the phase-clock build)
+#define BT_T0 unsigned bt_t_ = (unsigned)clock64()
+#define BT_T(i) do { __builtin_amdgcn_s_waitcnt(0); ph_d[i] += (unsigned)clock64() - bt_t_; bt_t_ = (unsigned)clock64(); } while (0)
 #define PH_FLUSH                                                                   \
   if (threadIdx.x == 0 && blockIdx.x < 2048) {                                     \
     unsigned* o_ = g_phase_blk + blockIdx.x * 32;                                  \
@@ -133,6 +139,9 @@ __device__ unsigned g_phase_blk[2048 * 32];
 #define PH_INIT
 #define PH(i)
 #define PH_ADD(i, v)
+#define BT_ADD(i, v)
+#define BT_T0
+#define BT_T(i)
 #define PH_FLUSH
 #endif
 
@@ -834,6 +843,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // B0: every env's own group assigns cache slots to its pairs, in pair order (same pair -> its slot; else the
       // first empty slot; else the least recently used one not touched in this substep; else none: plain query).
       // Lane k holds the header word of slot k.
+      BT_T0;
       {
         int4 hd = int4{-1, 0, 0, 0};
         if (live) hd = *reinterpret_cast<const int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN);
@@ -873,6 +883,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       __syncthreads();
       // B: a pair is worked on by one 16-lane group (hull scans shared by its lanes); the pairs of all 4 envs form
       // one task list that the 4 groups take round-robin. Lanes 0..3 of the group hold the manifold's points.
+      BT_T(17);
       for (int t0 = 0; t0 < TM; t0 += S16_ENVS_PER_BLOCK) {
         const bool has = t0 + g < TM;
         const int t = has ? t0 + g : t0;  // (idle groups shadow the round's first pair: valid shapes, no output)
@@ -914,6 +925,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             pA = f3{pp[0], pp[1], pp[2]}; pB = f3{pp[3], pp[4], pp[5]}; s0 = pp[6];
           }
         }
+        BT_T(18);
         const float offset = M.contact_offset;
         // ---- refresh: the cached points move with their shapes; sideways drift or an open gap drops a point
         {
@@ -1001,6 +1013,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         const bool main_q = has && (!cached || fresh || moved || (npts == 0 && !queried_empty));
         const bool growing = cached && !main_q && npts > 0 && npts < 3 && grow > 0;
         if (growing) grow--;
+        // (work counters of the debug builds: why this round's tasks query or not)
+        BT_ADD(10, __popcll(__ballot(c == 0 && has && !cached)));
+        BT_ADD(11, __popcll(__ballot(c == 0 && has && fresh)));
+        BT_ADD(12, __popcll(__ballot(c == 0 && has && cached && !fresh && moved)));
+        BT_ADD(13, __popcll(__ballot(c == 0 && has && cached && !fresh && !moved && main_q)));
+        BT_ADD(15, __popcll(__ballot(c == 0 && has && growing)));
+        BT_ADD(16, __popcll(__ballot(c == 0 && has && !main_q && !growing)));
         int mu_count = 0;  // the uncached pair's one-point result
         f3 mu_n = f3{0, 0, 0}, mu_x = f3{0, 0, 0};
         float mu_sep = 0.f;
@@ -1027,7 +1046,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
           manifold_t gq;
           manifold_clear(gq);
+          BT_T(19);
           if (main_q || growing) collide_mpr_t(Aq, B, offset, gq, sup);
+          BT_T(20);
           if (main_q) {
             if (!cached) {
               mu_count = gq.count; mu_n = gq.n; mu_x = gq.x[0]; mu_sep = gq.sep[0];
@@ -1048,6 +1069,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
         }
         // ---- the manifold as it stands -> staging tables of its env; the slot goes back to the cache
+        BT_T(21);
         if (has) {
           const f3 nw = cached ? mmulv(A.rot, nloc) : mu_n;
           const f3 wA = A.c + mmulv(A.rot, pA), wB = B.c + mmulv(B.rot, pB);
@@ -1095,6 +1117,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
         }
       }
+      BT_T(22);
       PH(25);
       // ---- stage C: box-box pairs by 16-lane groups, round-robin over the wave's list
       if (!bb_lane) {

@@ -339,7 +339,7 @@ template <typename R>
 inline void collide_mpr(const Shape<R>& A, const Shape<R>& B, R offset, Manifold<R>& m) {
   m.count = 0;
   const R margin = offset;
-  const R tol = R(1e-5);
+  const R tol = R(MSSIM_MPR_TOLERANCE);
   MVert<R> v0, v1, v2, v3, v4;
   v0.a = A.c; v0.b = B.c; v0.v = A.c - B.c;
   if (dot(v0.v, v0.v) < R(1e-12)) v0.v = V3<R>(R(1e-5), 0, 0);

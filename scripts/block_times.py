@@ -54,5 +54,12 @@ for rep in range(3):
     inv_sl = np.unique(cu * 4 + simd, return_inverse=True)[1]
     for b in order[:12]:
         print(f"    {end[b]:7.1f} {start[b]:7.1f} {dur[b]:7.1f} {a[b, 30]:5d} {a[b, 29]:5d} {a[b, 14]:4d} {a[b, 28]:4d}   {cnt[inv_cu[b]]} / {slot[inv_sl[b]]}")
+    print("  their generic-convex tasks: uncached | new slot | moved | empty manifold asked again | growth query | refresh only")
+    for b in order[:12]:
+        print(f"    {a[b, 10]:5d} {a[b, 11]:5d} {a[b, 12]:5d} {a[b, 13]:5d} {a[b, 15]:5d} {a[b, 16]:5d}")
+    print("  their stage B cycles: slot assignment | slot load | refresh + setup | MPR query | merge | store (last round: + wait)")
+    for b in order[:12]:
+        print("    " + " ".join(f"{a[b, k]:8d}" for k in (17, 18, 19, 20, 21, 22)))
+    print(f"  all blocks: uncached {a[:, 10].sum()} new slot {a[:, 11].sum()} moved {a[:, 12].sum()} empty asked again {a[:, 13].sum()} growth {a[:, 15].sum()} refresh only {a[:, 16].sum()}")
     c = np.corrcoef(dur, a[:, 29])[0, 1]
     print(f"  correlation duration ~ max-env contacts: {c:.2f}; mean duration by MPR rounds: " + ", ".join(f"{k}: {dur[a[:, 14] == k].mean():.0f} us (n={int((a[:, 14] == k).sum())})" for k in np.unique(a[:, 14])[:8]))
