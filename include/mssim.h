@@ -82,6 +82,11 @@ extern "C" {
  * sweeps a cold start does not converge on stiff loads -- the gripper's saturated 100 N squeeze leaves each pad 3.3 mm
  * inside the cube, a stack of two cubes creeps 1 mm/s -- the warm start does (0.02 mm, 6 um/s; scripts/tgs_vs_pgs.py).
  * The cache is hidden state like the sleep counters and the manifolds: mssim_wake_all clears it. */
+/* The position sweeps of a substep end early once a whole sweep moves no velocity component (joint velocities, free-body
+ * linear and angular velocities) by more than this (m/s or rad/s): the sweeps that would follow contract further, so
+ * what is left out is below the solver's own residual by orders of magnitude. solver_position_iterations is the maximum.
+ * An env without contacts and without an active joint limit takes one sweep, a warm-started resting contact two or three. */
+#define MSSIM_PGS_EXIT_TOLERANCE 1e-6f
 /* PxSceneDesc::wakeCounterResetValue (PhysX default 20 * 0.02 s): how long the energy of a free body has to stay below
  * sleep_threshold before it is put to sleep */
 #define MSSIM_WAKE_TIME 0.4f

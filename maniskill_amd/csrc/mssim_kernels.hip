@@ -1156,8 +1156,8 @@ extern "C++" {
 template <int TASK>
 static void launch_control_step(mssim_handle h, const DevState& S, int n_substeps, hipStream_t st) {
   prof_mark(h, 0, st);
-  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, TASK>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
-  else hipLaunchKernelGGL((k_solve16<0, 0>), env_grid(h->N, S16_ENVS_PER_BLOCK), dim3(16 * S16_ENVS_PER_BLOCK), 0, st, h->M, S, n_substeps);
+  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, TASK>), env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), dim3(64 * S16_WAVES), 0, st, h->M, S, n_substeps);
+  else hipLaunchKernelGGL((k_solve16<0, 0>), env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), dim3(64 * S16_WAVES), 0, st, h->M, S, n_substeps);
   prof_mark(h, 0, st);
 }
 }  // extern "C++"

@@ -23,6 +23,17 @@
 #pragma once
 
 #define S16_LANES 16
+// A block is S16_WAVES waves of 4 envs each. Every wave works on its own envs (its own slice of the LDS, wave-level
+// ordering only: WSYNC) except in narrowphase stage B, where the generic-convex pairs of ALL the block's envs form one
+// task list taken round-robin by all its 16-lane groups (BSYNC = block barrier around it): the launch lasts as long as
+// its slowest env, and an arm folded onto itself has 15-20 such pairs per substep -- 4-5 rounds for the 4 groups of one
+// wave, 1-2 rounds for the 16 groups of four.
+#ifndef S16_WAVES
+#define S16_WAVES 4
+#endif
+// ordering of LDS traffic among the lanes of ONE wave (its LDS instructions execute in program order): a compiler fence
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define BSYNC() __syncthreads()
 #ifndef S16_ENVS_PER_BLOCK
 #define S16_ENVS_PER_BLOCK 4
 #endif
@@ -471,17 +482,22 @@ struct SupCoop16 {
 // reward epilogue of a task -- 1 PickCube, 2 PushCube, 3 PegInsertionSide -- so that a whole control step
 // (action map, substeps, copy-out, epilogue) is one launch.
 template <int NDOF = 0, int TASK = 0>
-__global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M, DevState S, int n_sub) {
+__global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState S, int n_sub) {
   constexpr bool FUSED = true;  // (the per-substep variant fed by a separate narrowphase kernel is gone)
-  __shared__ __attribute__((aligned(16))) float sm[S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
+  __shared__ __attribute__((aligned(16))) float sm[S16_WAVES * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
+  __shared__ int blk_nml[S16_WAVES * S16_ENVS_PER_BLOCK];  // generic-convex pairs of every env of the block (stage B task list)
   const int N = S.N;
-  const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+  constexpr int BLK_ENVS = S16_WAVES * S16_ENVS_PER_BLOCK;
+  const int wv = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+  const int g = lane64 >> 4, c = threadIdx.x & 15;  // group within the wave, lane within the group
+  const int gb = wv * S16_ENVS_PER_BLOCK + g;       // group (= env slot) within the block
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  if (chunk * S16_ENVS_PER_BLOCK >= N) return;  // grid padding
-  const int e_raw = chunk * S16_ENVS_PER_BLOCK + g;
+  if (chunk * BLK_ENVS >= N) return;  // grid padding
+  const int e_raw = chunk * BLK_ENVS + gb;
   const bool live = e_raw < N;
   const int e = live ? e_raw : N - 1;  // dead groups shadow the last env and never store
-  float* L = sm + g * S16_ENV_FLOATS;
+  float* L = sm + gb * S16_ENV_FLOATS;
+  float* const smw = sm + wv * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS;  // the envs of this wave
   const int n = NDOF > 0 ? NDOF : M.n_dof, nf = M.n_free;
   const float dt = M.dt;
   const float inv_dt = rcp_f(dt);
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
   // for the two dependent global loads to be done when the impulse phase needs them, late enough not to be live
   // across the narrowphase.
   int nold = 0, oldp[3] = {-1, -1, -1};
-  __syncthreads();
+  WSYNC();
   PH(0);
 
   float v_c = 0.f;
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           o[16] = shH[k].x; o[17] = shH[k].y; o[18] = shH[k].z; o[19] = shTr[k];
         }
       }
-      __syncthreads();
+      WSYNC();
       PH(22);
       // ---- cull: 16 pairs of this env per round, survivors appended in pair order
       int nh = 0;
@@ -684,12 +700,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           surv = !cull;
         }
         // survivors are compacted in place into the staged pair table (write index <= read index)
-        __syncthreads();  // all reads of this round before its writes
+        WSYNC();  // all reads of this round before its writes
         const unsigned long long bal = __ballot(surv);
         const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
         if (surv) reinterpret_cast<int*>(L)[S16_NP_SCR + nh + __popc(m16 & ((1u << c) - 1u))] = p | (sa << 16) | (sb << 24);
         nh += __popc(m16);
-        __syncthreads();
+        WSYNC();
       };
 #pragma unroll 1
       for (int base = 0; base < M.n_pair; base += 16) {
@@ -729,7 +745,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         nh = nh2 < S16_MAX_HIT ? nh2 : S16_MAX_HIT;
         if (!live) nh = 0;  // (a shadow group of the last env produces nothing: its pairs would touch that env's manifold cache twice)
       }
-      __syncthreads();
+      WSYNC();
       if (__any(hit_over) && hit_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_HITS);
       PH(23);
       // ---- classification: generic convex pairs (MPR) and box-box pairs of this env (byte lists of hit indices)
@@ -780,8 +796,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // scratch is this area -- only possible while all tasks of the wave fit one round.
       const bool bb_lane = TB > S16_MAX_BBC && T <= 64;  // wave-uniform
       bool pool_over = false;
-      __syncthreads();
+      WSYNC();
       PH_ADD(14, (TM + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK);
+      (void)mcum;
       PH_ADD(26, T);
       // a manifold goes to the staging tables of its env: normal, size, `cnt` points from the pool
       auto pool_alloc = [&](float* Lg, int cnt) __attribute__((always_inline)) -> int {
@@ -792,13 +809,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // ---- stage A: plane pairs (and the box-box pairs when bb_lane), all such (env, pair) tasks of the wave
       // spread over the 64 lanes
       for (int t0 = 0; t0 < T; t0 += 64) {
-        const int t = t0 + (int)threadIdx.x;
+        const int t = t0 + lane64;
         const bool has = t < T;
         int ge = 0;
 #pragma unroll
         for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += (has && t >= cum[j]) ? 1 : 0;
         const int idx = has ? t - cum[ge] : 0;
-        float* Lg = sm + ge * S16_ENV_FLOATS;
+        float* Lg = smw + ge * S16_ENV_FLOATS;
         manifold_t m;
         manifold_clear(m);
         bool mine = false;
@@ -812,14 +829,14 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const bool is_plane = A.type == SH_PLANE, is_bb = bb_lane && A.type == SH_BOX && B.type == SH_BOX;
           if (is_plane) collide_plane(A, B, M.contact_offset, m);
           PH(11);
-          if (is_bb) collide_box_box<16>(A, B, M.contact_offset, m, sm + g * S16_ENV_FLOATS + S16_NP_SCR + c);
+          if (is_bb) collide_box_box<16>(A, B, M.contact_offset, m, L + S16_NP_SCR + c);
           PH(12);
           mine = is_plane || is_bb;
         }
-        __syncthreads();  // the clip scratch is dead: the staging tables take its place
+        WSYNC();  // the clip scratch is dead: the staging tables take its place
         if (t0 == 0) {
           if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
-          __syncthreads();
+          WSYNC();
         }
         if (mine && m.count > 0) {
           const int off = pool_alloc(Lg, m.count);
@@ -837,7 +854,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       if (T == 0) {  // (wave-uniform) no round ran: the pool counter is still to be cleared
         if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
       }
-      __syncthreads();
+      if (c == 0) blk_nml[gb] = nml;
+      BSYNC();  // every wave is done with its clip scratch: stage B may write manifolds into any env's staging tables
       PH(13);
       // ---- stage B: generic convex pairs through the persistent manifold cache (include/mssim.h MSSIM_PCM_*).
       // B0: every env's own group assigns cache slots to its pairs, in pair order (same pair -> its slot; else the
@@ -879,18 +897,25 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (live && (hd.x != hd0.x || hd.y != hd0.y || hd.z != hd0.z || hd.w != hd0.w))
           *reinterpret_cast<int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN) = hd;
       }
-      __threadfence_block();  // (the headers are read back below by other groups of this wave, through the CU's L1)
-      __syncthreads();
-      // B: a pair is worked on by one 16-lane group (hull scans shared by its lanes); the pairs of all 4 envs form
-      // one task list that the 4 groups take round-robin. Lanes 0..3 of the group hold the manifold's points.
+      __threadfence_block();  // (the headers are read back below by other groups of this block, through the CU's L1)
+      BSYNC();
+      // B: a pair is worked on by one 16-lane group (hull scans shared by its lanes); the pairs of all the block's envs
+      // form one task list that all its groups take round-robin. Lanes 0..3 of the group hold the manifold's points.
       BT_T(17);
-      for (int t0 = 0; t0 < TM; t0 += S16_ENVS_PER_BLOCK) {
-        const bool has = t0 + g < TM;
-        const int t = has ? t0 + g : t0;  // (idle groups shadow the round's first pair: valid shapes, no output)
-        int ge = 0;
+      int TMb = 0;
 #pragma unroll
-        for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= mcum[j] ? 1 : 0;
-        const int k = t - mcum[ge];
+      for (int j = 0; j < BLK_ENVS; j++) TMb += blk_nml[j];
+      for (int t0 = 0; t0 < TMb; t0 += BLK_ENVS) {
+        const bool has = t0 + gb < TMb;
+        const int t = has ? t0 + gb : t0;  // (idle groups shadow the round's first pair: valid shapes, no output)
+        int ge = 0, k = t;
+#pragma unroll
+        for (int j = 0; j < BLK_ENVS - 1; j++) {
+          const int nj = blk_nml[j];
+          const bool past = ge == j && k >= nj;
+          k -= past ? nj : 0;
+          ge += past ? 1 : 0;
+        }
         float* Lg = sm + ge * S16_ENV_FLOATS;
         const int idx = reinterpret_cast<const unsigned char*>(Lg + S16_NP_ML)[k];
         const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
@@ -903,7 +928,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         const int sbyte = reinterpret_cast<const unsigned char*>(Lg + S16_NP_SLOT)[idx];
         const bool cached = has && sbyte != 255;
         const bool fresh = cached && (sbyte & 0x80);
-        float* const slot = S.pcm + ((size_t)(chunk * S16_ENVS_PER_BLOCK + ge) * MSSIM_PCM_SLOTS + (cached ? (sbyte & 15) : 0)) * S16_PCM_LEN;
+        float* const slot = S.pcm + ((size_t)(chunk * BLK_ENVS + ge) * MSSIM_PCM_SLOTS + (cached ? (sbyte & 15) : 0)) * S16_PCM_LEN;
         auto b16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
         // ---- slot -> registers: header in every lane, point c in lane c < 4
         int npts = 0, grow = 0;
@@ -1117,6 +1142,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
         }
       }
+      BSYNC();  // the manifolds of this wave's envs may have been written by other waves
       BT_T(22);
       PH(25);
       // ---- stage C: box-box pairs by 16-lane groups, round-robin over the wave's list
@@ -1126,7 +1152,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #pragma unroll
           for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= bcum[j] ? 1 : 0;
           const int k = t - bcum[ge];
-          float* Lg = sm + ge * S16_ENV_FLOATS;
+          float* Lg = smw + ge * S16_ENV_FLOATS;
           const int idx = reinterpret_cast<const unsigned char*>(Lg + S16_NP_BL)[k];
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
@@ -1150,7 +1176,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
       }
       if (__any(pool_over) && pool_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_RAW);  // (recorded for the group's own env: a reported condition either way)
-      __syncthreads();
+      WSYNC();
       PH(24);
       // ---- contact patches (include/mssim.h, MSSIM_PATCH_COS): manifolds of one body pair with normals inside a
       // cone of the first of them are one patch, cut to its 4 most significant points. Lane c looks after the
@@ -1170,7 +1196,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           const bool tors = fmaxf(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 19], L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 19]) > 0.f;
           key_[i] = (int)(((pa >> 10) & 31u) | (((pb >> 10) & 31u) << 8)) | (tors ? 1 << 16 : 0);
         }
-        __syncthreads();
+        WSYNC();
         // sleeping free bodies: a "disturber" is an articulation link or a free body that is awake and not calm. A
         // sleeping body touched by a disturber wakes; the manifolds of a body that stays asleep are dropped; whether a
         // disturber touched it feeds its sleep counter at the end of the substep.
@@ -1201,7 +1227,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             const bool sa_ = ba >= 0 && (ba == 0 ? fwake[0] : fwake[1]) <= 0.f, sb_ = bb >= 0 && (bb == 0 ? fwake[0] : fwake[1]) <= 0.f;
             if (sa_ || sb_) cnt_[i] = 0;
           }
-          __syncthreads();
+          WSYNC();
         }
         bool any_big = false;
         for (int i = c; i < nh; i += 16) {
@@ -1216,7 +1242,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
           keep_[i] = (anchor << 4) | ((1 << ci) - 1);
         }
-        __syncthreads();
+        WSYNC();
         for (int a = c; a < nh; a += 16) {
           if ((keep_[a] >> 4) != a || cnt_[a] == 0) continue;
           int total = 0, tflag = 0;
@@ -1284,7 +1310,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           }
         }
         PH_ADD(9, __any(any_big) ? 1 : 0);
-        __syncthreads();
+        WSYNC();
         // records in solver order: patch by patch (patches in the order of their anchors), inside a patch manifold by
         // manifold (a manifold belongs to one patch: the points of a shape pair stay together), then the patch's
         // torsional friction record if one of its shapes carries a patch radius (one solver block each,
@@ -1352,7 +1378,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (tot > MAXC) { if (live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONTACTS); tot = MAXC; }
         nc = tot;
       }
-      __syncthreads();
+      WSYNC();
     }
     if (FUSED && last) {
       nold = S.hit_list[e];
@@ -1419,7 +1445,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       p[0] = S_c.w.x; p[1] = S_c.w.y; p[2] = S_c.w.z; p[3] = S_c.v.x; p[4] = S_c.v.y; p[5] = S_c.v.z;
       L[S16_VEC + c] = qd_c;
     }
-    __syncthreads();
+    WSYNC();
     // V_c = sum over (ancestors + self) of S_i qd_i
     sv6 V = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
     for (int i = 0; i < n; i++) {
@@ -1433,7 +1459,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       float* p = L + S16_T + 6 * c;
       p[0] = T.w.x * qd_c; p[1] = T.w.y * qd_c; p[2] = T.w.z * qd_c; p[3] = T.v.x * qd_c; p[4] = T.v.y * qd_c; p[5] = T.v.z * qd_c;
     }
-    __syncthreads();
+    WSYNC();
     sv6 Ab = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
     for (int i = 0; i < n; i++) {
       float m = (((anc_c | self_c) >> i) & 1u) ? 1.f : 0.f;
@@ -1465,7 +1491,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #pragma unroll
       for (int k = 0; k < 16; k++) L[S16_MAT + 16 * c + k] = 0.f;
     }
-    __syncthreads();
+    WSYNC();
     // composite force / inertia: sum over (descendants + self)
     sf6 Fc = sf6{f3{0, 0, 0}, f3{0, 0, 0}};
     si10 Icc = si10{0.f, f3{0, 0, 0}, s3{0, 0, 0, 0, 0, 0}};
@@ -1493,7 +1519,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         }
       }
     }
-    __syncthreads();
+    WSYNC();
     float Mrow[16], qdv[16];
     ld16(L + S16_MAT + 16 * c, Mrow);
     ld16(L + S16_VEC, qdv);
@@ -1548,12 +1574,12 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         if (k >= n) break;
-        __syncthreads();
+        WSYNC();
         if (c == k) {
 #pragma unroll
           for (int j = 0; j < NA; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + NA + j] = Irow[j]; }
         }
-        __syncthreads();
+        WSYNC();
         float PA[NA], PI[NA];
 #pragma unroll
         for (int j = 0; j < NA; j += 4) {
@@ -1571,9 +1597,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           Irow[j] = piv ? PI[j] * inv : Irow[j] - fac * PI[j];
         }
       }
-      __syncthreads();
+      WSYNC();
       L[S16_VEC + 16 + c] = rhs_c;
-      __syncthreads();
+      WSYNC();
       float rv[16];
       ld16(L + S16_VEC + 16, rv);
       vstar = 0.f;
@@ -1639,7 +1665,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     if (art) { jaxis_c = aw_c; jorigin_c = an_c; jrot_c = rev_c; }
     else if (freel) { jaxis_c = f3{(fk % 3) == 0 ? 1.f : 0.f, (fk % 3) == 1 ? 1.f : 0.f, (fk % 3) == 2 ? 1.f : 0.f}; jorigin_c = mycom; jrot_c = fk >= 3; }
     fforce_c = 0.f;  // an applied force acts during one substep only
-    __syncthreads();  // the dynamics staging area is dead from here on: rows overlay it
+    WSYNC();  // the dynamics staging area is dead from here on: rows overlay it
     PH(3);
 
     // ================================================================ rows
@@ -1749,7 +1775,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       L[S16_CS + 16 * i + 10] = ok ? w.y : 0.f;
       L[S16_CS + 16 * i + 11] = ok ? w.z : 0.f;
     }
-    __syncthreads();
+    WSYNC();
     float* const grow = S.rows + (size_t)e * ((size_t)S16_ROWS_GLB * S16_ROWLEN);
     float Jr[S16_REGC][3], Wr[S16_REGC][3], lamr[S16_REGC][3];
 #pragma unroll
@@ -1780,7 +1806,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     nrow_con = nc;
     PH_ADD(29, max_nc);
     PH_ADD(30, __shfl(nc, 0) + __shfl(nc, 16) + __shfl(nc, 32) + __shfl(nc, 48));
-    __syncthreads();
+    WSYNC();
     PH(4);
 
     // ================================================================ projected Gauss-Seidel
@@ -1849,6 +1875,9 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
 #else
     const int n_iters = M.pos_iters + M.vel_iters;
 #endif
+    // early exit of the position sweeps, per env (include/mssim.h MSSIM_PGS_EXIT_TOLERANCE): `settled` is group-uniform;
+    // a sweep runs under the exec mask of the envs that are not, and not at all once the wave's four are
+    bool settled = false;
     for (int it = 0; it <= n_iters; it++) {
       if (it == M.pos_iters) {
         q_c += dt * fminf(fmaxf(v_c, -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
@@ -1865,7 +1894,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           q4 dq = qmul(q4{0.f, ww.x, ww.y, ww.z}, qq);
           qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
           f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
-          __syncthreads();
+          WSYNC();
           if (fwake[b] <= 0.f) {  // asleep: the pose stays bit for bit
             pp = f3{pt[0], pt[1], pt[2]};
             qq = q4{pt[3], pt[4], pt[5], pt[6]};
@@ -1875,12 +1904,16 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
             SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
             SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
           }
-          __syncthreads();
+          WSYNC();
         }
       }
       if (it == n_iters) break;
       PH(17);
       const bool use_bias = it < M.pos_iters;
+      const bool run = !(settled && use_bias);
+      if (!__any(run)) { it = M.pos_iters - 1; continue; }  // (wave-uniform) every env of the wave has settled: on to the integration
+      const float v_before = v_c;
+      if (run) {
       // block scalars of contact k + 1 are read from the LDS table before the dependent chain of contact k
       // (one wave per SIMD: nothing else hides the LDS latency); slot k + 1 always exists in the table
       float4 ns0 = *reinterpret_cast<const float4*>(L + S16_CS), nsk = *reinterpret_cast<const float4*>(L + S16_CS + 4);
@@ -1972,6 +2005,8 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           cursor = act ? j + 1 : 16;
         }
       }
+      }  // run
+      if (use_bias) settled = settled || ((unsigned)(__ballot(fabsf(v_c - v_before) > MSSIM_PGS_EXIT_TOLERANCE) >> (16 * g)) & 0xFFFFu) == 0u;
       PH(18);
     }
     if (c == 0) {
@@ -1979,7 +2014,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       for (int k = 0; k < S16_REGC; k++)
         if (k < nc_reg) { L[S16_CS + 16 * k + 9] = lamr[k][0]; L[S16_CS + 16 * k + 10] = lamr[k][1]; L[S16_CS + 16 * k + 11] = lamr[k][2]; }
     }
-    __syncthreads();
+    WSYNC();
     // the multipliers of this substep, keyed by (shape pair, manifold slot) and stamped: the next substep's warm start
     for (int i = c; i < nc; i += 16) {
       const int pw = __float_as_int(L[S16_REC + S16_REC_LEN * i + 7]);
@@ -2025,7 +2060,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       }
       flush();
       if (FUSED) {
-        __syncthreads();
+        WSYNC();
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           const int po = oldp[k];
@@ -2034,7 +2069,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
           if (!still && live) S.pair_cnt[(size_t)po * N + e] = 0;
         }
         if (c == 0 && live) S.hit_list[e] = nnew;
-        __syncthreads();
+        WSYNC();
       }
     }
     PH(6);
@@ -2044,7 +2079,7 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
     // and composes with its ancestor's partial product, doubling the covered chain length per round
     // (4 rounds cover depth 16); sincos and the products run in all lanes at once instead of a
     // 9-long sequential chain. Same transforms as the sequential product, different association.
-    __syncthreads();
+    WSYNC();
     const pose_t rootf = lds_pose(L + S16_PT);
     pose_t nb = rootf;
     f3 naw = f3{0, 0, 0}, nan = f3{0, 0, 0};
@@ -2062,17 +2097,17 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
         if (!__any(up >= 0)) break;
         if (art) lds_pose_store(mine, T);
         upv[c] = up;
-        __syncthreads();
+        WSYNC();
         if (up >= 0) {
           const pose_t Tu = lds_pose(L + S16_BP + 7 * up);
           up = upv[up];
           T = pmul(Tu, T);
         }
-        __syncthreads();
+        WSYNC();
       }
       nb = pmul(rootf, T);
       if (art) lds_pose_store(mine, nb);
-      __syncthreads();
+      WSYNC();
       pose_t Wp = rootf;
       if (par_c >= 0) Wp = lds_pose(L + S16_BP + 7 * par_c);
       const pose_t Jw = pmul(Wp, JF_c);
@@ -2121,13 +2156,13 @@ __global__ __launch_bounds__(16 * S16_ENVS_PER_BLOCK) void k_solve16(DevModel M,
       // body velocities about O with the new subspaces
       sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
       if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
-      __syncthreads();
+      WSYNC();
       {
         float* p = L + S16_S + 6 * c;
         p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
         L[S16_VEC + c] = qd_c;
       }
-      __syncthreads();
+      WSYNC();
       sv6 nV = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
       for (int i = 0; i < n; i++) {
         float m = (((anc_c | self_c) >> i) & 1u) ? L[S16_VEC + i] : 0.f;

@@ -989,7 +989,20 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   std::vector<Real> v_pos;
   std::vector<Vec> fv_pos, fw_pos;
   if (!M.tgs) {
-    for (int it = 0; it < M.pos_iters; it++) sweep(true);
+    for (int it = 0; it < M.pos_iters; it++) {
+      const std::vector<Real> v0 = v;
+      const std::vector<Vec> fv0 = fv, fw0 = fw;
+      sweep(true);
+      // early exit (include/mssim.h MSSIM_PGS_EXIT_TOLERANCE): no velocity component moved by more than the tolerance
+      Real mx = 0;
+      for (int i = 0; i < n; i++) mx = std::max(mx, std::fabs(v[i] - v0[i]));
+      for (int b = 0; b < nf; b++) {
+        const Vec d = fv[b] - fv0[b], r = fw[b] - fw0[b];
+        mx = std::max(mx, std::max(std::max(std::fabs(d.x), std::fabs(d.y)), std::fabs(d.z)));
+        mx = std::max(mx, std::max(std::max(std::fabs(r.x), std::fabs(r.y)), std::fabs(r.z)));
+      }
+      if (!(mx > Real(MSSIM_PGS_EXIT_TOLERANCE))) break;
+    }
     v_pos = v; fv_pos = fv; fw_pos = fw;
   } else {
     // TGS-style position sub-stepping (the experiment behind DESIGN.md's PGS-vs-TGS comparison; never used by the

@@ -46,7 +46,7 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
 
 # slowest blocks of the last launch
 import numpy as np
-nb = min(2048, 8 * (((N + 3) // 4 + 7) // 8))
+nb = min(2048, 8 * (((N + 15) // 16 + 7) // 8))  # blocks of 4 waves x 4 envs
 arr = (ctypes.c_uint * (nb * 32))()
 dbg.mssim_debug_phase_blocks(arr, nb)
 a = np.frombuffer(arr, dtype=np.uint32).reshape(nb, 32).astype(np.float64)
