@@ -115,11 +115,12 @@ __device__ unsigned g_phase_blk[2048 * 32];  // per-block deltas of the most rec
 #define BT_T0
 #define BT_T(i)
 #define PH_FLUSH                                                                  \
-  if (threadIdx.x == 0) {                                                         \
+  if ((threadIdx.x & 63) == 0) {  /* one record per wave */                        \
+    const int w_ = blockIdx.x * S16_WAVES + (threadIdx.x >> 6);                    \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++)                             \
       if (ph_d[i_]) atomicAdd(&g_phase_clk[i_], (unsigned long long)ph_d[i_]);    \
-    if (blockIdx.x < 2048) {                                                      \
-      _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) g_phase_blk[blockIdx.x * 32 + i_] = ph_d[i_]; \
+    if (w_ < 2048) {                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) g_phase_blk[w_ * 32 + i_] = ph_d[i_]; \
     }                                                                             \
   }
 #elif defined(MSSIM_BLOCK_TIMES)
@@ -137,8 +138,8 @@ __device__ unsigned g_phase_blk[2048 * 32];
 #define BT_T0 unsigned bt_t_ = (unsigned)clock64()
 #define BT_T(i) do { __builtin_amdgcn_s_waitcnt(0); ph_d[i] += (unsigned)clock64() - bt_t_; bt_t_ = (unsigned)clock64(); } while (0)
 #define PH_FLUSH                                                                   \
-  if (threadIdx.x == 0 && blockIdx.x < 2048) {                                     \
-    unsigned* o_ = g_phase_blk + blockIdx.x * 32;                                  \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x * S16_WAVES + (threadIdx.x >> 6) < 2048) {  /* one record per wave */ \
+    unsigned* o_ = g_phase_blk + (blockIdx.x * S16_WAVES + (threadIdx.x >> 6)) * 32;  \
     _Pragma("unroll") for (int i_ = 8; i_ < 32; i_++) o_[i_] = ph_d[i_];           \
     o_[0] = (unsigned)bt_w0; o_[1] = (unsigned)(bt_w0 >> 32);                      \
     o_[2] = (unsigned)(wall_clock64() - bt_w0);                                    \
@@ -697,7 +698,13 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             const float rr = ra + rb + M.contact_offset;
             cull = dot(d, d) > rr * rr;
           }
-          surv = !cull;
+          // a pair of bodies that cannot move in this substep (fixed in the env frame, or asleep at its start) needs no manifold
+          const int s1a = (int)((__float_as_uint(ta_[14]) >> 10) & 31u), s1b = (int)((__float_as_uint(tb_[14]) >> 10) & 31u);
+          auto inactive = [&](int s1) {
+            const int b = s1 - 1 - S16_PT_FREE;
+            return s1 == 0 || (b >= 0 && b < S16_MAX_FREE && (b == 0 ? fwake[0] : fwake[1]) <= 0.f);
+          };
+          surv = !cull && !(inactive(s1a) && inactive(s1b));
         }
         // survivors are compacted in place into the staged pair table (write index <= read index)
         WSYNC();  // all reads of this round before its writes

@@ -515,6 +515,14 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
   for (int p = 0; p < M.n_pair; p++) {
     int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
     const Shape<Real>&A = sh[sa], &B = sh[sb];
+    // a pair of bodies that cannot move in this substep -- fixed in the env frame or asleep at its start -- needs no
+    // manifold (a sleeping body woken later in the substep gets its contacts with the static scene back in the next one)
+    {
+      auto inactive = [&](int s) {
+        return M.shape_kind[s] == MSSIM_BODY_WORLD || (M.shape_kind[s] == MSSIM_BODY_FREE && E.free_wake[M.shape_index[s]] <= 0);
+      };
+      if (inactive(sa) && inactive(sb)) continue;
+    }
     // bounding-sphere cull
     Real ra, rb;
     Vec cla, clb;

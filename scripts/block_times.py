@@ -24,7 +24,7 @@ steps = int(args[2]) if len(args) > 2 else 100
 env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos")
 env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
-nb = min(2048, 8 * (((N + 15) // 16 + 7) // 8))  # blocks of 4 waves x 4 envs
+nb = min(2048, 4 * 8 * (((N + 15) // 16 + 7) // 8))  # one record per wave (4 envs); blocks are 4 waves
 arr = (ctypes.c_uint * (nb * 32))()
 for rep in range(3):
     for _ in range(steps):

@@ -46,7 +46,7 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
 
 # slowest blocks of the last launch
 import numpy as np
-nb = min(2048, 8 * (((N + 15) // 16 + 7) // 8))  # blocks of 4 waves x 4 envs
+nb = min(2048, 4 * 8 * (((N + 15) // 16 + 7) // 8))  # one record per wave (4 envs); blocks are 4 waves
 arr = (ctypes.c_uint * (nb * 32))()
 dbg.mssim_debug_phase_blocks(arr, nb)
 a = np.frombuffer(arr, dtype=np.uint32).reshape(nb, 32).astype(np.float64)
