@@ -64,9 +64,10 @@ extern "C" {
  * substep, as without the cache. A pair that is in range but not in contact keeps an empty slot, so it is not queried
  * again until it moves. */
 /* The portal refinement of a generic-convex query (MPR) stops when the support plane along the portal normal lies within
- * this distance of the portal (Bullet's btMprPenetration uses the same 1e-4): the reported gap is accurate to 0.1 mm. A
- * tenth of it buys nothing the solver can see and costs ~40 % more refinement iterations on tessellated round hulls. */
-#define MSSIM_MPR_TOLERANCE 1e-4f
+ * this distance of the portal: the accuracy of the reported gap. (1e-4, Bullet's btMprPenetration value, saves a third of
+ * the refinement iterations on tessellated round hulls and 1-3 % of the control step; it is not used because the f32 kernel
+ * and the f64 oracle then stop at different portals and part by up to that much at every first contact.) */
+#define MSSIM_MPR_TOLERANCE 1e-5f
 #define MSSIM_PCM_SLOTS 16
 #define MSSIM_PCM_DRIFT 5e-3f       /* m, sideways drift that breaks a cached point (0.25 x contact offset)          */
 #define MSSIM_PCM_MOVE 1e-3f        /* m, relative translation since the last full query that forces a new one       */
@@ -218,7 +219,9 @@ typedef struct mssim_model_desc {
   int32_t n_env_shape;
   const int32_t* shape_env_slot; /* [n_shape] slot into the env_shape_* arrays, -1 = shared       */
   const float* env_shape_frame;  /* [n_env_shape*7][N]                                            */
-  const float* env_shape_param;  /* [n_env_shape*4][N]                                            */
+  const float* env_shape_param;  /* [n_env_shape*4][N]; a MSSIM_SHAPE_CONVEX shape: {first vertex in hull_verts, vertex count
+                                    (<= MSSIM_MAX_HULL_VERTS), -, -} as float-valued integers -- a different hull per env
+                                    (the reference's per-env object sets, e.g. one YCB model per sub-scene)              */
   const float* env_shape_bound;  /* [n_env_shape*4][N] bounding-sphere centre in the BODY frame, radius */
   int32_t n_env_free;
   const int32_t* free_env_slot;  /* [n_free] slot into env_free_inertial, -1 = shared             */

@@ -227,27 +227,6 @@ MS_DEV void free_inertial_of(const DevModel& M, int N, int b, int e, float* out)
   for (int k = 0; k < 10; k++) out[k] = slot < 0 ? M.free_inertial[10 * b + k] : M.env_free_inertial[(size_t)(10 * slot + k) * N + e];
 }
 
-MS_DEV shape_t make_shape(const DevModel& M, const DevState& S, int s, int e) {
-  shape_t sh;
-  const int slot = M.shape_env_slot[s];
-  pose_t F;
-  if (slot < 0) {
-    F = pose_from(M.shape_frame + 7 * s);
-    sh.p0 = M.shape_param[4 * s]; sh.p1 = M.shape_param[4 * s + 1]; sh.p2 = M.shape_param[4 * s + 2];
-  } else {
-    F = pose_soa(M.env_shape_frame, 7 * slot, S.N, e);
-    const float* pp = M.env_shape_param + (size_t)(4 * slot) * S.N + e;
-    sh.p0 = pp[0]; sh.p1 = pp[(size_t)S.N]; sh.p2 = pp[2 * (size_t)S.N];
-  }
-  pose_t W = pmul(body_pose_of(M, S, M.shape_kind[s], M.shape_index[s], e), F);
-  sh.type = M.shape_type[s];
-  sh.c = W.p;
-  sh.rot = qmat(W.q);
-  sh.verts = M.hull_verts + 3 * M.shape_hull[2 * s];
-  sh.nverts = M.shape_hull[2 * s + 1];
-  return sh;
-}
-
 // ------------------------------------------------------------------------------------------------
 // apply / fetch: transposes between the user-visible AoS buffers and the SoA state
 __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) {
@@ -895,6 +874,9 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   S->h_pair_shape.assign(d->pair_shape, d->pair_shape + 2 * (size_t)d->n_pair);
   UP(shape_frame, 7 * ns) UP(shape_param, 4 * ns) UP(shape_material, 4 * ns) UP(shape_bound, 4 * ns)
 #undef UP
+  // device copy of env_shape_param: a convex shape's rows become {first vertex | count << 17 (bit pattern), half extents of
+  // its box for the cull (shape frame, centred at the bound centre)}
+  std::vector<float> env_param_dev;
   {
     // hull vertices are repacked so that every hull starts on a multiple of 8 vertices and is padded
     // to a multiple of 8 with copies of its vertex 0: `support()` reads whole 8-vertex batches as six
@@ -902,21 +884,54 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
     std::vector<float> hv;
     std::vector<int32_t> sh(2 * (ns > 0 ? ns : 1), 0);
     std::vector<std::pair<std::pair<int, int>, int>> seen;  // (start, count) -> new start
+    auto repacked = [&](int st, int cnt) {
+      for (auto& kv : seen) if (kv.first.first == st && kv.first.second == cnt) return kv.second;
+      const int found = (int)(hv.size() / 3);
+      for (int i = 0; i < (cnt + 7) / 8 * 8; i++) {
+        const float* v = d->hull_verts + 3 * (size_t)(st + (i < cnt ? i : 0));
+        hv.push_back(v[0]); hv.push_back(v[1]); hv.push_back(v[2]);
+      }
+      seen.push_back({{st, cnt}, found});
+      return found;
+    };
     for (int s2 = 0; s2 < ns; s2++) {
       const int st = d->shape_hull[2 * s2], cnt = d->shape_hull[2 * s2 + 1];
       sh[2 * s2 + 1] = cnt;
       if (cnt <= 0) continue;
-      int found = -1;
-      for (auto& kv : seen) if (kv.first.first == st && kv.first.second == cnt) found = kv.second;
-      if (found < 0) {
-        found = (int)(hv.size() / 3);
-        for (int i = 0; i < (cnt + 7) / 8 * 8; i++) {
-          const float* v = d->hull_verts + 3 * (size_t)(st + (i < cnt ? i : 0));
-          hv.push_back(v[0]); hv.push_back(v[1]); hv.push_back(v[2]);
+      sh[2 * s2] = repacked(st, cnt);
+    }
+    if (d->n_env_shape > 0 && d->num_envs == num_envs) {
+      const size_t NE = (size_t)num_envs;
+      env_param_dev.assign(d->env_shape_param, d->env_shape_param + (size_t)4 * d->n_env_shape * NE);
+      for (int s2 = 0; s2 < ns; s2++) {
+        const int slot = d->shape_env_slot[s2];
+        if (slot < 0 || d->shape_type[s2] != MSSIM_SHAPE_CONVEX) continue;
+        for (size_t e = 0; e < NE; e++) {
+          const int st = (int)d->env_shape_param[(size_t)(4 * slot) * NE + e], cnt = (int)d->env_shape_param[(size_t)(4 * slot + 1) * NE + e];
+          if (cnt < 1 || cnt > MSSIM_MAX_HULL_VERTS || st < 0 || st + cnt > d->n_hull_verts) { g_create_error = "per-env hull reference out of range"; mssim_destroy(S); return 8; }
+          const int found = repacked(st, cnt);
+          // bound centre (body frame) back into the shape frame, then the extents of the hull about it
+          float fr[7], cb[3];
+          for (int k = 0; k < 7; k++) fr[k] = d->env_shape_frame[(size_t)(7 * slot + k) * NE + e];
+          for (int k = 0; k < 3; k++) cb[k] = d->env_shape_bound[(size_t)(4 * slot + k) * NE + e] - fr[k];
+          const float nq = std::sqrt(fr[3] * fr[3] + fr[4] * fr[4] + fr[5] * fr[5] + fr[6] * fr[6]);
+          const float qw = fr[3] / nq, qx = fr[4] / nq, qy = fr[5] / nq, qz = fr[6] / nq;
+          const float R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)},
+                                 {2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)},
+                                 {2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
+          float cs[3], h[3] = {0.f, 0.f, 0.f};
+          for (int k = 0; k < 3; k++) cs[k] = R[0][k] * cb[0] + R[1][k] * cb[1] + R[2][k] * cb[2];
+          for (int i = 0; i < cnt; i++) {
+            const float* v = d->hull_verts + 3 * (size_t)(st + i);
+            for (int k = 0; k < 3; k++) h[k] = std::max(h[k], std::fabs(v[k] - cs[k]));
+          }
+          const int32_t packed = found | (cnt << 17);
+          float pf;
+          std::memcpy(&pf, &packed, 4);
+          env_param_dev[(size_t)(4 * slot) * NE + e] = pf;
+          for (int k = 0; k < 3; k++) env_param_dev[(size_t)(4 * slot + 1 + k) * NE + e] = h[k];
         }
-        seen.push_back({{st, cnt}, found});
       }
-      sh[2 * s2] = found;
     }
     if (hv.size() / 3 >= (1u << 17)) { g_create_error = "too many hull vertices"; mssim_destroy(S); return 8; }
     if ((rc = upload(S, sh.data(), sh.size(), &M.shape_hull)) || (rc = upload(S, hv.data(), hv.size(), &M.hull_verts))) { mssim_destroy(S); return rc; }
@@ -1000,7 +1015,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
     if (has_ef) for (int i = 0; i < d->n_free; i++) fslot[i] = d->free_env_slot[i];
     if ((rc = upload(S, sslot.data(), sslot.size(), &M.shape_env_slot)) || (rc = upload(S, fslot.data(), fslot.size(), &M.free_env_slot)) ||
         (rc = upload(S, d->env_shape_frame, (size_t)7 * d->n_env_shape * num_envs, &M.env_shape_frame)) ||
-        (rc = upload(S, d->env_shape_param, (size_t)4 * d->n_env_shape * num_envs, &M.env_shape_param)) ||
+        (rc = upload(S, has_es ? env_param_dev.data() : d->env_shape_param, (size_t)4 * d->n_env_shape * num_envs, &M.env_shape_param)) ||
         (rc = upload(S, d->env_shape_bound, (size_t)4 * d->n_env_shape * num_envs, &M.env_shape_bound)) ||
         (rc = upload(S, d->env_free_inertial, (size_t)10 * d->n_env_free * num_envs, &M.env_free_inertial))) {
       mssim_destroy(S);

@@ -624,6 +624,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             for (int k2 = 0; k2 < 6; k2++) { const float4 t = rp[k2]; r[4 * k2] = t.x; r[4 * k2 + 1] = t.y; r[4 * k2 + 2] = t.z; r[4 * k2 + 3] = t.w; }
             const int ty = __float_as_int(r[18]);
             const int slot = __float_as_int(r[21]);
+            int hull_first = M.shape_hull[2 * s], hull_count = M.shape_hull[2 * s + 1];
             if (slot < 0) {
               shF[k] = pose_t{f3{r[0], r[1], r[2]}, qnormalized(q4{r[3], r[4], r[5], r[6]})};
               shP[k][0] = r[7]; shP[k][1] = r[8]; shP[k][2] = r[9];
@@ -637,16 +638,19 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
               shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
               shBr[k] = bb[3 * (size_t)N];
-              // per-env shapes are primitives centred on their frame: box of the type's extents
+              // per-env primitives are centred on their frame: box of the type's extents; a per-env hull brings its own
+              // (rows 1..3 of its parameters, row 0 = first vertex | count << 17; mssim_create)
               shH[k] = ty == SH_BOX ? f3{shP[k][0], shP[k][1], shP[k][2]}
                      : ty == SH_SPHERE ? f3{shP[k][0], shP[k][0], shP[k][0]}
                      : ty == SH_CAPSULE ? f3{shP[k][1] + shP[k][0], shP[k][0], shP[k][0]}
+                     : ty == SH_CONVEX ? f3{shP[k][1], shP[k][2], pp[3 * (size_t)N]}
                      : f3{shP[k][1], shP[k][0], shP[k][0]};
+              if (ty == SH_CONVEX) { hull_first = __float_as_int(shP[k][0]) & 0x1FFFF; hull_count = __float_as_int(shP[k][0]) >> 17; }
             }
             shMu[k] = r[17];
             shTr[k] = r[22];
             shSlot[k] = pose_slot(__float_as_int(r[19]), __float_as_int(r[20]));
-            shPk[k] = (unsigned)ty | ((unsigned)M.shape_hull[2 * s + 1] << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)M.shape_hull[2 * s] << 15);
+            shPk[k] = (unsigned)ty | ((unsigned)hull_count << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)hull_first << 15);
           }
         }
       }
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       BT_T0;
       {
         int4 hd = int4{-1, 0, 0, 0};
-        if (live) hd = *reinterpret_cast<const int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN);
+        if (live && nml > 0) hd = *reinterpret_cast<const int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN);  // (an env without such pairs leaves its cache alone)
         const int4 hd0 = hd;
         unsigned char* const slot_of = reinterpret_cast<unsigned char*>(L + S16_NP_SLOT);
         const unsigned char* const ml = reinterpret_cast<const unsigned char*>(L + S16_NP_ML);

@@ -406,16 +406,31 @@ class SceneModelBuilder:
         hull_verts = []
         st, sk, si, srow, sframe, sparam, smat, shull, sbound = [], [], [], [], [], [], [], [], []
         shape_env_slot, env_frame, env_param, env_bound = [], [], [], []
+        env_hulls = {}  # id(vertex array) -> (first vertex, count): per-env hulls that share a mesh are stored once
+
+        def hull_of(rec):
+            v = np.asarray(rec.vertices, dtype=np.float64)
+            if len(v) > MAX_HULL_VERTS:
+                v = mesh.simplify_hull(v, MAX_HULL_VERTS)
+            return v
+
         for s in shapes:
             if s.get("env") is not None:
-                if s["rec"].type == "convex":
-                    raise NotImplementedError("per-env convex meshes are not supported (sizes / poses of primitive shapes only)")
                 fr, pr, bd = [], [], []
                 for r_e in s["env"]:
                     f_e = r_e.pose if s["world_pose"] is None else geom.compose(s["world_pose"], r_e.pose)
                     c_e, rad_e = r_e.bound()
                     fr.append(f_e)
-                    pr.append(r_e.param())
+                    if r_e.type == "convex":
+                        # a different hull per env (include/mssim.h env_shape_param): first vertex and vertex count
+                        key = id(r_e.vertices)
+                        if key not in env_hulls:
+                            v = hull_of(r_e)
+                            env_hulls[key] = (len(hull_verts), len(v))
+                            hull_verts.extend(v.tolist())
+                        pr.append([float(env_hulls[key][0]), float(env_hulls[key][1]), 0.0, 0.0])
+                    else:
+                        pr.append(r_e.param())
                     bd.append([*geom.transform_point(f_e, c_e), rad_e])
                 shape_env_slot.append(len(env_frame))
                 env_frame.append(np.asarray(fr, dtype=np.float64).T)  # [7, N]
@@ -434,11 +449,12 @@ class SceneModelBuilder:
             # `min_patch_radius`; the reference sets both (0.1, panda.py:24-31), where the minimum rules: the larger one
             smat.append([r.static_friction, r.dynamic_friction, r.restitution, max(r.patch_radius, r.min_patch_radius)])
             if r.type == "convex":
-                v = np.asarray(r.vertices, dtype=np.float64)
-                if len(v) > MAX_HULL_VERTS:
-                    v = mesh.simplify_hull(v, MAX_HULL_VERTS)
-                shull.append([len(hull_verts), len(v)])
-                hull_verts.extend(v.tolist())
+                if s.get("env") is not None:
+                    shull.append(list(env_hulls[id(s["env"][0].vertices)]))  # (env 0's hull; every env reads its own)
+                else:
+                    v = hull_of(r)
+                    shull.append([len(hull_verts), len(v)])
+                    hull_verts.extend(v.tolist())
             else:
                 shull.append([0, 0])
             c, rad = r.bound()

@@ -1,4 +1,4 @@
-"""Collision-mesh cooking on the host: binary/ASCII STL -> convex hull with a vertex budget.
+"""Collision-mesh cooking on the host: STL / OBJ / PLY vertices -> convex hull with a vertex budget.
 
 Counterpart of PhysX convex-mesh cooking that SAPIEN runs inside
 `add_convex_collision_from_file` (mani_skill/utils/building/actor_builder.py:113-131 calls
@@ -27,6 +27,65 @@ def load_stl_vertices(path: str) -> np.ndarray:
     rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
     arr = np.frombuffer(data[84 : 84 + 50 * n], dtype=rec)
     return np.unique(arr["v"].reshape(-1, 3).astype(np.float64), axis=0)
+
+
+def load_obj_vertices(path: str) -> np.ndarray:
+    verts = []
+    with open(path, "r", errors="ignore") as f:
+        for line in f:
+            if line.startswith("v "):
+                t = line.split()
+                verts.append([float(t[1]), float(t[2]), float(t[3])])
+    return np.unique(np.array(verts, dtype=np.float64).reshape(-1, 3), axis=0)
+
+
+def load_ply_vertices(path: str) -> np.ndarray:
+    """vertex positions of an ASCII or binary PLY file (the YCB `collision.ply` format): the x, y, z properties of the
+    `vertex` element, whatever else it carries"""
+    with open(path, "rb") as f:
+        data = f.read()
+    end = data.index(b"end_header") + len(b"end_header")
+    end = data.index(b"\n", end) + 1
+    header = data[:end].decode("ascii", errors="ignore").splitlines()
+    fmt = next(l.split()[1] for l in header if l.startswith("format"))
+    types = dict(char="i1", uchar="u1", short="i2", ushort="u2", int="i4", uint="u4", float="f4", double="f8",
+                 int8="i1", uint8="u1", int16="i2", uint16="u2", int32="i4", uint32="u4", float32="f4", float64="f8")
+    n_vert, props, in_vertex, before = 0, [], False, 0
+    for l in header:
+        t = l.split()
+        if not t:
+            continue
+        if t[0] == "element":
+            in_vertex = t[1] == "vertex"
+            if in_vertex:
+                n_vert = int(t[2])
+            elif not props:
+                before += 1  # (an element in front of the vertices: not produced by any exporter we know)
+        elif t[0] == "property" and in_vertex:
+            if t[1] == "list":
+                raise ValueError(f"{path}: list property inside the vertex element")
+            props.append((t[2], types[t[1]]))
+    if before:
+        raise ValueError(f"{path}: elements in front of the vertex element are not supported")
+    names = [p[0] for p in props]
+    if fmt == "ascii":
+        rows = np.array([[float(x) for x in l.split()] for l in data[end:].decode("ascii", errors="ignore").splitlines()[:n_vert]])
+        v = rows[:, [names.index("x"), names.index("y"), names.index("z")]]
+    else:
+        order = "<" if fmt == "binary_little_endian" else ">"
+        rec = np.dtype([(n_, order + t_) for n_, t_ in props])
+        arr = np.frombuffer(data[end : end + rec.itemsize * n_vert], dtype=rec)
+        v = np.stack([arr["x"], arr["y"], arr["z"]], axis=1)
+    return np.unique(np.asarray(v, dtype=np.float64), axis=0)
+
+
+def load_mesh_vertices(path: str) -> np.ndarray:
+    ext = str(path).lower().rsplit(".", 1)[-1]
+    if ext == "obj":
+        return load_obj_vertices(path)
+    if ext == "ply":
+        return load_ply_vertices(path)
+    return load_stl_vertices(path)
 
 
 def hull_volume_com_inertia(verts: np.ndarray):
@@ -91,7 +150,7 @@ def simplify_hull(verts: np.ndarray, max_verts: int) -> np.ndarray:
 
 @lru_cache(maxsize=64)
 def _cook_cached(path: str, scale: tuple, max_verts: int):
-    v = load_stl_vertices(path) * np.array(scale)
+    v = load_mesh_vertices(path) * np.array(scale)
     return simplify_hull(v, max_verts)
 
 

@@ -54,8 +54,9 @@ class ActorBuilder:
     def set_scene_idxs(self, scene_idxs=None):
         """Restrict the actor to some envs. A proper subset yields a *fragment* that must later be
         combined with `Actor.merge` into one actor present in every env with per-env geometry
-        (same shape types, different sizes / poses), as PegInsertionSide does
-        (peg_insertion_side.py:114-181). Objects that exist in only some envs are not supported."""
+        (same shape types in every env; sizes, local poses and -- for convex meshes -- the hull itself may differ: one
+        object model per sub-scene, as PegInsertionSide (peg_insertion_side.py:114-181) and the PickSingleYCB family
+        do). Objects that exist in only some envs are not supported."""
         self.scene_idxs = None if scene_idxs is None else [int(i) for i in scene_idxs]
         return self
 

@@ -206,6 +206,10 @@ Shape<Real> make_shape(const Model& M, const EnvState& E, int s, int e) {
   for (int k = 0; k < 4; k++) sh.param[k] = pr[k];
   sh.verts = M.hull_verts.data() + 3 * M.shape_hull[2 * s];
   sh.nverts = M.shape_hull[2 * s + 1];
+  if (slot >= 0 && sh.type == SH_CONVEX) {  // this env's own hull (include/mssim.h env_shape_param)
+    sh.verts = M.hull_verts.data() + 3 * (size_t)(int)pr[0];
+    sh.nverts = (int)pr[1];
+  }
   return sh;
 }
 
@@ -465,9 +469,20 @@ inline Vec shape_obb_half(const Model& M, int s, int e) {
     case MSSIM_SHAPE_CAPSULE: h = Vec(pr[1] + pr[0], pr[0], pr[0]); break;
     case MSSIM_SHAPE_CYLINDER: h = Vec(pr[1], pr[0], pr[0]); break;
     case MSSIM_SHAPE_CONVEX: {
-      const float* b = &M.shape_bound[4 * s];
-      for (int i = 0; i < M.shape_hull[2 * s + 1]; i++) {
-        const float* v = &M.hull_verts[3 * (size_t)(M.shape_hull[2 * s] + i)];
+      float b[3] = {M.shape_bound[4 * s], M.shape_bound[4 * s + 1], M.shape_bound[4 * s + 2]};
+      int first = M.shape_hull[2 * s], count = M.shape_hull[2 * s + 1];
+      if (slot >= 0) {
+        // this env's hull; its bound centre is stored in the BODY frame: back into the shape frame
+        first = (int)pr[0]; count = (int)pr[1];
+        float fr[7];
+        for (int k = 0; k < 7; k++) fr[k] = M.env_shape_frame[(size_t)(7 * slot + k) * M.N + e];
+        const Pose<Real> F = pose7(fr);
+        const Vec cb(M.env_shape_bound[(size_t)(4 * slot) * M.N + e], M.env_shape_bound[(size_t)(4 * slot + 1) * M.N + e], M.env_shape_bound[(size_t)(4 * slot + 2) * M.N + e]);
+        const Vec cs = qmat(F.q).tmul(cb - F.p);
+        b[0] = (float)cs.x; b[1] = (float)cs.y; b[2] = (float)cs.z;
+      }
+      for (int i = 0; i < count; i++) {
+        const float* v = &M.hull_verts[3 * (size_t)(first + i)];
         h.x = std::max(h.x, (Real)std::fabs(v[0] - b[0])); h.y = std::max(h.y, (Real)std::fabs(v[1] - b[1])); h.z = std::max(h.z, (Real)std::fabs(v[2] - b[2]));
       }
       break;

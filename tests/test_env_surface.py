@@ -71,6 +71,59 @@ def test_unmerged_fragment_is_rejected():
         Partial(num_envs=4, sim_backend=BACKEND)
 
 
+def test_per_env_object_set_from_mesh_files(tmp_path):
+    """the PickSingleYCB pattern (mani_skill/envs/tasks/tabletop/pick_single_ycb.py:110-140: one object model per sub-scene,
+    built with set_scene_idxs([i]) and merged with Actor.merge) on synthetic assets: four polyhedra written as OBJ files,
+    env i carries model i % 4 as a convex collision mesh. The merged actor is one batched body whose geometry, mass and
+    rest height differ per env."""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+
+    from maniskill_amd.envs.tasks.tabletop.pick_cube import PickCubeEnv
+    from maniskill_amd.utils.structs.actor import Actor
+    from maniskill_amd.utils.structs.pose import Pose
+
+    rng = np.random.default_rng(5)
+    files = []
+    for k in range(4):
+        pts = rng.normal(size=(30, 3))
+        pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * np.array([0.03 + 0.01 * k, 0.03, 0.02 + 0.005 * k])
+        hull = ConvexHull(pts)
+        f = tmp_path / f"model{k}.obj"
+        with open(f, "w") as fh:
+            for v in pts:
+                fh.write(f"v {v[0]} {v[1]} {v[2]}\n")
+            for t in hull.simplices:
+                fh.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+        files.append(str(f))
+
+    class ObjectSet(PickCubeEnv):
+        def _load_scene(self, options):
+            super()._load_scene(options)
+            frags = []
+            for i in range(self.num_envs):
+                b = self.scene.create_actor_builder()
+                b.add_convex_collision_from_file(files[i % 4], density=500)
+                b.initial_pose = Pose.create_from_pq([0.25, 0.2, 0.06])
+                b.set_scene_idxs([i])
+                frags.append(b.build(name=f"model-{i}"))
+            self.obj_set = Actor.merge(frags, name="object_set")
+            self.add_to_state_dict_registry(self.obj_set)
+
+    N = 8
+    env = ObjectSet(num_envs=N, sim_backend=BACKEND, obs_mode="state")
+    env.reset(seed=0)
+    assert env.obj_set.pose.raw_pose.shape == (N, 7)
+    mass = env.obj_set._mass_per_env
+    assert torch.allclose(mass[:4], mass[4:]) and len(set(np.round(mass[:4].numpy(), 5))) == 4
+    for _ in range(30):
+        env.step(torch.zeros(N, env.single_action_space.shape[0]))
+    z = env.obj_set.pose.p[:, 2].cpu().numpy()
+    assert np.all(z > 0.005) and np.all(z < 0.06)
+    assert np.allclose(z[:4], z[4:], atol=1e-6) and len(set(np.round(z[:4], 4))) >= 3  # per-env geometry, per-env rest height
+    assert env.scene.px.overflow_count() == 0
+
+
 def test_physx_module_config_flow():
     ec.check_physx_module_config(BACKEND)
 

@@ -459,3 +459,50 @@ def test_persistent_manifold_lets_a_hull_rest_without_rocking():
     assert s[0].item() > 0.03 and abs(s[2].item() - 0.02) < 1e-3
     q = s[3:7]
     assert float(2 * torch.acos(torch.clamp(q[0].abs(), max=1.0))) < np.deg2rad(3.0)
+
+
+def _per_env_hull_model(N, n_kinds=4, seed=0):
+    """synthetic object set (per-env object sets, no downloaded assets): `n_kinds` random convex polyhedra
+    (hulls of points on ellipsoids with different axes, 12-40 vertices), env i carries kind i % n_kinds"""
+    from scipy.spatial import ConvexHull
+
+    rng = np.random.default_rng(seed)
+    kinds = []
+    for k in range(n_kinds):
+        axes = np.array([0.03 + 0.02 * k, 0.025 + 0.01 * ((k * 3) % 4), 0.015 + 0.005 * k])
+        pts = rng.normal(size=(14 + 10 * k, 3))
+        pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * axes
+        verts = pts[ConvexHull(pts).vertices]
+        kinds.append(np.ascontiguousarray(verts))
+    env_shapes = [[ShapeRecord("convex", geom.pose(), vertices=kinds[i % n_kinds])] for i in range(N)]
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(ActorRecord("obj", "dynamic", list(env_shapes[0]), initial_pose=geom.pose([0, 0, 0.08]), env_shapes=env_shapes))
+    return b.compile(num_envs=N), kinds
+
+
+def test_per_env_hulls_each_env_simulates_its_own_object():
+    """a merged actor whose convex hull differs per env (the reference builds one object per sub-scene and merges the
+    views, utils/structs/actor.py:99-126; PickSingleYCB-style tasks): every env drops ITS polyhedron on the table. Envs
+    with the same hull behave identically, envs with different hulls come to rest at different heights, each with its lowest
+    vertices on the table top (z = 0)."""
+    N, K = 8, 4
+    model, kinds = _per_env_hull_model(N, K)
+    px = ob.make_system(model, N)
+    row = model.row_of("obj")
+    px.step(150)
+    px.gpu_fetch_all()
+    s = px.cuda_rigid_body_data.torch()[row * N : (row + 1) * N].double().numpy()
+    assert np.isfinite(s).all()
+    for i in range(K):
+        assert np.allclose(s[i], s[i + K], atol=1e-9), i  # same hull, same initial state: the same trajectory
+    z = s[:, 2]
+    assert len(set(np.round(z[:K], 4))) == K, z  # four different objects, four different rest heights
+    from maniskill_amd.utils.geometry.rotation_conversions import quaternion_to_matrix
+
+    R = quaternion_to_matrix(torch.from_numpy(s[:, 3:7])).numpy()
+    for i in range(N):
+        low = (kinds[i % K] @ R[i].T + s[i, :3])[:, 2].min()
+        assert abs(low) < 1e-3, (i, low)  # resting ON the table: the lowest vertex within a millimetre of its top
+    assert np.abs(s[:, 7:13]).max() < 0.05
