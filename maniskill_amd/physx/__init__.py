@@ -8,12 +8,14 @@ system creation) pushes the env's `SimConfig` through these setters and compiles
 `current_config()`, so code that calls the setters directly (as the reference's `BaseEnv` does) and code
 that passes a `SimConfig` reach the native core (`mssim_model_desc`, include/mssim.h) the same way.
 
-Parameters that have no counterpart in this core are accepted, stored and reported by
+Parameters that do not select anything in this core are accepted, stored and reported by
 `current_config()` but change nothing: the GPU memory capacities (all buffers are sized exactly from
 the compiled model), `enable_pcm` / `enable_tgs` / `enable_ccd` / `enable_friction_every_iteration` /
-`cpu_workers` (one solver: PGS with per-substep contact generation, friction every iteration) and
-`enable_enhanced_determinism` (envs never share a broadphase or an island, so every env is always
-simulated independently of the others).
+`cpu_workers` (persistent contact manifolds are always on; one solver: warm-started PGS, friction in
+every iteration, measured against a TGS-style variant in DESIGN.md section 2; no CCD) and
+`enable_enhanced_determinism` as far as the physics goes (envs never share a broadphase or an island,
+so every env is always simulated independently of the others; the env layer honours the flag with
+per-env random generators).
 """
 import copy
 from typing import Sequence

@@ -41,6 +41,21 @@ class TimeLimitWrapper(gym.Wrapper):
 
     def __init__(self, env, max_episode_steps: int):
         super().__init__(env)
+        # Under real gymnasium `gym.make(id, max_episode_steps=K)` has already wrapped the env in gymnasium's own
+        # TimeLimit (scalar `truncated`, K or the registered value) by the time the additional wrappers are applied. The
+        # reference takes K over and removes that wrapper (mani_skill/utils/registration.py:131-150, by looking into
+        # gym.make's frame); here the limit is read from the wrapper itself before it is spliced out of the chain.
+        tl_cls = getattr(getattr(gym, "wrappers", None), "TimeLimit", None)
+        if tl_cls is not None:
+            parent, cur = self, env
+            while cur is not None:
+                if isinstance(cur, tl_cls):
+                    inner_limit = getattr(cur, "_max_episode_steps", None)
+                    if inner_limit is not None:
+                        max_episode_steps = inner_limit
+                    parent.env = cur.env
+                    break
+                parent, cur = cur, getattr(cur, "env", None)
         self._max_episode_steps = max_episode_steps
         # tasks with a fused native epilogue evaluate the comparison below in that launch
         self.env.unwrapped._time_limit = max_episode_steps

@@ -146,3 +146,31 @@ def test_mani_skill_alias_imports():
     from maniskill_amd.envs.sapien_env import BaseEnv as B2
 
     assert BaseEnv is B2 and Panda.uid == "panda"
+
+
+def test_time_limit_wrapper_takes_over_gymnasiums_own(monkeypatch):
+    """real gymnasium wraps the env in its scalar TimeLimit before the registered additional wrappers run; the ManiSkill
+    wrapper must take that limit over (it carries `gym.make(..., max_episode_steps=K)`) and remove the wrapper, as the
+    reference does (utils/registration.py:131-150). gymnasium itself is absent here: its wrapper is stood in for."""
+    import types
+
+    import gymnasium as gym
+
+    from maniskill_amd.utils.registration import REGISTERED_ENVS, TimeLimitWrapper
+
+    class FakeTimeLimit(gym.Wrapper):
+        def __init__(self, env, max_episode_steps):
+            super().__init__(env)
+            self._max_episode_steps = max_episode_steps
+
+        def step(self, action):
+            raise AssertionError("gymnasium's own TimeLimit must not stay in the chain")
+
+    monkeypatch.setattr(gym, "wrappers", types.SimpleNamespace(TimeLimit=FakeTimeLimit), raising=False)
+    base = REGISTERED_ENVS["PickCube-v1"].make(num_envs=2, sim_backend=BACKEND, obs_mode="state")
+    env = TimeLimitWrapper(FakeTimeLimit(base, 7), 50)  # registered limit 50, the user asked for 7
+    assert env._max_episode_steps == 7 and env.env is base
+    env.reset(seed=0)
+    for i in range(7):
+        _, _, _, truncated, _ = env.step(torch.zeros(2, base.single_action_space.shape[0]))
+        assert bool(truncated.all()) == (i == 6)
