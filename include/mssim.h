@@ -81,7 +81,7 @@ extern "C" {
  * key in the NEXT substep (also across control steps); their impulses are applied to the velocities before the first
  * sweep. Points without a predecessor, torsional rows and joint-limit rows start from zero. With 15 + 1 Gauss-Seidel
  * sweeps a cold start does not converge on stiff loads -- the gripper's saturated 100 N squeeze leaves each pad 3.3 mm
- * inside the cube, a stack of two cubes creeps 1 mm/s -- the warm start does (0.02 mm, 6 um/s; scripts/tgs_vs_pgs.py).
+ * inside the cube, the upper of two stacked cubes creeps 1 mm in 2 s -- the warm start does (0.02 mm, 6 um; scripts/tgs_vs_pgs.py).
  * The cache is hidden state like the sleep counters and the manifolds: mssim_wake_all clears it. */
 /* The position sweeps of a substep end early once a whole sweep moves no velocity component (joint velocities, free-body
  * linear and angular velocities) by more than this (m/s or rad/s): the sweeps that would follow contract further, so
@@ -129,7 +129,8 @@ enum {
   MSSIM_SHAPE_SPHERE = 2,  /* param[0] = radius                                             */
   MSSIM_SHAPE_CAPSULE = 3, /* param[0] = radius, param[1] = half length, axis = +x of frame  */
   MSSIM_SHAPE_CYLINDER = 4,/* param[0] = radius, param[1] = half length, axis = +x of frame  */
-  MSSIM_SHAPE_CONVEX = 5   /* hull vertices in `hull_verts[hull_offset .. +hull_count)`      */
+  MSSIM_SHAPE_CONVEX = 5,  /* hull vertices in `hull_verts[hull_offset .. +hull_count)`      */
+  MSSIM_SHAPE_NONE = 6     /* per-env types only: the env has no shape in this slot         */
 };
 /* what a shape / body row is attached to */
 enum {
@@ -219,9 +220,14 @@ typedef struct mssim_model_desc {
   int32_t n_env_shape;
   const int32_t* shape_env_slot; /* [n_shape] slot into the env_shape_* arrays, -1 = shared       */
   const float* env_shape_frame;  /* [n_env_shape*7][N]                                            */
-  const float* env_shape_param;  /* [n_env_shape*4][N]; a MSSIM_SHAPE_CONVEX shape: {first vertex in hull_verts, vertex count
-                                    (<= MSSIM_MAX_HULL_VERTS), -, -} as float-valued integers -- a different hull per env
-                                    (the reference's per-env object sets, e.g. one YCB model per sub-scene)              */
+  const float* env_shape_param;  /* [n_env_shape*4][N]: rows 0..2 = the parameters of the env's shape (see MSSIM_SHAPE_*; a
+                                    convex shape: first vertex in hull_verts, vertex count <= MSSIM_MAX_HULL_VERTS, -, as
+                                    float-valued integers: a different hull per env), row 3 = the env's shape type + 1 as a
+                                    float-valued integer, 0 = shape_type[s]. Envs may carry different shape types in a slot
+                                    (never a plane) or none at all (MSSIM_SHAPE_NONE) -- the reference's per-env object sets:
+                                    one object model per sub-scene, merged into one actor (utils/structs/actor.py:99-126). A
+                                    free body whose mass (env_free_inertial row 0) is 0 in an env does not exist there: it
+                                    is never awake, keeps the pose it is given and takes part in nothing              */
   const float* env_shape_bound;  /* [n_env_shape*4][N] bounding-sphere centre in the BODY frame, radius */
   int32_t n_env_free;
   const int32_t* free_env_slot;  /* [n_free] slot into env_free_inertial, -1 = shared             */

@@ -17,7 +17,7 @@
 #pragma once
 #include "mssim_dev.h"
 
-enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5 };
+enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5, SH_NONE = 6 };
 
 struct shape_t {
   int type;  // wave-uniform

@@ -874,8 +874,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   S->h_pair_shape.assign(d->pair_shape, d->pair_shape + 2 * (size_t)d->n_pair);
   UP(shape_frame, 7 * ns) UP(shape_param, 4 * ns) UP(shape_material, 4 * ns) UP(shape_bound, 4 * ns)
 #undef UP
-  // device copy of env_shape_param: a convex shape's rows become {first vertex | count << 17 (bit pattern), half extents of
-  // its box for the cull (shape frame, centred at the bound centre)}
+  // device copy of env_shape_param (row format below)
   std::vector<float> env_param_dev;
   {
     // hull vertices are repacked so that every hull starts on a multiple of 8 vertices and is padded
@@ -901,35 +900,47 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       sh[2 * s2] = repacked(st, cnt);
     }
     if (d->n_env_shape > 0 && d->num_envs == num_envs) {
+      // device rows of every per-env shape: word 0 = type | vertex count << 3 | first vertex << 10 (bit pattern),
+      // rows 1..3 = the three parameters of a primitive, or the half extents of a hull's box for the cull
       const size_t NE = (size_t)num_envs;
       env_param_dev.assign(d->env_shape_param, d->env_shape_param + (size_t)4 * d->n_env_shape * NE);
       for (int s2 = 0; s2 < ns; s2++) {
         const int slot = d->shape_env_slot[s2];
-        if (slot < 0 || d->shape_type[s2] != MSSIM_SHAPE_CONVEX) continue;
+        if (slot < 0) continue;
         for (size_t e = 0; e < NE; e++) {
-          const int st = (int)d->env_shape_param[(size_t)(4 * slot) * NE + e], cnt = (int)d->env_shape_param[(size_t)(4 * slot + 1) * NE + e];
-          if (cnt < 1 || cnt > MSSIM_MAX_HULL_VERTS || st < 0 || st + cnt > d->n_hull_verts) { g_create_error = "per-env hull reference out of range"; mssim_destroy(S); return 8; }
-          const int found = repacked(st, cnt);
-          // bound centre (body frame) back into the shape frame, then the extents of the hull about it
-          float fr[7], cb[3];
-          for (int k = 0; k < 7; k++) fr[k] = d->env_shape_frame[(size_t)(7 * slot + k) * NE + e];
-          for (int k = 0; k < 3; k++) cb[k] = d->env_shape_bound[(size_t)(4 * slot + k) * NE + e] - fr[k];
-          const float nq = std::sqrt(fr[3] * fr[3] + fr[4] * fr[4] + fr[5] * fr[5] + fr[6] * fr[6]);
-          const float qw = fr[3] / nq, qx = fr[4] / nq, qy = fr[5] / nq, qz = fr[6] / nq;
-          const float R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)},
-                                 {2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)},
-                                 {2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
-          float cs[3], h[3] = {0.f, 0.f, 0.f};
-          for (int k = 0; k < 3; k++) cs[k] = R[0][k] * cb[0] + R[1][k] * cb[1] + R[2][k] * cb[2];
-          for (int i = 0; i < cnt; i++) {
-            const float* v = d->hull_verts + 3 * (size_t)(st + i);
-            for (int k = 0; k < 3; k++) h[k] = std::max(h[k], std::fabs(v[k] - cs[k]));
+          const float* src = d->env_shape_param;
+          const int tcode = (int)src[(size_t)(4 * slot + 3) * NE + e];
+          const int type = tcode > 0 ? tcode - 1 : d->shape_type[s2];
+          if (type < MSSIM_SHAPE_BOX || type > MSSIM_SHAPE_NONE) { g_create_error = "per-env shape type out of range (planes cannot be per-env shapes)"; mssim_destroy(S); return 8; }
+          int32_t word = type;
+          float rows[3] = {src[(size_t)(4 * slot) * NE + e], src[(size_t)(4 * slot + 1) * NE + e], src[(size_t)(4 * slot + 2) * NE + e]};
+          if (type == MSSIM_SHAPE_NONE) rows[0] = rows[1] = rows[2] = 0.f;
+          if (type == MSSIM_SHAPE_CONVEX) {
+            const int st = (int)rows[0], cnt = (int)rows[1];
+            if (cnt < 1 || cnt > MSSIM_MAX_HULL_VERTS || st < 0 || st + cnt > d->n_hull_verts) { g_create_error = "per-env hull reference out of range"; mssim_destroy(S); return 8; }
+            const int found = repacked(st, cnt);
+            // bound centre (body frame) back into the shape frame, then the extents of the hull about it
+            float fr[7], cb[3];
+            for (int k = 0; k < 7; k++) fr[k] = d->env_shape_frame[(size_t)(7 * slot + k) * NE + e];
+            for (int k = 0; k < 3; k++) cb[k] = d->env_shape_bound[(size_t)(4 * slot + k) * NE + e] - fr[k];
+            const float nq = std::sqrt(fr[3] * fr[3] + fr[4] * fr[4] + fr[5] * fr[5] + fr[6] * fr[6]);
+            const float qw = fr[3] / nq, qx = fr[4] / nq, qy = fr[5] / nq, qz = fr[6] / nq;
+            const float R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)},
+                                   {2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)},
+                                   {2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
+            float cs[3];
+            for (int k = 0; k < 3; k++) cs[k] = R[0][k] * cb[0] + R[1][k] * cb[1] + R[2][k] * cb[2];
+            rows[0] = rows[1] = rows[2] = 0.f;
+            for (int i = 0; i < cnt; i++) {
+              const float* v = d->hull_verts + 3 * (size_t)(st + i);
+              for (int k = 0; k < 3; k++) rows[k] = std::max(rows[k], std::fabs(v[k] - cs[k]));
+            }
+            word |= (cnt << 3) | (found << 10);
           }
-          const int32_t packed = found | (cnt << 17);
-          float pf;
-          std::memcpy(&pf, &packed, 4);
-          env_param_dev[(size_t)(4 * slot) * NE + e] = pf;
-          for (int k = 0; k < 3; k++) env_param_dev[(size_t)(4 * slot + 1 + k) * NE + e] = h[k];
+          float wf;
+          std::memcpy(&wf, &word, 4);
+          env_param_dev[(size_t)(4 * slot) * NE + e] = wf;
+          for (int k = 0; k < 3; k++) env_param_dev[(size_t)(4 * slot + 1 + k) * NE + e] = rows[k];
         }
       }
     }

@@ -575,6 +575,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       float in0[10];
       free_inertial_of(M, N, b, e, in0);
       fcalm[b] = norm_energy(in0, v, w, P.q) < M.sleep_threshold;
+      if (!(in0[0] > 0.f)) { fwake[b] = 0.f; fcalm[b] = true; }  // mass 0: the body does not exist in this env -- never awake
     }
   }
   // pose table: root, links, free bodies, kinematic bodies
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             const float4* rp = reinterpret_cast<const float4*>(M.shape_pack + 24 * s);
 #pragma unroll
             for (int k2 = 0; k2 < 6; k2++) { const float4 t = rp[k2]; r[4 * k2] = t.x; r[4 * k2 + 1] = t.y; r[4 * k2 + 2] = t.z; r[4 * k2 + 3] = t.w; }
-            const int ty = __float_as_int(r[18]);
+            int ty = __float_as_int(r[18]);
             const int slot = __float_as_int(r[21]);
             int hull_first = M.shape_hull[2 * s], hull_count = M.shape_hull[2 * s + 1];
             if (slot < 0) {
@@ -633,19 +634,21 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               shH[k] = f3{r[14], r[15], r[16]};
             } else {
               shF[k] = pose_soa(M.env_shape_frame, 7 * slot, N, e);
+              // device rows of a per-env shape (mssim_create): word 0 = type | vertex count << 3 | first vertex << 10,
+              // rows 1..3 = the parameters of a primitive / the half extents of a hull's box
               const float* pp = M.env_shape_param + (size_t)(4 * slot) * N + e;
-              shP[k][0] = pp[0]; shP[k][1] = pp[(size_t)N]; shP[k][2] = pp[2 * (size_t)N];
+              const int w0 = __float_as_int(pp[0]);
+              ty = w0 & 7;
+              shP[k][0] = pp[(size_t)N]; shP[k][1] = pp[2 * (size_t)N]; shP[k][2] = pp[3 * (size_t)N];
               const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
               shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
               shBr[k] = bb[3 * (size_t)N];
               // per-env primitives are centred on their frame: box of the type's extents; a per-env hull brings its own
-              // (rows 1..3 of its parameters, row 0 = first vertex | count << 17; mssim_create)
-              shH[k] = ty == SH_BOX ? f3{shP[k][0], shP[k][1], shP[k][2]}
+              shH[k] = (ty == SH_BOX || ty == SH_CONVEX) ? f3{shP[k][0], shP[k][1], shP[k][2]}
                      : ty == SH_SPHERE ? f3{shP[k][0], shP[k][0], shP[k][0]}
                      : ty == SH_CAPSULE ? f3{shP[k][1] + shP[k][0], shP[k][0], shP[k][0]}
-                     : ty == SH_CONVEX ? f3{shP[k][1], shP[k][2], pp[3 * (size_t)N]}
                      : f3{shP[k][1], shP[k][0], shP[k][0]};
-              if (ty == SH_CONVEX) { hull_first = __float_as_int(shP[k][0]) & 0x1FFFF; hull_count = __float_as_int(shP[k][0]) >> 17; }
+              hull_count = (w0 >> 3) & 127; hull_first = w0 >> 10;
             }
             shMu[k] = r[17];
             shTr[k] = r[22];
@@ -708,7 +711,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             const int b = s1 - 1 - S16_PT_FREE;
             return s1 == 0 || (b >= 0 && b < S16_MAX_FREE && (b == 0 ? fwake[0] : fwake[1]) <= 0.f);
           };
-          surv = !cull && !(inactive(s1a) && inactive(s1b));
+          const int tb = (int)(__float_as_uint(tb_[14]) & 7u);
+          surv = !cull && !(inactive(s1a) && inactive(s1b)) && ta != SH_NONE && tb != SH_NONE;  // (SH_NONE: no shape in this env's slot)
         }
         // survivors are compacted in place into the staged pair table (write index <= read index)
         WSYNC();  // all reads of this round before its writes

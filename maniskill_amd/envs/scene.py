@@ -166,11 +166,13 @@ class ManiSkillScene:
     # ------------------------------------------------------------------ setup / stepping
     def _setup(self, enable_gpu: bool = True):
         """px.gpu_init + initial apply/fetch (scene.py:897-939)"""
-        if self._fragments:
-            raise NotImplementedError(
-                f"actors {sorted(self._fragments)} exist in a subset of the envs and were never merged: per-env distinct "
-                "object sets are not supported by this core (only Actor.merge of one fragment per env)"
-            )
+        # actors built for a subset of the envs and never merged: each becomes a batched object over its own envs (the
+        # reference keeps such an actor as a view over its sub-scenes' entities, actor_builder.py:166-260)
+        for frag in list(self._fragments.values()):
+            own = Actor.merge([frag], name=frag.name)
+            frag.__dict__.update(own.__dict__)  # the object the builder returned IS the registered actor
+            self.actors[frag.name] = frag
+            self.add_to_state_dict_registry(frag)
         # the env's SimConfig goes through the module-level setters like the reference's _set_scene_config
         # (sapien_env.py:1066-1070); the model is compiled from the resulting process-wide defaults
         self._set_scene_config()

@@ -18,7 +18,7 @@ from .urdf import RobotDescription
 
 # enums mirrored from include/mssim.h
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
-SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_CONVEX = range(6)
+SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_CONVEX, SHAPE_NONE = range(7)
 BODY_WORLD, BODY_ART, BODY_FREE, BODY_KIN = range(4)
 MAX_DOF, MAX_FREE, MAX_HULL_VERTS = 16, 8, 64
 
@@ -29,6 +29,7 @@ _SHAPE_NAMES = {
     "capsule": SHAPE_CAPSULE,
     "cylinder": SHAPE_CYLINDER,
     "convex": SHAPE_CONVEX,
+    "none": SHAPE_NONE,  # per-env padding: this env has no shape in the slot (include/mssim.h MSSIM_SHAPE_NONE)
 }
 
 
@@ -36,7 +37,7 @@ _SHAPE_NAMES = {
 class ShapeRecord:
     """One collision shape in its owner's (actor / link) frame."""
 
-    type: str  # plane | box | sphere | capsule | cylinder | convex
+    type: str  # plane | box | sphere | capsule | cylinder | convex | none (no shape in this env's slot)
     pose: np.ndarray = field(default_factory=geom.pose)
     half_size: Optional[np.ndarray] = None  # box
     radius: float = 0.0
@@ -71,6 +72,8 @@ class ShapeRecord:
             return np.zeros(3), float(self.radius + self.half_length)
         if self.type == "cylinder":
             return np.zeros(3), float(np.hypot(self.radius, self.half_length))
+        if self.type == "none":
+            return np.zeros(3), 0.0
         return mesh.bounding_sphere(self.vertices)
 
     def mass_properties(self):
@@ -345,10 +348,12 @@ class SceneModelBuilder:
         for a in self.actors:
             if a.env_shapes is not None:
                 assert len(a.env_shapes) == num_envs, f"{a.name}: per-env shapes need one entry per env"
-                sig = [(s.type) for s in a.env_shapes[0]]
-                for es in a.env_shapes:
-                    assert [(s.type) for s in es] == sig, f"{a.name}: merged actors must have the same shape types in every env"
-                a.shapes = list(a.env_shapes[0])
+                # envs may carry different shape types and different numbers of shapes: every env's list is padded to
+                # the longest with "none" records; a slot's type in the shared tables is the first real one found
+                width = max(len(es) for es in a.env_shapes)
+                a.env_shapes = [list(es) + [ShapeRecord("none") for _ in range(width - len(es))] for es in a.env_shapes]
+                assert all(s.type != "plane" for es in a.env_shapes for s in es), f"{a.name}: planes cannot be per-env shapes"
+                a.shapes = [next((es[k] for es in a.env_shapes if es[k].type != "none"), a.env_shapes[0][k]) for k in range(width)]
             if a.body_type == "dynamic":
                 if a.mass is not None:
                     m, c, I = a.mass, np.zeros(3) if a.com is None else a.com, a.inertia
@@ -365,8 +370,11 @@ class SceneModelBuilder:
                 if a.env_shapes is not None and a.mass is None:
                     per = []
                     for es in a.env_shapes:
-                        items = [geom.transform_inertial(s.pose, *s.mass_properties()) for s in es]
-                        me, ce, Ie = geom.combine_inertials(items)
+                        items = [geom.transform_inertial(s.pose, *s.mass_properties()) for s in es if s.type != "none"]
+                        me, ce, Ie = geom.combine_inertials(items) if items else (0.0, np.zeros(3), np.eye(3))
+                        if me <= 0:
+                            # no shape in this env: the body does not exist there (mass 0 = never awake, include/mssim.h)
+                            me, ce, Ie = 0.0, np.zeros(3), np.eye(3)
                         per.append([me, *ce, *geom.inertia_mat_to_vec(Ie)])
                     free_env_slot.append(len(env_free_inertial))
                     env_free_inertial.append(np.asarray(per, dtype=np.float64).T)  # [10, N]
@@ -428,9 +436,9 @@ class SceneModelBuilder:
                             v = hull_of(r_e)
                             env_hulls[key] = (len(hull_verts), len(v))
                             hull_verts.extend(v.tolist())
-                        pr.append([float(env_hulls[key][0]), float(env_hulls[key][1]), 0.0, 0.0])
+                        pr.append([float(env_hulls[key][0]), float(env_hulls[key][1]), 0.0, float(SHAPE_CONVEX + 1)])
                     else:
-                        pr.append(r_e.param())
+                        pr.append([*r_e.param()[:3], float(_SHAPE_NAMES[r_e.type] + 1)])  # [3]: this env's shape type + 1
                     bd.append([*geom.transform_point(f_e, c_e), rad_e])
                 shape_env_slot.append(len(env_frame))
                 env_frame.append(np.asarray(fr, dtype=np.float64).T)  # [7, N]
@@ -450,7 +458,7 @@ class SceneModelBuilder:
             smat.append([r.static_friction, r.dynamic_friction, r.restitution, max(r.patch_radius, r.min_patch_radius)])
             if r.type == "convex":
                 if s.get("env") is not None:
-                    shull.append(list(env_hulls[id(s["env"][0].vertices)]))  # (env 0's hull; every env reads its own)
+                    shull.append(list(env_hulls[id(r.vertices)]))  # (the representative's hull; every env reads its own)
                 else:
                     v = hull_of(r)
                     shull.append([len(hull_verts), len(v)])

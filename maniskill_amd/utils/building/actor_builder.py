@@ -52,11 +52,11 @@ class ActorBuilder:
         return self
 
     def set_scene_idxs(self, scene_idxs=None):
-        """Restrict the actor to some envs. A proper subset yields a *fragment* that must later be
-        combined with `Actor.merge` into one actor present in every env with per-env geometry
-        (same shape types in every env; sizes, local poses and -- for convex meshes -- the hull itself may differ: one
-        object model per sub-scene, as PegInsertionSide (peg_insertion_side.py:114-181) and the PickSingleYCB family
-        do). Objects that exist in only some envs are not supported."""
+        """Restrict the actor to some envs. Built for a proper subset it is a *fragment*: either it is combined with
+        the fragments of other envs by `Actor.merge` into one actor with per-env geometry (shape types, sizes, local
+        poses, hulls and shape counts may all differ: one object model per sub-scene, as PegInsertionSide
+        (peg_insertion_side.py:114-181) and the PickSingleYCB family do), or it stays what it is: an object that exists
+        in those envs only, a batched object over them (getters and setters have one row per such env)."""
         self.scene_idxs = None if scene_idxs is None else [int(i) for i in scene_idxs]
         return self
 

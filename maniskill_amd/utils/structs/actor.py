@@ -22,6 +22,10 @@ class _RigidBase:
     name: str
     scene = None
     _body_row: Optional[int] = None
+    # envs the object exists in (ascending), None = all of them. An object built for a subset of the sub-scenes
+    # (`set_scene_idxs`, the reference's per-env object sets) is a batched object over THOSE envs: its getters return
+    # `len(_own_idx)` rows and its setters take as many (structs/base.py:103-110, actor.py:378-380)
+    _own_idx: Optional[torch.Tensor] = None
 
     @property
     def device(self):
@@ -33,33 +37,52 @@ class _RigidBase:
 
     @property
     def _num_objs(self):
-        return self.scene.num_envs
+        return self.scene.num_envs if self._own_idx is None else len(self._own_idx)
 
     @property
     def _scene_idxs(self):
-        return self.scene._all_env_idx
+        return self.scene._all_env_idx if self._own_idx is None else self._own_idx.to(self.device)
 
     @property
     def _body_data_index(self) -> torch.Tensor:
         """row indices into `px.cuda_rigid_body_data` (structs/base.py:103-110)"""
         N = self.scene.num_envs
-        return torch.arange(self._body_row * N, (self._body_row + 1) * N, device=self.device)
+        return self._body_row * N + self._scene_idxs
 
     @property
     def _body_data(self) -> torch.Tensor:
         return self.px.cuda_rigid_body_data.torch()
 
     def _rows(self) -> torch.Tensor:
+        """the object's rows: a zero-copy view when it exists in every env, a gathered copy for a subset (write through
+        `_write_rows`)"""
         N = self.scene.num_envs
-        return self._body_data[self._body_row * N : (self._body_row + 1) * N]
+        if self._own_idx is None:
+            return self._body_data[self._body_row * N : (self._body_row + 1) * N]
+        return self._body_data[self._body_data_index]
+
+    def _write_rows(self, cols: slice, value):
+        """all of the object's rows, whatever the reset mask says"""
+        if self._own_idx is None:
+            self._rows()[:, cols] = value
+        else:
+            self._body_data[self._body_data_index, cols] = value
 
     def _masked_write(self, cols: slice, value):
         value = common.to_tensor(value, device=self.device)
-        rows = self._rows()
-        if self.scene._reset_mask_all:
-            rows[:, cols] = value
-        else:
-            rows[self.scene._reset_idx, cols] = value  # (index list, not the boolean mask: no host sync)
+        if self._own_idx is None:
+            rows = self._rows()
+            if self.scene._reset_mask_all:
+                rows[:, cols] = value
+            else:
+                rows[self.scene._reset_idx, cols] = value  # (index list, not the boolean mask: no host sync)
+            return
+        # subset object: its rows among the envs being reset, in ascending env order (the reference's
+        # `_reset_mask[self._scene_idxs]`); `value` has one row per selected object (or broadcasts)
+        idx = self._body_data_index
+        if not self.scene._reset_mask_all:
+            idx = idx[self.scene._reset_mask[self._scene_idxs]]
+        self._body_data[idx, cols] = value
 
     # velocities -------------------------------------------------------------
     @property
@@ -110,13 +133,14 @@ class Actor(_RigidBase):
         self._body_row = None
         self.merged = False
         self._fragment = None
+        self._own_idx = None
 
     @classmethod
     def merge(cls, actors: List["Actor"], name: str = None) -> "Actor":
-        """Combine per-env fragments (built with `set_scene_idxs([i])`) into one actor that exists
-        in every env with per-env geometry. Counterpart of the reference's merged views
-        (utils/structs/actor.py:99-126), restricted to the case this core supports: every env gets
-        exactly one fragment and all fragments have the same shape types."""
+        """Combine per-env fragments (built with `set_scene_idxs([...])`) into one batched actor with per-env geometry.
+        Counterpart of the reference's merged views (utils/structs/actor.py:99-126): the fragments may differ in shape
+        types and shape counts; envs that no fragment covers do not contain the object (the merged actor is then a batched
+        object over the covered envs only). An env may carry at most one of the fragments."""
         from maniskill_amd.model import geom
         from maniskill_amd.model.compile import ActorRecord
 
@@ -128,20 +152,25 @@ class Actor(_RigidBase):
             for i in a._fragment["scene_idxs"]:
                 assert i not in by_env, f"env {i} has more than one fragment"
                 by_env[i] = a
-        assert sorted(by_env) == list(range(N)), "Actor.merge needs exactly one fragment per env (objects present in only some envs are not supported)"
-        first = by_env[0]
-        assert all(by_env[i].px_body_type == first.px_body_type for i in range(N))
+        covered = sorted(by_env)
+        first = by_env[covered[0]]
+        assert all(by_env[i].px_body_type == first.px_body_type for i in covered)
+        assert first.px_body_type == "dynamic" or covered == list(range(N)), "only dynamic objects may exist in a subset of the envs"
         name = name if name is not None else first.name
-        raw = torch.cat([by_env[i].initial_pose.raw_pose[:1] for i in range(N)], dim=0)
+        # (an env without the object still has the body's row: it keeps this pose, has mass 0 there and takes part in nothing)
+        raw = torch.cat([by_env.get(i, first).initial_pose.raw_pose[:1] for i in range(N)], dim=0)
         p0 = common.to_numpy(raw[0])
         rec = ActorRecord(
             name, first.px_body_type, list(first._fragment["shapes"]), initial_pose=geom.pose(p0[:3], p0[3:]),
             linear_damping=first._fragment["linear_damping"], angular_damping=first._fragment["angular_damping"],
-            env_shapes=[list(by_env[i]._fragment["shapes"]) for i in range(N)],
+            env_shapes=[list(by_env[i]._fragment["shapes"]) if i in by_env else [] for i in range(N)],
         )
-        masses = [sum(s.mass_properties()[0] for s in by_env[i]._fragment["shapes"]) for i in range(N)]
+        masses = [sum(s.mass_properties()[0] for s in by_env[i]._fragment["shapes"]) for i in covered]
         merged = cls(scene, name, first.px_body_type, Pose.create(raw), has_collision_shapes=first.has_collision_shapes, mass=0.0)
         merged._mass_per_env = torch.tensor(masses, dtype=torch.float32)
+        if covered != list(range(N)):
+            merged._own_idx = torch.tensor(covered, dtype=torch.long, device=scene.device)
+            merged.initial_pose = Pose.create(raw[merged._own_idx.to(raw.device)])
         merged.merged = True
         for a in actors:
             scene._fragments.pop(a.name, None)
@@ -171,7 +200,7 @@ class Actor(_RigidBase):
         if self.hidden:
             return
         self.before_hide_pose = self._rows()[:, :7].clone()
-        self._rows()[:, :3] = self.before_hide_pose[:, :3] + 99999
+        self._write_rows(slice(0, 3), self.before_hide_pose[:, :3] + 99999)
         self.scene._gpu_apply_all()
         self.scene._gpu_fetch_all()
         self.hidden = True
@@ -181,7 +210,7 @@ class Actor(_RigidBase):
         if not self.hidden:
             return
         self.hidden = False
-        self._rows()[:, :7] = self.before_hide_pose
+        self._write_rows(slice(0, 7), self.before_hide_pose)
         self.scene._gpu_apply_all()
         self.scene._gpu_fetch_all()
 
@@ -201,15 +230,21 @@ class Actor(_RigidBase):
         """force for the next simulation step only (actor.py:305-316)"""
         force = common.to_tensor(force, device=self.device)
         N = self.scene.num_envs
-        buf = self.px.cuda_rigid_body_force.torch()[self._body_row * N : (self._body_row + 1) * N]
-        buf[self.scene._reset_idx, :3] = force
+        if self._own_idx is None:
+            buf = self.px.cuda_rigid_body_force.torch()[self._body_row * N : (self._body_row + 1) * N]
+            buf[self.scene._reset_idx, :3] = force
+        else:
+            idx = self._body_data_index
+            if not self.scene._reset_mask_all:
+                idx = idx[self.scene._reset_mask[self._scene_idxs]]
+            self.px.cuda_rigid_body_force.torch()[idx, :3] = force
         self.px.gpu_apply_rigid_dynamic_force()
 
     @property
     def mass(self):
         if getattr(self, "_mass_per_env", None) is not None:
             return self._mass_per_env.to(self.device)
-        return torch.full((self.scene.num_envs,), float(self._mass), device=self.device)
+        return torch.full((self._num_objs,), float(self._mass), device=self.device)
 
     def get_mass(self):
         return self.mass
@@ -237,8 +272,10 @@ class Actor(_RigidBase):
         if self.hidden:
             if self.scene._reset_mask_all:
                 self.before_hide_pose[:] = raw
-            else:
+            elif self._own_idx is None:
                 self.before_hide_pose[self.scene._reset_idx] = raw
+            else:
+                self.before_hide_pose[self.scene._reset_mask[self._scene_idxs]] = raw
             return
         self._masked_write(slice(0, 7), raw)
 

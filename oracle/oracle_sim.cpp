@@ -201,6 +201,7 @@ Shape<Real> make_shape(const Model& M, const EnvState& E, int s, int e) {
   for (int k = 0; k < 4; k++) pr[k] = slot < 0 ? M.shape_param[4 * s + k] : M.env_shape_param[(size_t)(4 * slot + k) * M.N + e];
   Pose<Real> W = pmul(body_world_pose(M, E, M.shape_kind[s], M.shape_index[s]), pose7(fr));
   sh.type = M.shape_type[s];
+  if (slot >= 0 && pr[3] > 0) sh.type = (int)pr[3] - 1;  // this env's own shape type (include/mssim.h env_shape_param)
   sh.c = W.p;
   sh.rot = qmat(W.q);
   for (int k = 0; k < 4; k++) sh.param[k] = pr[k];
@@ -463,7 +464,8 @@ inline Vec shape_obb_half(const Model& M, int s, int e) {
   float pr[4];
   for (int k = 0; k < 4; k++) pr[k] = slot < 0 ? M.shape_param[4 * s + k] : M.env_shape_param[(size_t)(4 * slot + k) * M.N + e];
   Vec h;
-  switch (M.shape_type[s]) {
+  const int type = (slot >= 0 && pr[3] > 0) ? (int)pr[3] - 1 : M.shape_type[s];
+  switch (type) {
     case MSSIM_SHAPE_BOX: h = Vec(pr[0], pr[1], pr[2]); break;
     case MSSIM_SHAPE_SPHERE: h = Vec(pr[0], pr[0], pr[0]); break;
     case MSSIM_SHAPE_CAPSULE: h = Vec(pr[1] + pr[0], pr[0], pr[0]); break;
@@ -489,7 +491,7 @@ inline Vec shape_obb_half(const Model& M, int s, int e) {
     }
     default: h = Vec(3e30, 3e30, 3e30);
   }
-  if (slot < 0 && M.shape_type[s] != MSSIM_SHAPE_CONVEX && M.shape_type[s] != MSSIM_SHAPE_PLANE) {
+  if (slot < 0 && type != MSSIM_SHAPE_CONVEX && type != MSSIM_SHAPE_PLANE) {
     // primitives are centred on their frame; the box stays valid if the bound centre is offset
     h.x += std::fabs(M.shape_bound[4 * s]); h.y += std::fabs(M.shape_bound[4 * s + 1]); h.z += std::fabs(M.shape_bound[4 * s + 2]);
   }
@@ -537,6 +539,7 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
         return M.shape_kind[s] == MSSIM_BODY_WORLD || (M.shape_kind[s] == MSSIM_BODY_FREE && E.free_wake[M.shape_index[s]] <= 0);
       };
       if (inactive(sa) && inactive(sb)) continue;
+      if (A.type == MSSIM_SHAPE_NONE || B.type == MSSIM_SHAPE_NONE) continue;  // no shape in this env's slot
     }
     // bounding-sphere cull
     Real ra, rb;
@@ -709,7 +712,14 @@ void substep(mssim_sim* S, EnvState& E, int e) {
     return Real(0.5) * (dot(v, v) + dot(w, Iw * w) / in[0]);
   };
   E.free_calm.assign(nf, 0);
-  for (int b = 0; b < nf; b++) E.free_calm[b] = normalised_energy(b, E.free_v[b], E.free_w[b]) < M.sleep_threshold;
+  for (int b = 0; b < nf; b++) {
+    if (!(finert[10 * b] > 0)) {  // mass 0: the body does not exist in this env (include/mssim.h env_shape_param) -- never awake
+      E.free_wake[b] = 0; E.free_v[b] = Vec(); E.free_w[b] = Vec();
+      E.free_calm[b] = 1;
+      continue;
+    }
+    E.free_calm[b] = normalised_energy(b, E.free_v[b], E.free_w[b]) < M.sleep_threshold;
+  }
   // 2. narrowphase
   std::vector<Contact> contacts;
   narrowphase(M, E, e, contacts);

@@ -54,21 +54,46 @@ def test_peg_insertion_per_env_geometry():
     ec.check_peg_insertion(BACKEND, "cpu")
 
 
-def test_unmerged_fragment_is_rejected():
-    """objects that exist in only some envs are not supported: the scene must say so, not mis-simulate"""
-    import gymnasium as gym
+def test_object_that_exists_in_some_envs_only():
+    """an actor built for a subset of the sub-scenes and not merged (set_scene_idxs, actor_builder.py:166-260) is a batched
+    object over ITS envs: getters return one row per such env, setters take as many, partial resets address the object's
+    envs among the ones being reset; in the other envs the body does not exist -- nothing rests on it, it never moves"""
     from maniskill_amd.envs.tasks.tabletop.pick_cube import PickCubeEnv
+    from maniskill_amd.utils.structs.pose import Pose
 
     class Partial(PickCubeEnv):
         def _load_scene(self, options):
             super()._load_scene(options)
             b = self.scene.create_actor_builder()
-            b.add_box_collision(half_size=[0.02] * 3)
-            b.set_scene_idxs([0])
-            b.build("only_in_env0")
+            b.add_box_collision(half_size=[0.02, 0.02, 0.03])
+            b.initial_pose = Pose.create_from_pq([0.2, 0.25, 0.05])
+            b.set_scene_idxs([0, 2])
+            self.extra = b.build("only_in_envs_0_and_2")
 
-    with pytest.raises(NotImplementedError):
-        Partial(num_envs=4, sim_backend=BACKEND)
+    N = 4
+    env = Partial(num_envs=N, sim_backend=BACKEND, obs_mode="state")
+    env.reset(seed=0)
+    extra = env.extra
+    assert extra._num_objs == 2 and extra.pose.raw_pose.shape == (2, 7) and extra.linear_velocity.shape == (2, 3)
+    assert extra.mass.shape == (2,) and torch.allclose(extra.mass, torch.full((2,), 1000 * 8 * 0.02 * 0.02 * 0.03))
+    zero = torch.zeros(N, env.single_action_space.shape[0])
+    for _ in range(30):
+        env.step(zero)
+    assert torch.allclose(extra.pose.p[:, 2], torch.full((2,), 0.03), atol=5e-4)  # dropped from 0.05, resting on its 0.03 half height
+    # the body's rows in the envs without it: where they were put, at rest
+    rows = env.scene.px.cuda_rigid_body_data.torch()[extra._body_row * N : (extra._body_row + 1) * N]
+    assert torch.allclose(rows[[1, 3], :3].cpu(), torch.tensor([[0.2, 0.25, 0.05]] * 2)) and float(rows[[1, 3], 7:].abs().max()) == 0.0
+    # setters address the object's own envs; a partial reset of env 2 (and of env 1, where it does not exist) moves one row
+    extra.set_pose(Pose.create_from_pq(torch.tensor([[0.3, 0.2, 0.1], [0.3, -0.2, 0.1]])))
+    assert torch.allclose(extra.pose.p[:, 1], torch.tensor([0.2, -0.2]))
+    with env.scene._narrow_reset_mask(torch.tensor([1, 2])):
+        extra.set_pose(Pose.create_from_pq(torch.tensor([[0.0, 0.3, 0.2]])))
+    assert torch.allclose(extra.pose.p, torch.tensor([[0.3, 0.2, 0.1], [0.0, 0.3, 0.2]]))
+    state = env.get_state_dict()
+    assert state["actors"]["only_in_envs_0_and_2"].shape == (2, 13)
+    env.step(zero)
+    env.set_state_dict(state)
+    assert torch.allclose(extra.pose.p, torch.tensor([[0.3, 0.2, 0.1], [0.0, 0.3, 0.2]]))
 
 
 def test_per_env_object_set_from_mesh_files(tmp_path):

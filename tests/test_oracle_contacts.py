@@ -506,3 +506,54 @@ def test_per_env_hulls_each_env_simulates_its_own_object():
         low = (kinds[i % K] @ R[i].T + s[i, :3])[:, 2].min()
         assert abs(low) < 1e-3, (i, low)  # resting ON the table: the lowest vertex within a millimetre of its top
     assert np.abs(s[:, 7:13]).max() < 0.05
+
+
+def _mixed_object_model(N):
+    """per-env object sets with different shape types and counts (Actor.merge over heterogeneous sub-scenes,
+    utils/structs/actor.py:99-126): env i carries kind i % 5 -- a box, a sphere, a hull, a compound of two boxes, nothing"""
+    from scipy.spatial import ConvexHull
+
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(24, 3))
+    pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * np.array([0.04, 0.03, 0.025])
+    hull = np.ascontiguousarray(pts[ConvexHull(pts).vertices])
+    kinds = [
+        [ShapeRecord("box", geom.pose(), half_size=np.array([0.03, 0.02, 0.02]))],
+        [ShapeRecord("sphere", geom.pose(), radius=0.03)],
+        [ShapeRecord("convex", geom.pose(), vertices=hull)],
+        [ShapeRecord("box", geom.pose([0, 0, 0]), half_size=np.array([0.04, 0.01, 0.01])),
+         ShapeRecord("box", geom.pose([0, 0, 0.02]), half_size=np.array([0.01, 0.01, 0.01]))],
+        [],
+    ]
+    env_shapes = [list(kinds[i % 5]) for i in range(N)]
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(ActorRecord("obj", "dynamic", list(env_shapes[0]), initial_pose=geom.pose([0, 0, 0.08]), env_shapes=env_shapes))
+    return b.compile(num_envs=N), hull
+
+
+def test_per_env_object_sets_with_different_shape_types():
+    """every env simulates the object IT carries: a box rests at its half height, a sphere at its radius, the hull on its
+    lowest vertices, the two-box compound on its long box; in the envs that carry nothing the body does not exist (mass 0):
+    it keeps the pose it was given, is never awake and touches nothing"""
+    N = 10
+    model, hull = _mixed_object_model(N)
+    px = ob.make_system(model, N)
+    row = model.row_of("obj")
+    px.step(200)
+    px.gpu_fetch_all()
+    s = px.cuda_rigid_body_data.torch()[row * N : (row + 1) * N].double().numpy()
+    assert np.isfinite(s).all()
+    for i in range(5):
+        assert np.allclose(s[i], s[i + 5], atol=1e-9), i
+    assert abs(s[0, 2] - 0.02) < 2e-4, s[0]          # box: half height
+    assert abs(s[1, 2] - 0.03) < 2e-4, s[1]          # sphere: radius
+    from maniskill_amd.utils.geometry.rotation_conversions import quaternion_to_matrix
+
+    R = quaternion_to_matrix(torch.from_numpy(s[2:3, 3:7])).numpy()[0]
+    assert abs((hull @ R.T + s[2, :3])[:, 2].min()) < 1e-3  # hull: lowest vertices on the table
+    assert abs(s[3, 2] - 0.01) < 1e-3 or s[3, 2] < 0.045    # compound: lying on the long box (possibly tipped over)
+    assert np.allclose(s[4, :3], [0, 0, 0.08]) and np.allclose(s[4, 7:], 0)  # nothing there: the body stays where it was put
+    assert px.read_internal("free_wake", 1).reshape(-1)[4] <= 0
+    assert px.overflow_count() == 0
