@@ -39,6 +39,47 @@ def load_obj_vertices(path: str) -> np.ndarray:
     return np.unique(np.array(verts, dtype=np.float64).reshape(-1, 3), axis=0)
 
 
+def load_obj_parts(path: str):
+    """the convex parts of a decomposition file (V-HACD / CoACD style OBJ: one `o` / `g` group per part): list of vertex
+    arrays, each the vertices its group's faces use (all of the group's `v` lines when it has no faces)"""
+    verts, parts, cur = [], [], None
+    with open(path, "r", errors="ignore") as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                verts.append([float(t[1]), float(t[2]), float(t[3])])
+                if cur is not None:
+                    cur["own"].append(len(verts) - 1)
+            elif t[0] in ("o", "g"):
+                cur = dict(own=[], used=set())
+                parts.append(cur)
+            elif t[0] == "f":
+                if cur is None:
+                    cur = dict(own=[], used=set())
+                    parts.append(cur)
+                for w in t[1:]:
+                    i = int(w.split("/")[0])
+                    cur["used"].add(i - 1 if i > 0 else len(verts) + i)
+    V = np.array(verts, dtype=np.float64).reshape(-1, 3)
+    out = []
+    for part in parts:
+        idx = sorted(part["used"]) if part["used"] else part["own"]
+        if len(idx) >= 4:
+            out.append(np.unique(V[idx], axis=0))
+    return out if out else [np.unique(V, axis=0)]
+
+
+def cook_convex_parts(path: str, scale=(1.0, 1.0, 1.0), max_verts: int = 64):
+    """one cooked hull per convex part of the file (`add_multiple_convex_collisions_from_file`)"""
+    if str(path).lower().endswith(".obj"):
+        parts = load_obj_parts(path)
+    else:
+        parts = [load_mesh_vertices(path)]
+    return [simplify_hull(v * np.array(scale), max_verts) for v in parts]
+
+
 def load_ply_vertices(path: str) -> np.ndarray:
     """vertex positions of an ASCII or binary PLY file (the YCB `collision.ply` format): the x, y, z properties of the
     `vertex` element, whatever else it carries"""

@@ -181,7 +181,9 @@ class PhysxCollisionShapeConvexMesh(PhysxCollisionShape):
 
     @staticmethod
     def load_multiple(filename, scale=(1.0, 1.0, 1.0), material=None):
-        raise NotImplementedError("multi-convex collision (convex decomposition files) is not available in this build (SURVEY.md 8f rank 4)")
+        """one convex shape per part of a convex-decomposition file (sapien: PhysxCollisionShapeConvexMesh.load_multiple,
+        used by actor_builder.py:121-135): OBJ files with one `o` / `g` group per part"""
+        return [PhysxCollisionShapeConvexMesh(filename, scale, material, vertices=v) for v in mesh.cook_convex_parts(str(filename), tuple(float(x) for x in scale))]
 
 
 class PhysxCollisionShapeTriangleMesh(PhysxCollisionShape):

@@ -123,8 +123,11 @@ class ActorBuilder:
             comp.attach(shape)
         return comp
 
-    def add_multiple_convex_collisions_from_file(self, *a, **kw):
-        raise NotImplementedError("convex decomposition is not available in this build (SURVEY.md 8f rank 4)")
+    def add_multiple_convex_collisions_from_file(self, filename, pose=None, scale=(1, 1, 1), material=None, density=1000, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        """every convex part of a decomposition file becomes a shape of the body (actor_builder.py:121-135)"""
+        for shape in pxc.PhysxCollisionShapeConvexMesh.load_multiple(filename, scale, self._mat(material)):
+            self._attach(shape, pose, density, patch_radius, min_patch_radius)
+        return self
 
     def add_nonconvex_collision_from_file(self, *a, **kw):
         raise NotImplementedError("triangle-mesh collision is not available in this build (SURVEY.md 8f rank 4)")

@@ -1,6 +1,6 @@
-"""Batched rigid actors and articulation links as views over `px.cuda_rigid_body_data`.
+"""Batched rigid actors as views over `px.cuda_rigid_body_data`.
 
-API counterpart of mani_skill/utils/structs/{base,actor,link}.py. The reference keeps one
+API counterpart of mani_skill/utils/structs/actor.py (shared row logic: structs/base.py, links: structs/link.py). The reference keeps one
 `sapien.Entity` per sub-scene and gathers rows by `_body_data_index`; here one record describes
 the body in all envs and its rows are one contiguous slice (body-major rows), so getters are
 zero-copy views. Setters keep the reference's partial-reset contract: only rows selected by
@@ -14,108 +14,7 @@ import torch
 
 from maniskill_amd.utils import common
 from maniskill_amd.utils.structs.pose import Pose, vectorize_pose
-
-
-class _RigidBase:
-    """state shared by Actor and Link"""
-
-    name: str
-    scene = None
-    _body_row: Optional[int] = None
-    # envs the object exists in (ascending), None = all of them. An object built for a subset of the sub-scenes
-    # (`set_scene_idxs`, the reference's per-env object sets) is a batched object over THOSE envs: its getters return
-    # `len(_own_idx)` rows and its setters take as many (structs/base.py:103-110, actor.py:378-380)
-    _own_idx: Optional[torch.Tensor] = None
-
-    @property
-    def device(self):
-        return self.scene.device
-
-    @property
-    def px(self):
-        return self.scene.px
-
-    @property
-    def _num_objs(self):
-        return self.scene.num_envs if self._own_idx is None else len(self._own_idx)
-
-    @property
-    def _scene_idxs(self):
-        return self.scene._all_env_idx if self._own_idx is None else self._own_idx.to(self.device)
-
-    @property
-    def _body_data_index(self) -> torch.Tensor:
-        """row indices into `px.cuda_rigid_body_data` (structs/base.py:103-110)"""
-        N = self.scene.num_envs
-        return self._body_row * N + self._scene_idxs
-
-    @property
-    def _body_data(self) -> torch.Tensor:
-        return self.px.cuda_rigid_body_data.torch()
-
-    def _rows(self) -> torch.Tensor:
-        """the object's rows: a zero-copy view when it exists in every env, a gathered copy for a subset (write through
-        `_write_rows`)"""
-        N = self.scene.num_envs
-        if self._own_idx is None:
-            return self._body_data[self._body_row * N : (self._body_row + 1) * N]
-        return self._body_data[self._body_data_index]
-
-    def _write_rows(self, cols: slice, value):
-        """all of the object's rows, whatever the reset mask says"""
-        if self._own_idx is None:
-            self._rows()[:, cols] = value
-        else:
-            self._body_data[self._body_data_index, cols] = value
-
-    def _masked_write(self, cols: slice, value):
-        value = common.to_tensor(value, device=self.device)
-        if self._own_idx is None:
-            rows = self._rows()
-            if self.scene._reset_mask_all:
-                rows[:, cols] = value
-            else:
-                rows[self.scene._reset_idx, cols] = value  # (index list, not the boolean mask: no host sync)
-            return
-        # subset object: its rows among the envs being reset, in ascending env order (the reference's
-        # `_reset_mask[self._scene_idxs]`); `value` has one row per selected object (or broadcasts)
-        idx = self._body_data_index
-        if not self.scene._reset_mask_all:
-            idx = idx[self.scene._reset_mask[self._scene_idxs]]
-        self._body_data[idx, cols] = value
-
-    # velocities -------------------------------------------------------------
-    @property
-    def linear_velocity(self) -> torch.Tensor:
-        return self._rows()[:, 7:10]
-
-    @property
-    def angular_velocity(self) -> torch.Tensor:
-        return self._rows()[:, 10:13]
-
-    def get_linear_velocity(self):
-        return self.linear_velocity
-
-    def get_angular_velocity(self):
-        return self.angular_velocity
-
-    def get_pose(self) -> Pose:
-        return self.pose
-
-    # contact forces -----------------------------------------------------------
-    def get_net_contact_impulses(self):
-        q = self.scene._body_query(self._body_row)
-        self.px.gpu_query_contact_body_impulses(q)
-        return q.cuda_impulses.torch().clone()
-
-    def get_net_contact_forces(self):
-        return self.get_net_contact_impulses() / self.scene.timestep
-
-    def __hash__(self):
-        return hash((type(self).__name__, self.name, id(self.scene)))
-
-    def __repr__(self):
-        return f"<{type(self).__name__} {self.name}>"
+from maniskill_amd.utils.structs.base import _RigidBase
 
 
 class Actor(_RigidBase):
@@ -297,68 +196,4 @@ class Actor(_RigidBase):
         self.set_angular_velocity(v)
 
 
-class Link(_RigidBase):
-    """articulation link (link.py:27-340)"""
-
-    def __init__(self, scene, articulation, name: str, index: int, joint=None):
-        self.scene = scene
-        self.articulation = articulation
-        self.name = name
-        self.index_int = index
-        self._body_row = index
-        self.joint = joint
-        self.merged = False
-        self.disable_gravity_flag = False
-
-    @property
-    def index(self) -> torch.Tensor:
-        return torch.full((self.scene.num_envs,), self.index_int, dtype=torch.int, device=self.device)
-
-    @property
-    def is_root(self) -> torch.Tensor:
-        return torch.full((self.scene.num_envs,), self.index_int == 0, dtype=torch.bool, device=self.device)
-
-    def get_index(self):
-        return self.index
-
-    def get_joint(self):
-        return self.joint
-
-    def get_articulation(self):
-        return self.articulation
-
-    def get_name(self):
-        return self.name
-
-    @property
-    def disable_gravity(self):
-        return torch.full((self.scene.num_envs,), self.disable_gravity_flag, dtype=torch.bool, device=self.device)
-
-    @disable_gravity.setter
-    def disable_gravity(self, v: bool):
-        if self.scene._gpu_sim_initialized:
-            raise AssertionError("disable_gravity cannot be changed after gpu_init (structs/decorators.py:1-13)")
-        self.disable_gravity_flag = bool(v)
-        self.articulation._record.link_gravity[self.name] = not bool(v)
-
-    def set_collision_group_bit(self, group: int, bit_idx: int, bit):
-        self.articulation._set_link_collision_group_bit(self.name, group, bit_idx, bit)
-
-    def set_collision_group(self, group: int, value):
-        self.articulation._set_link_collision_group(self.name, group, value)
-
-    @property
-    def pose(self) -> Pose:
-        return Pose.create(self._rows()[:, :7])
-
-    @pose.setter
-    def pose(self, arg1) -> None:
-        """only meaningful for the root link (articulation root pose, link.py:239-269)"""
-        raw = vectorize_pose(arg1, device=self.device)
-        if not self.scene._gpu_sim_initialized:
-            self.articulation.initial_pose = Pose.create(raw)
-            return
-        self._masked_write(slice(0, 7), raw)
-
-    def set_pose(self, arg1) -> None:
-        self.pose = arg1
+from maniskill_amd.utils.structs.link import Link  # noqa: E402,F401  (historic import path)

@@ -56,3 +56,39 @@ def test_cooked_hull_respects_the_vertex_budget(tmp_path):
     vol, com, I = mesh.hull_volume_com_inertia(hull)
     full = 4 / 3 * np.pi * 0.1 * 0.03 * 0.02
     assert 0.85 * full < vol < full and np.linalg.norm(com) < 2e-3 and np.all(np.linalg.eigvalsh(I) > 0)
+
+
+def test_convex_decomposition_file_gives_one_hull_per_part(tmp_path):
+    """`add_multiple_convex_collisions_from_file` (actor_builder.py:121-135): an L-shaped bracket written as two boxes in one
+    OBJ (one `o` group per part, the layout V-HACD / CoACD write) becomes two convex shapes whose union has the bracket's
+    mass -- one hull over all vertices would fill the notch"""
+    import itertools
+
+    from maniskill_amd.model.compile import ShapeRecord
+
+    def box(lo, hi):
+        return np.array(list(itertools.product(*zip(lo, hi))), dtype=np.float64)
+
+    parts = [box((0, 0, 0), (0.1, 0.02, 0.02)), box((0, 0, 0.02), (0.02, 0.02, 0.1))]
+    faces = [(0, 1, 3), (0, 3, 2), (4, 5, 7), (4, 7, 6), (0, 1, 5), (0, 5, 4), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 3, 7), (1, 7, 5)]
+    f = tmp_path / "bracket.obj"
+    with open(f, "w") as fh:
+        base = 0
+        for k, v in enumerate(parts):
+            fh.write(f"o part{k}\n")
+            for p in v:
+                fh.write(f"v {p[0]} {p[1]} {p[2]}\n")
+            for t in faces:
+                fh.write(f"f {t[0] + 1 + base} {t[1] + 1 + base} {t[2] + 1 + base}\n")
+            base += len(v)
+    hulls = mesh.cook_convex_parts(str(f))
+    assert len(hulls) == 2 and all(len(h) == 8 for h in hulls)
+    vol = sum(ShapeRecord("convex", vertices=h, density=1.0).mass_properties()[0] for h in hulls)
+    assert abs(vol - (0.1 * 0.02 * 0.02 + 0.02 * 0.02 * 0.08)) < 1e-9
+    one = mesh.cook_convex_mesh(str(f))
+    assert ShapeRecord("convex", vertices=one, density=1.0).mass_properties()[0] > 1.5 * vol
+
+    from maniskill_amd.physx.components import PhysxCollisionShapeConvexMesh
+
+    shapes = PhysxCollisionShapeConvexMesh.load_multiple(str(f), scale=(2, 2, 2))
+    assert len(shapes) == 2 and abs(shapes[0].vertices[:, 0].max() - 0.2) < 1e-12

@@ -113,8 +113,6 @@ def test_unsupported_shapes_say_so():
 
     with pytest.raises(NotImplementedError):
         physx.PhysxCollisionShapeTriangleMesh("x.obj")
-    with pytest.raises(NotImplementedError):
-        physx.PhysxCollisionShapeConvexMesh.load_multiple("x.obj")
     c = physx.PhysxRigidDynamicComponent()
     with pytest.raises(NotImplementedError):
         c.set_locked_motion_axes([True, False, False, False, False, False])
