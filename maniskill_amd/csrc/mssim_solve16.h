@@ -113,6 +113,7 @@ __device__ unsigned g_phase_blk[2048 * 32];  // per-block deltas of the most rec
 #define PH_ADD(i, v) ph_d[i] += (unsigned)(v)
 #define BT_ADD(i, v)
 #define BT_T0
+#define BT_T0b
 #define BT_T(i)
 #define PH_FLUSH                                                                  \
   if ((threadIdx.x & 63) == 0) {  /* one record per wave */                        \
@@ -136,6 +137,7 @@ __device__ unsigned g_phase_blk[2048 * 32];
 #define PH_ADD(i, v) ph_d[i] += (unsigned)(v)
 #define BT_ADD(i, v) ph_d[i] += (unsigned)(v)  // (slots that are cycle counts in the phase-clock build)
 #define BT_T0 unsigned bt_t_ = (unsigned)clock64()
+#define BT_T0b bt_t_ = (unsigned)clock64()
 #define BT_T(i) do { __builtin_amdgcn_s_waitcnt(0); ph_d[i] += (unsigned)clock64() - bt_t_; bt_t_ = (unsigned)clock64(); } while (0)
 #define PH_FLUSH                                                                   \
   if ((threadIdx.x & 63) == 0 && blockIdx.x * S16_WAVES + (threadIdx.x >> 6) < 2048) {  /* one record per wave */ \
@@ -153,6 +155,7 @@ __device__ unsigned g_phase_blk[2048 * 32];
 #define PH_ADD(i, v)
 #define BT_ADD(i, v)
 #define BT_T0
+#define BT_T0b
 #define BT_T(i)
 #define PH_FLUSH
 #endif
@@ -280,6 +283,13 @@ MS_DEV float gmax16(float x) {
   x = fmaxf(x, dpp_f<0x124>(x));
   x = fmaxf(x, dpp_f<0x122>(x));
   x = fmaxf(x, dpp_f<0x121>(x));
+  return x;
+}
+MS_DEV int gmin16i(int x) {
+  x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false));
+  x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false));
+  x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x122, 0xF, 0xF, false));
+  x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x121, 0xF, 0xF, false));
   return x;
 }
 // Box-box manifold by the 16 lanes of a group (same result as collide_box_box, which spends ~3400
@@ -602,6 +612,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     const bool last = sub == n_sub - 1;
     // ================================================================ contacts -> LDS records
     pcm_tick++;
+    BT_T0;
     int nc = 0;
     unsigned fdist = 0u;  // free bodies touched by a disturber in this substep (sleep counters)
     if (FUSED) {
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       // B0: every env's own group assigns cache slots to its pairs, in pair order (same pair -> its slot; else the
       // first empty slot; else the least recently used one not touched in this substep; else none: plain query).
       // Lane k holds the header word of slot k.
-      BT_T0;
+      BT_T0b;
       {
         int4 hd = int4{-1, 0, 0, 0};
         if (live && nml > 0) hd = *reinterpret_cast<const int4*>(S.pcm + ((size_t)e * MSSIM_PCM_SLOTS + c) * S16_PCM_LEN);  // (an env without such pairs leaves its cache alone)
@@ -1193,6 +1204,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       if (__any(pool_over) && pool_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_RAW);  // (recorded for the group's own env: a reported condition either way)
       WSYNC();
       PH(24);
+      BT_T0b;
       // ---- contact patches (include/mssim.h, MSSIM_PATCH_COS): manifolds of one body pair with normals inside a
       // cone of the first of them are one patch, cut to its 4 most significant points. Lane c looks after the
       // manifolds c, c + 16, ..: (1) body-pair key, (2) anchor = first manifold of the same key within the cone,
@@ -1244,6 +1256,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           }
           WSYNC();
         }
+        BT_T(8);
         bool any_big = false;
         for (int i = c; i < nh; i += 16) {
           int anchor = i;
@@ -1258,6 +1271,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           keep_[i] = (anchor << 4) | ((1 << ci) - 1);
         }
         WSYNC();
+        BT_T(25);
+        // pass 1, the anchor's lane: size of its patch and whether it carries a torsional record
         for (int a = c; a < nh; a += 16) {
           if ((keep_[a] >> 4) != a || cnt_[a] == 0) continue;
           int total = 0, tflag = 0;
@@ -1266,64 +1281,181 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             total += mem ? cnt_[i] : 0;
             tflag |= (mem && cnt_[i] > 0) ? (key_[i] >> 16) & 1 : 0;
           }
-          key_[a] |= tflag << 17;  // bit 17 (anchors): the patch carries a torsional friction record
-          if (total <= 4) continue;
-          any_big = true;
-          const f3 na = f3{L[S16_NP_HN + 3 * a], L[S16_NP_HN + 3 * a + 1], L[S16_NP_HN + 3 * a + 2]};
-          // point id = manifold * 4 + point; "first candidate wins" in (manifold, point) order, as the oracle
-          auto scan = [&](auto&& f) __attribute__((always_inline)) {
-            for (int i = a; i < nh; i++) {
-              if ((keep_[i] >> 4) != a) continue;
-              const int cn = cnt_[i], of = off_[i];
-              for (int q = 0; q < cn; q++) f(4 * i + q, *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (of + q)));
+          // bit 17 (anchors): the patch carries a torsional friction record; bit 18: more than 4 points, to be cut
+          key_[a] |= (tflag << 17) | (total > 4 ? 1 << 18 : 0);
+          any_big = any_big || total > 4;
+        }
+        WSYNC();
+        // pass 2, the whole group on one patch at a time: its candidate points in (manifold, point) order are spread over
+        // the lanes (position p in lane p % 16), every scan of the selection rule is a group reduction -- the extremum,
+        // then the lowest position within the tie tolerance of it ("first candidate wins", as the oracle's sequential scans)
+        if (__any(any_big)) {
+          unsigned short* const cl = reinterpret_cast<unsigned short*>(L + S16_NP_ML);  // (the stage B / C lists are dead) candidate: id | pool index << 8
+          auto b16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
+          for (int a = 0; a < nh; a++) {  // (group-uniform)
+            if (!((key_[a] >> 18) & 1)) continue;
+            const f3 na = f3{L[S16_NP_HN + 3 * a], L[S16_NP_HN + 3 * a + 1], L[S16_NP_HN + 3 * a + 2]};
+            int n = 0;
+            for (int base = a; base < nh; base += 16) {
+              const int i = base + c;
+              const bool mem = i < nh && (keep_[i] >> 4) == a && cnt_[i] > 0;
+              const int ni = mem ? cnt_[i] : 0;
+              const unsigned b0 = b16(ni & 1), b1 = b16(ni & 2), b2 = b16(ni & 4), lt = (1u << c) - 1u;
+              const int pre = n + __popc(b0 & lt) + 2 * __popc(b1 & lt) + 4 * __popc(b2 & lt);
+              if (mem) {
+                const int of = off_[i];
+                for (int q = 0; q < ni; q++)
+                  if (pre + q < 64) cl[pre + q] = (unsigned short)((4 * i + q) | ((of + q) << 8));
+              }
+              n += __popc(b0) + 2 * __popc(b1) + 4 * __popc(b2);
             }
-          };
-          // every scan: the extremum, then the first candidate within the tie tolerance of it (include/mssim.h)
-          int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
-          float best = 3e38f;
-          f3 p0 = f3{0, 0, 0}, p1 = f3{0, 0, 0};
-          scan([&](int, float4 P) { best = fminf(best, P.w); });
-          scan([&](int id, float4 P) { if (i0 < 0 && P.w <= best + MSSIM_PATCH_TIE_SEP) { i0 = id; p0 = f3{P.x, P.y, P.z}; } });
-          best = -1.f;
-          scan([&](int id, float4 P) {
-            const f3 d = f3{P.x, P.y, P.z} - p0;
-            if (id != i0) best = fmaxf(best, dot(d, d));
-          });
-          scan([&](int id, float4 P) {
-            const f3 d = f3{P.x, P.y, P.z} - p0;
-            if (i1 < 0 && id != i0 && dot(d, d) >= best - MSSIM_PATCH_TIE_REL * best) { i1 = id; p1 = f3{P.x, P.y, P.z}; }
-          });
-          const f3 ed = p1 - p0;
-          best = -1.f;
-          scan([&](int id, float4 P) {
-            if (id != i0 && id != i1) best = fmaxf(best, fabsf(dot(cross(ed, f3{P.x, P.y, P.z} - p0), na)));
-          });
-          float sgn2 = 0.f;
-          scan([&](int id, float4 P) {
-            const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
-            if (i2 < 0 && id != i0 && id != i1 && fabsf(ar) >= best - MSSIM_PATCH_TIE_REL * best) { i2 = id; sgn2 = ar; }
-          });
-          best = 0.f;
-          scan([&](int id, float4 P) {
-            const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
-            if (id != i0 && id != i1 && id != i2) best = fmaxf(best, sgn2 >= 0.f ? -ar : ar);
-          });
-          if (best > 0.f)
-            scan([&](int id, float4 P) {
-              const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
-              const float v = sgn2 >= 0.f ? -ar : ar;
-              if (i3 < 0 && id != i0 && id != i1 && id != i2 && v >= best - MSSIM_PATCH_TIE_REL * best) i3 = id;
-            });
-          for (int i = a; i < nh; i++) {
-            if ((keep_[i] >> 4) != a) continue;
-            int mk = 0;
-            if ((i0 >> 2) == i) mk |= 1 << (i0 & 3);
-            if ((i1 >> 2) == i) mk |= 1 << (i1 & 3);
-            if ((i2 >> 2) == i) mk |= 1 << (i2 & 3);
-            if (i3 >= 0 && (i3 >> 2) == i) mk |= 1 << (i3 & 3);
-            keep_[i] = (a << 4) | mk;
+            WSYNC();
+            int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+            if (n <= 64) {
+              float4 P[4];
+              bool has[4];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                has[k] = c + 16 * k < n;
+                const int w = has[k] ? cl[c + 16 * k] : 0;
+                P[k] = *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (w >> 8));
+              }
+              auto point_at = [&](int pos) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (cl[pos] >> 8)); };
+              // first position whose value passes `ok` (lowest over the group), -1 if none
+              auto first_pos = [&](const bool (&ok)[4]) __attribute__((always_inline)) {
+                int p = 1 << 20;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) p = ok[k] ? c + 16 * k : p;
+                p = gmin16i(p);
+                return p == (1 << 20) ? -1 : p;
+              };
+              float v[4];
+              bool ok[4];
+              // deepest point
+              float best = 3e38f;
+#pragma unroll
+              for (int k = 0; k < 4; k++) best = fminf(best, has[k] ? P[k].w : 3e38f);
+              best = -gmax16(-best);
+#pragma unroll
+              for (int k = 0; k < 4; k++) ok[k] = has[k] && P[k].w <= best + MSSIM_PATCH_TIE_SEP;
+              const int q0 = first_pos(ok);
+              const float4 P0 = point_at(q0);
+              const f3 p0 = f3{P0.x, P0.y, P0.z};
+              // farthest from it
+              best = -1.f;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const f3 d = f3{P[k].x, P[k].y, P[k].z} - p0;
+                v[k] = dot(d, d);
+                has[k] = has[k] && c + 16 * k != q0;
+                best = fmaxf(best, has[k] ? v[k] : -1.f);
+              }
+              best = gmax16(best);
+#pragma unroll
+              for (int k = 0; k < 4; k++) ok[k] = has[k] && v[k] >= best - MSSIM_PATCH_TIE_REL * best;
+              const int q1 = first_pos(ok);
+              const float4 P1 = point_at(q1);
+              const f3 ed = f3{P1.x, P1.y, P1.z} - p0;
+              // largest area on either side of that edge
+              best = -1.f;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                v[k] = dot(cross(ed, f3{P[k].x, P[k].y, P[k].z} - p0), na);
+                has[k] = has[k] && c + 16 * k != q1;
+                best = fmaxf(best, has[k] ? fabsf(v[k]) : -1.f);
+              }
+              best = gmax16(best);
+#pragma unroll
+              for (int k = 0; k < 4; k++) ok[k] = has[k] && fabsf(v[k]) >= best - MSSIM_PATCH_TIE_REL * best;
+              const int q2 = first_pos(ok);
+              const float4 P2 = point_at(q2);
+              const float sgn2 = dot(cross(ed, f3{P2.x, P2.y, P2.z} - p0), na);
+              best = 0.f;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                v[k] = sgn2 >= 0.f ? -v[k] : v[k];
+                has[k] = has[k] && c + 16 * k != q2;
+                best = fmaxf(best, has[k] ? v[k] : 0.f);
+              }
+              best = gmax16(best);
+              int q3 = -1;
+              if (best > 0.f) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) ok[k] = has[k] && v[k] >= best - MSSIM_PATCH_TIE_REL * best;
+                q3 = first_pos(ok);
+              }
+              i0 = cl[q0] & 255; i1 = cl[q1] & 255; i2 = cl[q2] & 255; i3 = q3 >= 0 ? (cl[q3] & 255) : -1;
+              for (int i = a + c; i < nh; i += 16) {
+                if ((keep_[i] >> 4) != a) continue;
+                int mk = 0;
+                if ((i0 >> 2) == i) mk |= 1 << (i0 & 3);
+                if ((i1 >> 2) == i) mk |= 1 << (i1 & 3);
+                if ((i2 >> 2) == i) mk |= 1 << (i2 & 3);
+                if (i3 >= 0 && (i3 >> 2) == i) mk |= 1 << (i3 & 3);
+                keep_[i] = (a << 4) | mk;
+              }
+            } else if (c == 0) {
+              // more than 64 candidates in one patch (a heap of bodies on one another): the sequential scans, one lane
+          const f3 na = f3{L[S16_NP_HN + 3 * a], L[S16_NP_HN + 3 * a + 1], L[S16_NP_HN + 3 * a + 2]};
+              // point id = manifold * 4 + point; "first candidate wins" in (manifold, point) order, as the oracle
+              auto scan = [&](auto&& f) __attribute__((always_inline)) {
+                for (int i = a; i < nh; i++) {
+                  if ((keep_[i] >> 4) != a) continue;
+                  const int cn = cnt_[i], of = off_[i];
+                  for (int q = 0; q < cn; q++) f(4 * i + q, *reinterpret_cast<const float4*>(L + S16_NP_POOL + 4 * (of + q)));
+                }
+              };
+              // every scan: the extremum, then the first candidate within the tie tolerance of it (include/mssim.h)
+              int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+              float best = 3e38f;
+              f3 p0 = f3{0, 0, 0}, p1 = f3{0, 0, 0};
+              scan([&](int, float4 P) { best = fminf(best, P.w); });
+              scan([&](int id, float4 P) { if (i0 < 0 && P.w <= best + MSSIM_PATCH_TIE_SEP) { i0 = id; p0 = f3{P.x, P.y, P.z}; } });
+              best = -1.f;
+              scan([&](int id, float4 P) {
+                const f3 d = f3{P.x, P.y, P.z} - p0;
+                if (id != i0) best = fmaxf(best, dot(d, d));
+              });
+              scan([&](int id, float4 P) {
+                const f3 d = f3{P.x, P.y, P.z} - p0;
+                if (i1 < 0 && id != i0 && dot(d, d) >= best - MSSIM_PATCH_TIE_REL * best) { i1 = id; p1 = f3{P.x, P.y, P.z}; }
+              });
+              const f3 ed = p1 - p0;
+              best = -1.f;
+              scan([&](int id, float4 P) {
+                if (id != i0 && id != i1) best = fmaxf(best, fabsf(dot(cross(ed, f3{P.x, P.y, P.z} - p0), na)));
+              });
+              float sgn2 = 0.f;
+              scan([&](int id, float4 P) {
+                const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
+                if (i2 < 0 && id != i0 && id != i1 && fabsf(ar) >= best - MSSIM_PATCH_TIE_REL * best) { i2 = id; sgn2 = ar; }
+              });
+              best = 0.f;
+              scan([&](int id, float4 P) {
+                const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
+                if (id != i0 && id != i1 && id != i2) best = fmaxf(best, sgn2 >= 0.f ? -ar : ar);
+              });
+              if (best > 0.f)
+                scan([&](int id, float4 P) {
+                  const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
+                  const float v = sgn2 >= 0.f ? -ar : ar;
+                  if (i3 < 0 && id != i0 && id != i1 && id != i2 && v >= best - MSSIM_PATCH_TIE_REL * best) i3 = id;
+                });
+              for (int i = a; i < nh; i++) {
+                if ((keep_[i] >> 4) != a) continue;
+                int mk = 0;
+                if ((i0 >> 2) == i) mk |= 1 << (i0 & 3);
+                if ((i1 >> 2) == i) mk |= 1 << (i1 & 3);
+                if ((i2 >> 2) == i) mk |= 1 << (i2 & 3);
+                if (i3 >= 0 && (i3 >> 2) == i) mk |= 1 << (i3 & 3);
+                keep_[i] = (a << 4) | mk;
+              }
+
+            }
+            WSYNC();
           }
         }
+        BT_T(23);
         PH_ADD(9, __any(any_big) ? 1 : 0);
         WSYNC();
         // records in solver order: patch by patch (patches in the order of their anchors), inside a patch manifold by
@@ -1331,34 +1463,58 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         // torsional friction record if one of its shapes carries a patch radius (one solver block each,
         // include/mssim.h shape_material). The lane of manifold i writes its points, the lane of an anchor the
         // torsional record of its patch.
+        // slot layout, the whole group on one patch at a time (patches in anchor order): a member manifold's points start at
+        // the running count plus the points of the members in front of it (prefix over the lanes by ballots), the patch's
+        // torsional record follows its points. Lane c keeps the results of its manifolds c, c + 16, c + 32, c + 48.
+        int offs[4] = {0, 0, 0, 0}, offe[4] = {0, 0, 0, 0};
+        float trr[4] = {-1.f, -1.f, -1.f, -1.f};  // (anchors) torsional radius of the patch, < 0: no torsional record
         int tot = 0;
-        for (int i = c; i < nh; i += 16) {
+        {
+          auto b16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
+          for (int a = 0; a < nh; a++) {  // (group-uniform)
+            if ((keep_[a] >> 4) != a || cnt_[a] == 0) continue;
+            const bool tpatch = (key_[a] >> 17) & 1;
+            float tr = 0.f;
+            for (int base = a & ~15; base < nh; base += 16) {
+              const int i = base + c;
+              const int wi = i < nh ? keep_[i] : 0;
+              const bool mem = i >= a && i < nh && (wi >> 4) == a;
+              const int ni = mem ? __popc(wi & 15) : 0;
+              const unsigned b0 = b16(ni & 1), b1 = b16(ni & 2), b2 = b16(ni & 4), lt = (1u << c) - 1u;
+              const int pre = tot + __popc(b0 & lt) + 2 * __popc(b1 & lt) + 4 * __popc(b2 & lt);
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (mem && (base >> 4) == k) offs[k] = pre;
+              tot += __popc(b0) + 2 * __popc(b1) + 4 * __popc(b2);
+              if (tpatch) {
+                float t = 0.f;
+                if (mem && cnt_[i] > 0 && ((key_[i] >> 16) & 1)) {
+                  const int pkj = hit_[i];
+                  t = fmaxf(L[S16_NP_SHP + S16_SHP * ((pkj >> 16) & 0xFF) + 19], L[S16_NP_SHP + S16_SHP * ((pkj >> 24) & 0xFF) + 19]);
+                }
+                tr = fmaxf(tr, gmax16(t));
+              }
+            }
+            if (tpatch) {
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (c + 16 * k == a) { offe[k] = tot; trr[k] = tr; }
+              tot++;
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = c + 16 * k;
+          if (i >= nh) continue;
           const int wi = keep_[i];
           const int mk = wi & 15, a = wi >> 4;
           const bool is_anchor = a == i && cnt_[i] > 0;
-          tot += __popc(mk);
           if (mk == 0 && !is_anchor) continue;
-          // slots before this manifold's points | before the end of its patch; patch-level torsion flags of the earlier patches
-          int off = 0, off_end = 0;
-          bool my_tors = false;
-          float my_tr = 0.f;
-          for (int j = 0; j < nh; j++) {
-            const int wj = keep_[j];
-            const int aj = wj >> 4, nj = __popc(wj & 15);
-            if (aj < a || (aj == a && j < i)) off += nj;
-            if (aj <= a) off_end += nj;
-            if (is_anchor && aj == a && cnt_[j] > 0 && ((key_[j] >> 16) & 1)) {
-              const int pkj = hit_[j];
-              my_tors = true;
-              my_tr = fmaxf(my_tr, fmaxf(L[S16_NP_SHP + S16_SHP * ((pkj >> 16) & 0xFF) + 19], L[S16_NP_SHP + S16_SHP * ((pkj >> 24) & 0xFF) + 19]));
-            }
-          }
-          // torsional records of the patches in front (bit 17 of their anchors' keys)
-          int tors_before = 0;
-          for (int a2 = 0; a2 < a; a2++) tors_before += (key_[a2] >> 17) & 1;
-          off += tors_before;
-          off_end += tors_before;
-          if (is_anchor && my_tors) tot += 1;
+          int off = offs[k];
+          const int off_end = offe[k];
+          const bool my_tors = is_anchor && trr[k] >= 0.f;
+          const float my_tr = trr[k];
           const int pk = hit_[i];
           const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
           const float mu = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
@@ -1380,7 +1536,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             }
             off++;
           }
-          if (is_anchor && my_tors && off_end < MAXC) {
+          if (my_tors && off_end < MAXC) {
             float* r = L + S16_REC + S16_REC_LEN * off_end;
             r[0] = nn.x; r[1] = nn.y; r[2] = nn.z;
             r[3] = 0.f; r[4] = 0.f; r[5] = 0.f; r[6] = 0.f;
@@ -1389,7 +1545,6 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             r[9] = mu * my_tr;
           }
         }
-        tot += __shfl_xor(tot, 8, 16); tot += __shfl_xor(tot, 4, 16); tot += __shfl_xor(tot, 2, 16); tot += __shfl_xor(tot, 1, 16);
         if (tot > MAXC) { if (live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONTACTS); tot = MAXC; }
         nc = tot;
       }
@@ -1401,6 +1556,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       for (int k = 0; k < 3; k++)
         if (c + 16 * k < nold) oldp[k] = S.hit_list[(size_t)(1 + c + 16 * k) * N + e];
     }
+    BT_T(24);
     PH(21);
 
     // ================================================================ per-env constants of this lane

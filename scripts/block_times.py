@@ -60,6 +60,9 @@ for rep in range(3):
     print("  their stage B cycles: slot assignment | slot load | refresh + setup | MPR query | merge | store (last round: + wait)")
     for b in order[:12]:
         print("    " + " ".join(f"{a[b, k]:8d}" for k in (17, 18, 19, 20, 21, 22)))
+    print("  their patch-pass cycles: keys + sleeping | anchor search | 4-point selection | records")
+    for b in order[:12]:
+        print("    " + " ".join(f"{a[b, k]:8d}" for k in (8, 25, 23, 24)))
     print(f"  all blocks: uncached {a[:, 10].sum()} new slot {a[:, 11].sum()} moved {a[:, 12].sum()} empty asked again {a[:, 13].sum()} growth {a[:, 15].sum()} refresh only {a[:, 16].sum()}")
     c = np.corrcoef(dur, a[:, 29])[0, 1]
     print(f"  correlation duration ~ max-env contacts: {c:.2f}; mean duration by MPR rounds: " + ", ".join(f"{k}: {dur[a[:, 14] == k].mean():.0f} us (n={int((a[:, 14] == k).sum())})" for k in np.unique(a[:, 14])[:8]))
