@@ -497,6 +497,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
   constexpr bool FUSED = true;  // (the per-substep variant fed by a separate narrowphase kernel is gone)
   __shared__ __attribute__((aligned(16))) float sm[S16_WAVES * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   __shared__ int blk_nml[S16_WAVES * S16_ENVS_PER_BLOCK];  // generic-convex pairs of every env of the block (stage B task list)
+  __shared__ int blk_nbl[S16_WAVES * S16_ENVS_PER_BLOCK];  // its box-box pairs that go to 16-lane groups (stage C task list)
   const int N = S.N;
   constexpr int BLK_ENVS = S16_WAVES * S16_ENVS_PER_BLOCK;
   const int wv = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       if (T == 0) {  // (wave-uniform) no round ran: the pool counter is still to be cleared
         if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
       }
-      if (c == 0) blk_nml[gb] = nml;
+      if (c == 0) { blk_nml[gb] = nml; blk_nbl[gb] = bb_lane ? 0 : nbl; }
       BSYNC();  // every wave is done with its clip scratch: stage B may write manifolds into any env's staging tables
       PH(13);
       // ---- stage B: generic convex pairs through the persistent manifold cache (include/mssim.h MSSIM_PCM_*).
@@ -1168,17 +1169,24 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           }
         }
       }
-      BSYNC();  // the manifolds of this wave's envs may have been written by other waves
       BT_T(22);
       PH(25);
-      // ---- stage C: box-box pairs by 16-lane groups, round-robin over the wave's list
-      if (!bb_lane) {
-        for (int t = g; t < TB; t += S16_ENVS_PER_BLOCK) {
-          int ge = 0;
+      // ---- stage C: box-box pairs by 16-lane groups, round-robin over the block's list like stage B (the pairs of a wave
+      // that has more than 16 of them were done one per lane in stage A)
+      {
+        int TBb = 0;
 #pragma unroll
-          for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= bcum[j] ? 1 : 0;
-          const int k = t - bcum[ge];
-          float* Lg = smw + ge * S16_ENV_FLOATS;
+        for (int j = 0; j < BLK_ENVS; j++) TBb += blk_nbl[j];
+        for (int t = gb; t < TBb; t += BLK_ENVS) {
+          int ge = 0, k = t;
+#pragma unroll
+          for (int j = 0; j < BLK_ENVS - 1; j++) {
+            const int nj = blk_nbl[j];
+            const bool past = ge == j && k >= nj;
+            k -= past ? nj : 0;
+            ge += past ? 1 : 0;
+          }
+          float* Lg = sm + ge * S16_ENV_FLOATS;
           const int idx = reinterpret_cast<const unsigned char*>(Lg + S16_NP_BL)[k];
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
@@ -1201,6 +1209,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           }
         }
       }
+      BSYNC();  // the manifolds of this wave's envs may have been written by other waves
+      (void)bcum; (void)TB;
       if (__any(pool_over) && pool_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_RAW);  // (recorded for the group's own env: a reported condition either way)
       WSYNC();
       PH(24);
