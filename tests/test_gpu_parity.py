@@ -622,3 +622,36 @@ def test_per_env_shape_types_match_oracle():
         assert torch.all((z[0::5] - 0.02).abs() < 3e-4) and torch.all((z[1::5] - 0.03).abs() < 3e-4)
         assert torch.all((z[4::5] - 0.05).abs() < 1e-7)  # absent objects stay put
     assert gpu.overflow_count() == 0
+
+
+def test_create_rejects_what_the_kernel_cannot_hold():
+    """`mssim_create` fails with an error string -- it never falls back to another path -- for a model that does not fit
+    the control-step kernel's tables (three free bodies next to the Panda: 27 velocity components for 16 lanes) and for
+    per-env rows that make no sense (a hull reference outside hull_verts, a plane as a per-env shape type)"""
+    from maniskill_amd.model import geom
+    from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+    from tests.test_oracle_contacts import _per_env_hull_model
+
+    b = SceneModelBuilder()
+    b.set_articulation(panda_record())
+    b.add_actor(table_record())
+    for k in range(3):
+        b.add_actor(cube_record(name=f"c{k}", p=(0.1 * k, 0.2, 0.02)))
+    with pytest.raises(Exception) as ei:
+        too_big = b.compile()
+        MssimSystem(device="cuda:0").gpu_init(too_big, 4)
+    assert "free" in str(ei.value).lower() or "component" in str(ei.value).lower() or "exceed" in str(ei.value).lower(), ei.value
+
+    N = 4
+    model, _ = _per_env_hull_model(N, 2)
+    par = model.arrays["env_shape_param"]
+    keep = par.copy()
+    par[1, 2] = 99.0  # vertex count of env 2's hull
+    with pytest.raises(RuntimeError, match="hull"):
+        MssimSystem(device="cuda:0").gpu_init(model, N)
+    par[:] = keep
+    par[3, 1] = 1.0  # type code 1 = plane
+    with pytest.raises(RuntimeError, match="plane"):
+        MssimSystem(device="cuda:0").gpu_init(model, N)
+    par[:] = keep
+    MssimSystem(device="cuda:0").gpu_init(model, N)  # (the untouched model is fine)
