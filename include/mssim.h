@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MSSIM_ABI_VERSION 4
+#define MSSIM_ABI_VERSION 5
 /* Free bodies: the angular velocity a substep starts from, and the one its pose is integrated with, are clamped
  * to this magnitude (rad/s) -- PhysX's default PxRigidDynamic maxAngularVelocity. Without it a thin body knocked
  * into a fast spin (a peg squeezed out of the gripper) feeds the explicitly integrated gyroscopic term until the
@@ -95,6 +95,7 @@ extern "C" {
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
 #define MSSIM_MAX_HULL_VERTS 64 /* per convex hull (PhysX GPU-compatible hull limit)      */
+#define MSSIM_MAX_TRI_HITS 32   /* triangles of one mesh in range of one convex shape at a time (more: reported overflow) */
 /* Contact patches. A compound body (the Panda finger: 4 boxes, panda_v3.urdf:244-283; the box with a hole: 4 boxes,
  * envs/tasks/tabletop/peg_insertion_side.py:150-181) touching another compound body yields one <= 4-point manifold per
  * SHAPE pair -- 16 shape pairs x 4 points for one finger inside the hole. Before the solver the manifolds of one BODY
@@ -116,7 +117,8 @@ enum {
   MSSIM_OVERFLOW_HITS = 1,     /* more than MSSIM_MAX_HITS shape pairs survived the cull            */
   MSSIM_OVERFLOW_CONVEX = 2,   /* more generic convex (MPR) pairs than the kernel's per-env list      */
   MSSIM_OVERFLOW_RAW = 4,      /* more than MSSIM_MAX_RAW_POINTS manifold points before the reduction */
-  MSSIM_OVERFLOW_CONTACTS = 8  /* more than MSSIM_MAX_CONTACTS contact points after the reduction     */
+  MSSIM_OVERFLOW_CONTACTS = 8, /* more than MSSIM_MAX_CONTACTS contact points after the reduction     */
+  MSSIM_OVERFLOW_TRI = 16      /* more than MSSIM_MAX_TRI_HITS triangles of a mesh near one convex shape */
 };
 /* joint types of the moving articulation bodies (fixed joints are folded at compile time) */
 enum { MSSIM_JOINT_REVOLUTE = 0, MSSIM_JOINT_PRISMATIC = 1 };
@@ -130,7 +132,17 @@ enum {
   MSSIM_SHAPE_CAPSULE = 3, /* param[0] = radius, param[1] = half length, axis = +x of frame  */
   MSSIM_SHAPE_CYLINDER = 4,/* param[0] = radius, param[1] = half length, axis = +x of frame  */
   MSSIM_SHAPE_CONVEX = 5,  /* hull vertices in `hull_verts[hull_offset .. +hull_count)`      */
-  MSSIM_SHAPE_NONE = 6     /* per-env types only: the env has no shape in this slot         */
+  MSSIM_SHAPE_NONE = 6,    /* per-env types only: the env has no shape in this slot         */
+  MSSIM_SHAPE_TRIMESH = 7  /* triangle mesh of a fixed or kinematic body (the reference's nonconvex collision,
+                              actor_builder.py:136-150): shape_hull = (root node in tri_bvh, triangle count). Every
+                              triangle is a 3-vertex hull; a convex shape near the mesh is tested against the triangles
+                              whose boxes lie within its bounding sphere + contact offset (found through the 16-wide BVH),
+                              in index order; each gives a manifold of up to 4 points (the plain query + three queries
+                              with the convex shape tilted by MSSIM_PCM_TILT about three axes in the contact plane) with
+                              the triangle's FACE normal whenever the query's normal is within 60 degrees of it (no
+                              tripping over inner edges), points whose foot lies outside the triangle left to its
+                              neighbour; the contact patches merge the manifolds of coplanar triangles. At most
+                              MSSIM_MAX_TRI_HITS triangles per shape pair.                                          */
 };
 /* what a shape / body row is attached to */
 enum {
@@ -232,6 +244,12 @@ typedef struct mssim_model_desc {
   int32_t n_env_free;
   const int32_t* free_env_slot;  /* [n_free] slot into env_free_inertial, -1 = shared             */
   const float* env_free_inertial;/* [n_env_free*10][N]                                            */
+  /* ---- triangle meshes (ABI v5) ---- */
+  int32_t n_tri;
+  const float* tri_soup;         /* [n_tri][12] centroid (3), then the three corners relative to it (shape frame)  */
+  int32_t n_tri_node;
+  const float* tri_bvh;          /* [n_tri_node][112] 16-wide BVH: child c's box in words 6c..6c+5 (min xyz, max xyz; min > max:
+                                    no child), its reference in word 96 + c as an int32 bit pattern (>= 0: node, < 0: ~triangle) */
 } mssim_model_desc;
 
 /* User-visible buffers (device pointers owned by the caller, e.g. torch tensors); mirrors

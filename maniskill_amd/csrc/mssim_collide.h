@@ -17,7 +17,7 @@
 #pragma once
 #include "mssim_dev.h"
 
-enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5, SH_NONE = 6 };
+enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5, SH_NONE = 6, SH_TRIMESH = 7 };
 
 struct shape_t {
   int type;  // wave-uniform
@@ -467,15 +467,17 @@ __device__ unsigned long long g_mpr_clk[8];
 #define MPR_T(i)
 #define MPR_ADD(i, v)
 #endif
+// `use_inside`: `inside` is a point of B to take instead of its frame origin as B's part of the interior point A.c - B.c
+// (a triangle of a mesh: the point of the triangle nearest to A's centre, so that the origin ray runs along the contact normal)
 template <class SUP>
-MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, manifold_t& m, const SUP& sup) {
+MS_DEV void collide_mpr_t(const shape_t& A, const shape_t& B, float offset, manifold_t& m, const SUP& sup, bool use_inside = false, f3 inside = f3{0.f, 0.f, 0.f}) {
   manifold_clear(m);
   MPR_T0;
   MPR_ADD(4, 1);
   const float margin = offset;
   const float tol = MSSIM_MPR_TOLERANCE;
   mvert v0, v1, v2, v3, v4;
-  v0.a = A.c; v0.b = B.c; v0.v = A.c - B.c;
+  v0.a = A.c; v0.b = use_inside ? inside : B.c; v0.v = A.c - v0.b;
   if (dot(v0.v, v0.v) < 1e-12f) v0.v = f3{1e-5f, 0.f, 0.f};
   f3 dir = -v0.v;
   v1 = msupport(sup, A, B, dir, margin);

@@ -40,6 +40,8 @@ struct DevModel {
   const float* dof_pack;      // [n_dof][32]  all per-joint constants of the cooperative kernel in one 128-byte record
   const float* shape_pack;    // [n_shape][24] all per-shape constants of its narrowphase in one 96-byte record
   const float* shape_half;    // [n_shape][3] half extents of a box in the SHAPE frame, centred at the bound centre, that contains the shape
+  const float* tri_soup;      // [n_tri][12] triangle meshes: centroid, three corners relative to it (include/mssim.h)
+  const float* tri_bvh;       // [n_tri_node][112] their 16-wide BVH
   // per-env overrides ([items][N], env fastest); slot < 0 = shared value
   const int *shape_env_slot, *free_env_slot;
   const float *env_shape_frame, *env_shape_param, *env_shape_bound, *env_free_inertial;
@@ -762,6 +764,7 @@ struct mssim_sim {
   std::vector<float> drive_host;
   float* d_drive = nullptr;
   bool panda = false;
+  bool has_tri = false;  // the model has triangle-mesh shapes: control steps run the kernel variant with the mesh stage
   bool dirty = true;
   int n_cu = 256;  // compute units of the device
   unsigned deferred_fetch = 0u;  // mssim_defer_fetch: copy-out owed to the next call on the handle
@@ -895,6 +898,17 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
     };
     for (int s2 = 0; s2 < ns; s2++) {
       const int st = d->shape_hull[2 * s2], cnt = d->shape_hull[2 * s2 + 1];
+      if (d->shape_type[s2] == MSSIM_SHAPE_TRIMESH) {  // (root node of its BVH, no hull vertices)
+        if (st < 0 || st >= d->n_tri_node || d->shape_body_kind[s2] == MSSIM_BODY_FREE || d->shape_body_kind[s2] == MSSIM_BODY_ART) {
+          g_create_error = "triangle mesh: BVH root out of range, or the mesh belongs to a moving body (fixed / kinematic bodies only)";
+          mssim_destroy(S);
+          return 8;
+        }
+        sh[2 * s2] = st;
+        sh[2 * s2 + 1] = 0;
+        S->has_tri = true;
+        continue;
+      }
       sh[2 * s2 + 1] = cnt;
       if (cnt <= 0) continue;
       sh[2 * s2] = repacked(st, cnt);
@@ -981,13 +995,24 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
             for (int k = 0; k < 3; k++) h[k] = std::max(h[k], std::fabs(v[k] - b[k]));
           }
           break;
+        case MSSIM_SHAPE_TRIMESH: {
+          const int first = (int)pp[0], count = (int)pp[1];
+          if (first < 0 || count < 0 || first + count > d->n_tri) { g_create_error = "triangle mesh: triangle range out of tri_soup"; mssim_destroy(S); return 8; }
+          for (int t = first; t < first + count; t++) {
+            const float* q = d->tri_soup + 12 * (size_t)t;
+            for (int c3 = 0; c3 < 3; c3++)
+              for (int k = 0; k < 3; k++) h[k] = std::max(h[k], std::fabs(q[k] + q[3 + 3 * c3 + k] - b[k]));
+          }
+          break;
+        }
         default: h[0] = h[1] = h[2] = 3e30f;  // plane: never used
       }
       // primitive shapes are centred on their frame; keep the box valid if the bound centre is offset
-      if (d->shape_type[s2] != MSSIM_SHAPE_CONVEX && d->shape_type[s2] != MSSIM_SHAPE_PLANE)
+      if (d->shape_type[s2] != MSSIM_SHAPE_CONVEX && d->shape_type[s2] != MSSIM_SHAPE_PLANE && d->shape_type[s2] != MSSIM_SHAPE_TRIMESH)
         for (int k = 0; k < 3; k++) h[k] += std::fabs(b[k]);
     }
     if ((rc = upload(S, half.data(), (size_t)3 * ns, &M.shape_half))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, d->tri_soup, (size_t)12 * d->n_tri, &M.tri_soup)) || (rc = upload(S, d->tri_bvh, (size_t)112 * d->n_tri_node, &M.tri_bvh))) { mssim_destroy(S); return rc; }
     // packed constant records (one or two cache lines per joint / shape instead of ~10 arrays)
     auto fbits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     std::vector<float> sp(24 * (size_t)(ns > 0 ? ns : 1), 0.f);
@@ -1182,8 +1207,12 @@ extern "C++" {
 template <int TASK>
 static void launch_control_step(mssim_handle h, const DevState& S, int n_substeps, hipStream_t st) {
   prof_mark(h, 0, st);
-  if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, TASK>), env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), dim3(64 * S16_WAVES), 0, st, h->M, S, n_substeps);
-  else hipLaunchKernelGGL((k_solve16<0, 0>), env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), dim3(64 * S16_WAVES), 0, st, h->M, S, n_substeps);
+  const dim3 grid = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), block(64 * S16_WAVES);
+  if (h->has_tri) {  // models with triangle meshes: the variant that carries the mesh stage (never with a task tail)
+    if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
+    else hipLaunchKernelGGL((k_solve16<0, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
+  } else if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, TASK>), grid, block, 0, st, h->M, S, n_substeps);
+  else hipLaunchKernelGGL((k_solve16<0, 0>), grid, block, 0, st, h->M, S, n_substeps);
   prof_mark(h, 0, st);
 }
 }  // extern "C++"
@@ -1339,7 +1368,7 @@ static int finger_pair_list(mssim_handle h, int obj_row, int f1_row, int f2_row)
 extern "C++" {
 template <int TASK>
 static bool control_step_with_task(mssim_handle h, DevState& S, hipStream_t st) {
-  if (!(h->deferred_action && h->deferred_fetch && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0)) return false;
+  if (!(h->deferred_action && h->deferred_fetch && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0) || h->has_tri) return false;
   // The tail runs at the kernel's one wave per SIMD: worth it while all blocks are resident at once (4 per CU) and
   // the launch is latency-bound anyway; with more blocks the separate, fully occupied copy-out + epilogue launch
   // is cheaper than a tail per block.

@@ -492,7 +492,9 @@ struct SupCoop16 {
 // TASK > 0 (with FUSED): the launch ends with the copy-out (mssim_fetch) of its envs and the evaluate / obs /
 // reward epilogue of a task -- 1 PickCube, 2 PushCube, 3 PegInsertionSide -- so that a whole control step
 // (action map, substeps, copy-out, epilogue) is one launch.
-template <int NDOF = 0, int TASK = 0>
+// TRI: the model has triangle-mesh shapes (MSSIM_SHAPE_TRIMESH): the narrowphase carries the mesh stage (BVH traversal, one
+// multi-point manifold per triangle in range); instantiated without a task tail only.
+template <int NDOF = 0, int TASK = 0, bool TRI = false>
 __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState S, int n_sub) {
   constexpr bool FUSED = true;  // (the per-substep variant fed by a separate narrowphase kernel is gone)
   __shared__ __attribute__((aligned(16))) float sm[S16_WAVES * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             const int ta = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 14]) & 7u);
             const int tb = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]) & 7u);
             is_bb = ta == SH_BOX && tb == SH_BOX;
-            is_mpr = !(ta == SH_PLANE || is_bb);
+            is_mpr = !(ta == SH_PLANE || is_bb || (TRI && tb == SH_TRIMESH));  // (mesh pairs: stage T)
             reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = 0;
           }
           const unsigned m16 = (unsigned)(__ballot(is_mpr) >> (16 * g)) & 0xFFFFu;
@@ -1169,6 +1171,235 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           }
         }
       }
+      // ---- stage T (models with triangle meshes): every (convex shape, mesh) pair of an env becomes one task per triangle
+      // in range; a task gives a manifold of its own -- a new entry of the env's hit list -- which the patch pass merges with
+      // those of the coplanar neighbours (include/mssim.h MSSIM_SHAPE_TRIMESH).
+      if (TRI) {
+        // T0, the env's own group: BVH traversal. A node is 16 child boxes, one per lane; children in range of the convex
+        // shape's bounding sphere (+ contact offset, mesh frame) are pushed (nodes) or collected (triangles). The triangles
+        // are then ranked by index (the order of the oracle's plain loop): rank r becomes hit nh + r and task ntask + r.
+        int* const tl = reinterpret_cast<int*>(L + S16_NP_BSCR);         // [56] tasks: triangle | hit index << 24 (BSCR + KEEP, both idle here)
+        int* const cand = reinterpret_cast<int*>(L + S16_NP_BSCR) + 56;  // [32] triangles of the pair being traversed
+        int* const stack = reinterpret_cast<int*>(L + S16_NP_BOUT);      // [20] nodes to visit
+        int* const hitw = reinterpret_cast<int*>(L) + S16_NP_HIT;
+        int* const cntw = reinterpret_cast<int*>(L) + S16_NP_CNT;
+        auto b16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
+        int ntask = 0;
+        bool tri_over = false;
+        const int nh0 = nh;
+        for (int idx = 0; idx < nh0; idx++) {  // (group-uniform)
+          const int pk = hitw[idx];
+          const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
+          if ((int)(__float_as_uint(tb_[14]) & 7u) != SH_TRIMESH) continue;
+          const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
+          const m3 RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
+          const f3 cq = mtmulv(RB, f3{ta_[10], ta_[11], ta_[12]} - f3{tb_[0], tb_[1], tb_[2]});
+          const float rq = ta_[13] + M.contact_offset;
+          int sp = 1, ncand = 0;
+          if (c == 0) stack[0] = (int)(__float_as_uint(tb_[14]) >> 15);
+          WSYNC();
+          while (sp > 0) {
+            const int node = stack[sp - 1];
+            sp--;
+            WSYNC();
+            const float* nd = M.tri_bvh + (size_t)node * 112;
+            const float lx = nd[6 * c], ly = nd[6 * c + 1], lz = nd[6 * c + 2], hx = nd[6 * c + 3], hy = nd[6 * c + 4], hz = nd[6 * c + 5];
+            const int ref = __float_as_int(nd[96 + c]);
+            const float dx = fmaxf(fmaxf(lx - cq.x, cq.x - hx), 0.f), dy = fmaxf(fmaxf(ly - cq.y, cq.y - hy), 0.f), dz = fmaxf(fmaxf(lz - cq.z, cq.z - hz), 0.f);
+            const bool in = lx <= hx && dx * dx + dy * dy + dz * dz <= rq * rq;
+            const unsigned mn = b16(in && ref >= 0), ml2 = b16(in && ref < 0), lt = (1u << c) - 1u;
+            if (in && ref >= 0) {
+              const int at = sp + __popc(mn & lt);
+              if (at < 20) stack[at] = ref; else tri_over = true;
+            }
+            if (in && ref < 0) {
+              const int at = ncand + __popc(ml2 & lt);
+              if (at < MSSIM_MAX_TRI_HITS) cand[at] = ~ref; else tri_over = true;
+            }
+            sp = min(sp + __popc(mn), 20);
+            ncand = min(ncand + __popc(ml2), MSSIM_MAX_TRI_HITS);
+            WSYNC();
+          }
+          // rank by triangle index; room in the hit list and the task list permitting
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int i = c + 16 * k;
+            if (i < ncand) {
+              const int t = cand[i];
+              int rank = 0;
+              for (int j = 0; j < ncand; j++) rank += cand[j] < t ? 1 : 0;
+              if (nh + rank < S16_MAX_HIT && ntask + rank < 56) {
+                tl[ntask + rank] = t | ((nh + rank) << 24);
+                hitw[nh + rank] = pk;
+                cntw[nh + rank] = 0;
+              } else {
+                tri_over = true;
+              }
+            }
+          }
+          const int room = min(S16_MAX_HIT - nh, 56 - ntask);
+          const int take = min(ncand, room);
+          nh += take; ntask += take;
+          WSYNC();
+        }
+        if (__any(tri_over) && tri_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_TRI);
+        // T1: the wave's tasks, one per 16-lane group at a time
+        int tcum[S16_ENVS_PER_BLOCK + 1];
+        tcum[0] = 0;
+#pragma unroll
+        for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) tcum[j + 1] = tcum[j] + __shfl(ntask, 16 * j);
+        const int TT = tcum[S16_ENVS_PER_BLOCK];
+        WSYNC();
+        for (int t0 = 0; t0 < TT; t0 += S16_ENVS_PER_BLOCK) {
+          const bool has = t0 + g < TT;
+          const int t = has ? t0 + g : t0;
+          int ge = 0;
+#pragma unroll
+          for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= tcum[j] ? 1 : 0;
+          float* Lg = smw + ge * S16_ENV_FLOATS;
+          const int tw = reinterpret_cast<const int*>(Lg + S16_NP_BSCR)[t - tcum[ge]];
+          const int tri = tw & 0xFFFFFF, idx = tw >> 24;
+          const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
+          const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
+          const float* tb_ = Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
+          const float* tq = M.tri_soup + (size_t)tri * 12;
+          shape_t Tr;
+          Tr.type = SH_CONVEX;
+          Tr.rot = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
+          Tr.c = f3{tb_[0], tb_[1], tb_[2]} + mmulv(Tr.rot, f3{tq[0], tq[1], tq[2]});
+          Tr.p0 = Tr.p1 = Tr.p2 = 0.f;
+          Tr.verts = tq + 3;
+          Tr.nverts = 3;
+          SupCoop16 sup;
+          sup.c = c;
+          SupCoop16::load_one(sup.va, A, c);
+          SupCoop16::load_one(sup.vb, Tr, c);
+          const float offset = M.contact_offset;
+          const f3 q0 = Tr.c + mmulv(Tr.rot, f3{tq[3], tq[4], tq[5]}), q1 = Tr.c + mmulv(Tr.rot, f3{tq[6], tq[7], tq[8]}), q2 = Tr.c + mmulv(Tr.rot, f3{tq[9], tq[10], tq[11]});
+          f3 nf = normalized(cross(q1 - q0, q2 - q0));
+          if (dot(nf, A.c - q0) < 0.f) nf = -nf;  // the side A's centre is on
+          const f3 e0 = q1 - q0, e1 = q2 - q0;
+          const float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
+          const float den = d00 * d11 - d01 * d01, tol = MSSIM_PCM_MERGE * rsq_f(fminf(d00, d11));
+          // candidates of this lane, at most 4 (hull vertices c, c + 16, ..); id = their place in the oracle's order:
+          // (1) A's plane-contact points over the triangle, 0..63; (2) the triangle's corners under a box, 64..66
+          f3 X[4];
+          float Sp[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { X[k] = f3{0, 0, 0}; Sp[k] = 3e38f; ok[k] = false; }
+          auto cand1 = [&](int k, f3 p, float radius, bool exists) __attribute__((always_inline)) {
+            const float sgap = dot(nf, p - q0) - radius;
+            const f3 dd = p - nf * (radius + sgap) - q0;
+            const float d20 = dot(dd, e0), d21 = dot(dd, e1);
+            const float v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
+            ok[k] = exists && sgap < offset && !(v < -tol || w < -tol || v + w > 1.f + tol);
+            X[k] = p - nf * (radius + 0.5f * sgap);
+            Sp[k] = sgap;
+          };
+          if (A.type == SH_BOX) {
+            cand1(0, A.c + mmulv(A.rot, f3{(c & 1) ? A.p0 : -A.p0, (c & 2) ? A.p1 : -A.p1, (c & 4) ? A.p2 : -A.p2}), 0.f, c < 8);
+            // the triangle's corner (c - 8) under the box: the line corner + t nf in the box frame against the three slabs
+            const f3 qc = c == 8 ? q0 : (c == 9 ? q1 : q2);
+            const f3 ol = mtmulv(A.rot, qc - A.c), dl = mtmulv(A.rot, nf);
+            float t_in = -1e30f, t_out = 1e30f;
+            bool miss = false;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float hb = a == 0 ? A.p0 : (a == 1 ? A.p1 : A.p2), ov = comp(ol, a), dv = comp(dl, a);
+                if (fabsf(dv) < 1e-9f) { miss = miss || fabsf(ov) > hb; continue; }
+                const float t0 = (-hb - ov) / dv, t1 = (hb - ov) / dv;
+                t_in = fmaxf(t_in, fminf(t0, t1));
+                t_out = fminf(t_out, fmaxf(t0, t1));
+            }
+            if (c >= 8 && c < 11) {
+              ok[1] = !(miss || t_in > t_out || !(t_in < offset));
+              X[1] = qc + nf * (0.5f * t_in);
+              Sp[1] = t_in;
+            }
+          } else if (A.type == SH_SPHERE) {
+            cand1(0, A.c, A.p0, c == 0);
+          } else if (A.type == SH_CAPSULE) {
+            const f3 ax = mcol(A.rot, 0) * A.p1;
+            cand1(0, c == 0 ? A.c - ax : A.c + ax, A.p0, c < 2);
+          } else if (A.type == SH_CONVEX) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) cand1(k, A.c + mmulv(A.rot, sup.va[k]), 0.f, c + 16 * k < A.nverts);
+          } else {
+            cand1(0, support(A, -nf), 0.f, c == 0);
+          }
+          // candidate ids: (1) box corner / capsule end / hull vertex index; (2) 64 + corner
+          auto cid = [&](int k) __attribute__((always_inline)) { return (A.type == SH_BOX && k == 1) ? 64 + (c - 8) : c + 16 * k; };
+          // the 4 deepest, the lowest id among equals first (the oracle's keep4_deepest)
+          f3 mx[4];
+          float msep[4];
+          int cnt = 0;
+#pragma unroll 1
+          for (int r = 0; r < 4; r++) {
+            float best = 3e38f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) best = fminf(best, ok[k] ? Sp[k] : 3e38f);
+            best = -gmax16(-best);
+            if (!(best < 3e38f)) break;  // (group-uniform)
+            int id = 1 << 20;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) id = (ok[k] && Sp[k] == best) ? min(id, cid(k)) : id;
+            id = gmin16i(id);
+            // the owner lane and slot of that id
+            const int owner = id >= 64 ? 8 + (id - 64) : (id & 15), slot = id >= 64 ? 1 : (id >> 4);
+            const f3 mine = slot == 0 ? X[0] : (slot == 1 ? X[1] : (slot == 2 ? X[2] : X[3]));
+            const f3 px = f3{gbc(mine.x, owner), gbc(mine.y, owner), gbc(mine.z, owner)};
+#pragma unroll
+            for (int t2 = 0; t2 < 4; t2++)
+              if (t2 == cnt) { mx[t2] = px; msep[t2] = best; }
+            if (c == owner) {
+#pragma unroll
+              for (int k = 0; k < 4; k++) ok[k] = ok[k] && k != slot;
+            }
+            cnt++;
+          }
+          f3 nrm = nf;
+          if (__any(has && cnt == 0)) {
+            // nothing over or under the triangle: the generic query (from the side, or a round shape next to / across it)
+            f3 inside;
+            {
+              float w[3];
+              closest_on_triangle(q0 - A.c, q1 - A.c, q2 - A.c, w);
+              inside = q0 * w[0] + q1 * w[1] + q2 * w[2];
+            }
+            manifold_t gq;
+            manifold_clear(gq);
+            if (has && cnt == 0) collide_mpr_t(A, Tr, offset, gq, sup, true, inside);
+            if (has && cnt == 0 && gq.count > 0) {
+              const bool face = dot(nf, gq.n) > 0.5f;
+              if (!(face && A.type == SH_BOX)) {  // (a box's corners and the corners under it are complete: see the oracle)
+                nrm = face ? nf : gq.n;
+                mx[0] = gq.x[0]; msep[0] = gq.sep[0];
+                cnt = 1;
+              }
+            }
+          }
+          if (has && cnt > 0) {
+            int off = 0;
+            if (c == 0) off = pool_alloc(Lg, cnt);
+            off = gbci(off, 0);
+            if (off >= 0) {
+              if (c == 0) {
+                reinterpret_cast<int*>(Lg)[S16_NP_CNT + idx] = cnt;
+                reinterpret_cast<int*>(Lg)[S16_NP_OFF + idx] = off;
+                float* hn = Lg + S16_NP_HN + 3 * idx;
+                hn[0] = nrm.x; hn[1] = nrm.y; hn[2] = nrm.z;
+              }
+              if (c < cnt) {
+                const f3 x = c == 0 ? mx[0] : (c == 1 ? mx[1] : (c == 2 ? mx[2] : mx[3]));
+                const float sp = c == 0 ? msep[0] : (c == 1 ? msep[1] : (c == 2 ? msep[2] : msep[3]));
+                *reinterpret_cast<float4*>(Lg + S16_NP_POOL + 4 * (off + c)) = float4{x.x, x.y, x.z, sp};
+              }
+            }
+          }
+        }
+        WSYNC();
+      }
       BT_T(22);
       PH(25);
       // ---- stage C: box-box pairs by 16-lane groups, round-robin over the block's list like stage B (the pairs of a wave
@@ -1540,7 +1771,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               r[0] = nn.x; r[1] = nn.y; r[2] = nn.z;
               r[3] = P.x; r[4] = P.y; r[5] = P.z;
               r[6] = P.w - M.rest_offset;
-              r[7] = __int_as_float((pk & 0xFFFF) | (a << 16) | (q << 24));  // pair | patch | manifold slot (warm-start key)
+              // pair | patch | manifold slot (warm-start key) | bit 27: no key (the manifolds of a mesh pair's triangles share the pair)
+              r[7] = __int_as_float((pk & 0xFFFF) | (a << 16) | (q << 24) | ((TRI && (__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) & 7u) == SH_TRIMESH) ? 1 << 27 : 0));
               r[8] = __int_as_float(bodies);
               r[9] = mu;
             }
@@ -1947,7 +2179,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       bool ok = false;
       if (i < nc && live) {
         const int pw = __float_as_int(L[S16_REC + S16_REC_LEN * i + 7]);
-        if (!((pw >> 30) & 1)) {
+        if (!((pw >> 30) & 1) && !(TRI && ((pw >> 27) & 1))) {
           w = *reinterpret_cast<const float4*>(S.warm + (((size_t)(4 * (pw & 0xFFFF) + ((pw >> 24) & 3))) * N + e) * 4);
           ok = __float_as_int(w.w) == pcm_tick - 1;
         }
@@ -2199,7 +2431,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     // the multipliers of this substep, keyed by (shape pair, manifold slot) and stamped: the next substep's warm start
     for (int i = c; i < nc; i += 16) {
       const int pw = __float_as_int(L[S16_REC + S16_REC_LEN * i + 7]);
-      if (((pw >> 30) & 1) || !live) continue;
+      if (((pw >> 30) & 1) || !live || (TRI && ((pw >> 27) & 1))) continue;
       *reinterpret_cast<float4*>(S.warm + (((size_t)(4 * (pw & 0xFFFF) + ((pw >> 24) & 3))) * N + e) * 4) =
           float4{L[S16_CS + 16 * i + 9], L[S16_CS + 16 * i + 10], L[S16_CS + 16 * i + 11], __int_as_float(pcm_tick)};
     }

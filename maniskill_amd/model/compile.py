@@ -18,7 +18,7 @@ from .urdf import RobotDescription
 
 # enums mirrored from include/mssim.h
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
-SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_CONVEX, SHAPE_NONE = range(7)
+SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CAPSULE, SHAPE_CYLINDER, SHAPE_CONVEX, SHAPE_NONE, SHAPE_TRIMESH = range(8)
 BODY_WORLD, BODY_ART, BODY_FREE, BODY_KIN = range(4)
 MAX_DOF, MAX_FREE, MAX_HULL_VERTS = 16, 8, 64
 
@@ -30,6 +30,7 @@ _SHAPE_NAMES = {
     "cylinder": SHAPE_CYLINDER,
     "convex": SHAPE_CONVEX,
     "none": SHAPE_NONE,  # per-env padding: this env has no shape in the slot (include/mssim.h MSSIM_SHAPE_NONE)
+    "trimesh": SHAPE_TRIMESH,  # triangle mesh of a static / kinematic body (vertices + triangles)
 }
 
 
@@ -42,7 +43,8 @@ class ShapeRecord:
     half_size: Optional[np.ndarray] = None  # box
     radius: float = 0.0
     half_length: float = 0.0
-    vertices: Optional[np.ndarray] = None  # convex, shape frame
+    vertices: Optional[np.ndarray] = None  # convex / trimesh, shape frame
+    triangles: Optional[np.ndarray] = None  # trimesh: [T, 3] vertex indices
     static_friction: float = 0.3
     dynamic_friction: float = 0.3
     restitution: float = 0.0
@@ -74,6 +76,9 @@ class ShapeRecord:
             return np.zeros(3), float(np.hypot(self.radius, self.half_length))
         if self.type == "none":
             return np.zeros(3), 0.0
+        if self.type == "trimesh":
+            used = np.asarray(self.vertices, dtype=np.float64)[np.unique(np.asarray(self.triangles))]
+            return mesh.bounding_sphere(used)
         return mesh.bounding_sphere(self.vertices)
 
     def mass_properties(self):
@@ -412,6 +417,7 @@ class SceneModelBuilder:
 
         # ---------------- shape tables ----------------
         hull_verts = []
+        tri_soup, tri_nodes = [], []
         st, sk, si, srow, sframe, sparam, smat, shull, sbound = [], [], [], [], [], [], [], [], []
         shape_env_slot, env_frame, env_param, env_bound = [], [], [], []
         env_hulls = {}  # id(vertex array) -> (first vertex, count): per-env hulls that share a mesh are stored once
@@ -452,7 +458,7 @@ class SceneModelBuilder:
             si.append(s["index"])
             srow.append(s["row"])
             sframe.append(s["frame"])
-            sparam.append(r.param())
+            sparam.append(r.param() if r.type != "trimesh" else np.zeros(4))  # (trimesh: first triangle / count, filled in below)
             # [3]: torsional patch radius. PhysX scales `patch_radius` with the penetration and never goes below
             # `min_patch_radius`; the reference sets both (0.1, panda.py:24-31), where the minimum rules: the larger one
             smat.append([r.static_friction, r.dynamic_friction, r.restitution, max(r.patch_radius, r.min_patch_radius)])
@@ -463,6 +469,21 @@ class SceneModelBuilder:
                     v = hull_of(r)
                     shull.append([len(hull_verts), len(v)])
                     hull_verts.extend(v.tolist())
+            elif r.type == "trimesh":
+                # triangle mesh (static / kinematic bodies): its triangles join the soup, its 16-wide BVH the node table;
+                # shape_hull = (root node, triangle count) -- include/mssim.h MSSIM_SHAPE_TRIMESH
+                assert s["kind"] in (BODY_WORLD, BODY_KIN), f"{s['owner']}: triangle-mesh collision needs a static or kinematic body"
+                soup = mesh.triangle_soup(r.vertices, r.triangles)
+                nodes = mesh.build_bvh16(soup)
+                refs = nodes[:, 96:].view(np.int32)
+                n_nodes0, n_tri0 = sum(len(x) for x in tri_nodes), sum(len(x) for x in tri_soup)
+                leaf = (refs < 0) & (refs != -2**31)
+                refs[refs >= 0] += n_nodes0                # node references: global node index
+                refs[leaf] = ~((~refs[leaf]) + n_tri0)     # leaf references: global triangle index
+                shull.append([n_nodes0, len(soup)])
+                sparam[-1] = np.array([float(n_tri0), float(len(soup)), 0.0, 0.0])  # its triangles: tri_soup[first .. first + count)
+                tri_soup.append(soup)
+                tri_nodes.append(nodes)  # (kept as float32 arrays: the references are int32 bit patterns)
             else:
                 shull.append([0, 0])
             c, rad = r.bound()
@@ -498,7 +519,7 @@ class SceneModelBuilder:
                     pjb = art.robot.parent_joint.get(b["link"])
                     if (pja is not None and pja.parent == b["link"]) or (pjb is not None and pjb.parent == a["link"]):
                         continue
-                if st[ia] == SHAPE_PLANE and st[ib] == SHAPE_PLANE:
+                if st[ia] in (SHAPE_PLANE, SHAPE_TRIMESH) and st[ib] in (SHAPE_PLANE, SHAPE_TRIMESH):
                     continue
                 # canonical order: lower shape type first (plane < box < ... < convex)
                 if st[ia] <= st[ib]:
@@ -541,6 +562,8 @@ class SceneModelBuilder:
         A["shape_hull"] = arr(shull, i32, (ns, 2))
         A["shape_bound"] = arr(sbound, f32, (ns, 4))
         A["hull_verts"] = arr(hull_verts, f32, (len(hull_verts), 3))
+        A["tri_soup"] = np.ascontiguousarray(np.concatenate(tri_soup)) if tri_soup else np.zeros((0, 12), dtype=f32)
+        A["tri_bvh"] = np.ascontiguousarray(np.concatenate(tri_nodes)) if tri_nodes else np.zeros((0, 112), dtype=f32)
         A["pair_shape"] = arr(pairs, i32, (len(pairs), 2))
         # per-env overrides ([items][N], env fastest -- the layout the kernels read directly)
         n_es, n_ef = len(env_frame), len(env_free_inertial)
@@ -563,6 +586,8 @@ class SceneModelBuilder:
             n_kin=n_kin,
             n_shape=ns,
             n_hull_verts=len(hull_verts),
+            n_tri=int(sum(len(x) for x in tri_soup)),
+            n_tri_node=int(sum(len(x) for x in tri_nodes)),
             n_pair=len(pairs),
             n_env_shape=n_es,
             n_env_free=n_ef,

@@ -204,3 +204,84 @@ def bounding_sphere(verts: np.ndarray):
     c = 0.5 * (lo + hi)
     r = float(np.linalg.norm(verts - c, axis=1).max())
     return c, r
+
+
+# ---------------------------------------------------------------------------------------------- triangle meshes
+def load_triangles(path: str):
+    """(vertices [V,3], triangles [T,3]) of a mesh file: OBJ (polygons are fanned) or STL (every facet)"""
+    ext = str(path).lower().rsplit(".", 1)[-1]
+    if ext == "obj":
+        verts, tris = [], []
+        with open(path, "r", errors="ignore") as f:
+            for line in f:
+                t = line.split()
+                if not t:
+                    continue
+                if t[0] == "v":
+                    verts.append([float(t[1]), float(t[2]), float(t[3])])
+                elif t[0] == "f":
+                    idx = [int(w.split("/")[0]) for w in t[1:]]
+                    idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                    for k in range(1, len(idx) - 1):
+                        tris.append([idx[0], idx[k], idx[k + 1]])
+        return np.asarray(verts, dtype=np.float64).reshape(-1, 3), np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:5].lower() == b"solid" and b"facet" in data[:1024]:
+        pts = [[float(x) for x in l.split()[1:4]] for l in data.decode("ascii", errors="ignore").splitlines() if l.strip().startswith("vertex")]
+        v = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+    else:
+        (n,) = struct.unpack("<I", data[80:84])
+        rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+        v = np.frombuffer(data[84 : 84 + 50 * n], dtype=rec)["v"].reshape(-1, 3).astype(np.float64)
+    return v, np.arange(len(v), dtype=np.int64).reshape(-1, 3)
+
+
+def triangle_soup(verts: np.ndarray, tris: np.ndarray) -> np.ndarray:
+    """[T, 12] float32 per triangle: centroid, then the three corners relative to it (a triangle is handed to the
+    narrowphase as a 3-vertex hull in a frame at its centroid). Degenerate triangles are dropped."""
+    P = np.asarray(verts, dtype=np.float64)[np.asarray(tris, dtype=np.int64)]  # [T,3,3]
+    area2 = np.linalg.norm(np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]), axis=1)
+    P = P[area2 > 1e-14]
+    c = P.mean(axis=1)
+    return np.concatenate([c, (P - c[:, None, :]).reshape(-1, 9)], axis=1).astype(np.float32)
+
+
+def build_bvh16(soup: np.ndarray) -> np.ndarray:
+    """16-wide bounding-volume hierarchy over the triangles of `soup`: [n_nodes, 112] float32, node 0 the root. A node
+    holds 16 children, one per lane of the 16-lane group that traverses it: child c's box in words 6c .. 6c+5 (min xyz,
+    max xyz; an empty child has min > max) and its reference in word 96 + c as an int32 bit pattern -- >= 0: node index,
+    < 0: ~triangle index (a leaf child is ONE triangle, its box the triangle's own)."""
+    T = len(soup)
+    cen = soup[:, :3].astype(np.float64)
+    corners = (soup[:, None, :3] + soup[:, 3:].reshape(T, 3, 3)).astype(np.float32)  # f32 corners as the kernels see them
+    tmin, tmax = corners.min(axis=1), corners.max(axis=1)
+    nodes = []
+
+    def split(ids, parts):
+        """ids -> `parts` groups of nearly equal size by recursive median splits along the longest axis"""
+        if parts == 1 or len(ids) <= 1:
+            return [ids]
+        ext = cen[ids].max(axis=0) - cen[ids].min(axis=0)
+        order = ids[np.argsort(cen[ids, int(np.argmax(ext))], kind="stable")]
+        half = len(order) // 2
+        return split(order[:half], parts // 2) + split(order[half:], parts - parts // 2)
+
+    def make(ids):
+        me = len(nodes)
+        node = np.zeros(112, dtype=np.float32)
+        node[:96].reshape(16, 6)[:] = [1, 1, 1, -1, -1, -1]
+        refs = np.full(16, -2**31, dtype=np.int32)
+        nodes.append(node)
+        # (few, full leaves: a set of up to 256 triangles is cut into ceil(n / 16) groups of at most 16)
+        groups = [ids[k : k + 1] for k in range(len(ids))] if len(ids) <= 16 else [g for g in split(ids, min(16, -(-len(ids) // 16))) if len(g)]
+        for k, g in enumerate(groups):
+            node[6 * k : 6 * k + 3] = tmin[g].min(axis=0)
+            node[6 * k + 3 : 6 * k + 6] = tmax[g].max(axis=0)
+            refs[k] = ~int(g[0]) if len(g) == 1 else make(g)
+        node[96:112] = refs.view(np.float32)
+        return me
+
+    if T:
+        make(np.arange(T))
+    return np.asarray(nodes, dtype=np.float32).reshape(-1, 112)

@@ -13,7 +13,7 @@ import numpy as np
 from . import PACKAGE_DIR
 from .model.compile import CompiledModel
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NATIVE_LIB_PATH = os.environ.get("MSSIM_LIB") or os.path.join(PACKAGE_DIR, "_native", "libmssim.so")  # MSSIM_LIB: debug builds of the same HIP library
 
 # apply / fetch selector bits (include/mssim.h)
@@ -92,6 +92,10 @@ class ModelDesc(C.Structure):
         ("n_env_free", C.c_int32),
         ("free_env_slot", _I32P),
         ("env_free_inertial", _F32P),
+        ("n_tri", C.c_int32),
+        ("tri_soup", _F32P),
+        ("n_tri_node", C.c_int32),
+        ("tri_bvh", _F32P),
     ]
 
 

@@ -187,8 +187,22 @@ class PhysxCollisionShapeConvexMesh(PhysxCollisionShape):
 
 
 class PhysxCollisionShapeTriangleMesh(PhysxCollisionShape):
-    def __init__(self, *a, **kw):
-        raise NotImplementedError("triangle-mesh collision is not available in this build (SURVEY.md 8f rank 4)")
+    """triangle mesh of a static or kinematic body (the reference's nonconvex collision, actor_builder.py:136-150): the
+    triangles of an OBJ / STL file, or explicit vertices + triangles"""
+
+    _type = "trimesh"
+
+    def __init__(self, filename: Optional[str] = None, scale=(1.0, 1.0, 1.0), material: Optional[PhysxMaterial] = None, vertices=None, triangles=None):
+        super().__init__(material)
+        self.filename, self.scale = filename, tuple(float(s) for s in scale)
+        self.density = 0.0
+        if vertices is None:
+            vertices, triangles = mesh.load_triangles(str(filename))
+        self.vertices = np.asarray(vertices, dtype=np.float64).reshape(-1, 3) * np.asarray(self.scale)
+        self.triangles = np.asarray(triangles, dtype=np.int64).reshape(-1, 3)
+
+    def _geometry(self):
+        return dict(vertices=self.vertices, triangles=self.triangles)
 
 
 class PhysxBaseComponent:

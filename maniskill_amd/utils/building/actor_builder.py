@@ -129,8 +129,9 @@ class ActorBuilder:
             self._attach(shape, pose, density, patch_radius, min_patch_radius)
         return self
 
-    def add_nonconvex_collision_from_file(self, *a, **kw):
-        raise NotImplementedError("triangle-mesh collision is not available in this build (SURVEY.md 8f rank 4)")
+    def add_nonconvex_collision_from_file(self, filename, pose=None, scale=(1, 1, 1), material=None, patch_radius=0, min_patch_radius=0, is_trigger=False):
+        """triangle-mesh collision for static / kinematic bodies (actor_builder.py:136-150)"""
+        return self._attach(pxc.PhysxCollisionShapeTriangleMesh(filename, scale, self._mat(material)), pose, 0.0, patch_radius, min_patch_radius)
 
     # -- visuals: accepted, ignored -------------------------------------------------------
     def add_box_visual(self, *a, **kw):

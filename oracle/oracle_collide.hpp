@@ -18,7 +18,7 @@
 
 namespace orc {
 
-enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5 };
+enum { SH_PLANE = 0, SH_BOX = 1, SH_SPHERE = 2, SH_CAPSULE = 3, SH_CYLINDER = 4, SH_CONVEX = 5, SH_NONE = 6, SH_TRIMESH = 7 };
 
 template <typename R>
 struct Shape {
@@ -336,12 +336,14 @@ inline void closest_on_triangle(const V3<R>& a, const V3<R>& b, const V3<R>& c, 
 }
 
 template <typename R>
-inline void collide_mpr(const Shape<R>& A, const Shape<R>& B, R offset, Manifold<R>& m) {
+inline void collide_mpr(const Shape<R>& A, const Shape<R>& B, R offset, Manifold<R>& m, const V3<R>* b_inside = nullptr) {
+  // `b_inside`: a point of B to take instead of its frame origin as B's part of the interior point A.c - B.c (a triangle
+  // of a mesh: the point of the triangle nearest to A's centre, so that the origin ray runs along the contact normal)
   m.count = 0;
   const R margin = offset;
   const R tol = R(MSSIM_MPR_TOLERANCE);
   MVert<R> v0, v1, v2, v3, v4;
-  v0.a = A.c; v0.b = B.c; v0.v = A.c - B.c;
+  v0.a = A.c; v0.b = b_inside ? *b_inside : B.c; v0.v = A.c - v0.b;
   if (dot(v0.v, v0.v) < R(1e-12)) v0.v = V3<R>(R(1e-5), 0, 0);
   V3<R> dir = -v0.v;
   v1 = msupport(A, B, dir, margin);

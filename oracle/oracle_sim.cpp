@@ -62,7 +62,7 @@ struct Model {
   std::vector<float> dof_frame, dof_axis, dof_limit, dof_drive, dof_armature, body_inertial, tendon_param, link_frame;
   std::vector<float> free_inertial, free_damping;
   std::vector<int32_t> shape_type, shape_kind, shape_index, shape_row, shape_hull, pair_shape;
-  std::vector<float> shape_frame, shape_param, shape_material, shape_bound, hull_verts;
+  std::vector<float> shape_frame, shape_param, shape_material, shape_bound, hull_verts, tri_soup;
   // per-env overrides ([items][N])
   int N = 0, n_env_shape = 0, n_env_free = 0;
   std::vector<int32_t> shape_env_slot, free_env_slot;
@@ -317,6 +317,95 @@ void select4(int n, const Vec* x, const Real* sep, const Vec& na, char* keep) {
   for (int i = 0; i < n; i++) keep[i] = (i == i0 || i == i1 || i == i2 || i == i3) ? 1 : 0;
 }
 
+// Manifold of a convex shape A against ONE triangle T of a mesh (T: a 3-vertex hull in a frame at its centroid).
+// The triangle is taken as a bounded piece of its plane, normal = its face normal on the side of A's centre:
+//  (1) A's plane-contact points (the corners of a box, the end spheres of a capsule, the vertices of a hull, ... exactly what
+//      plane-vs-shape uses) whose gap is inside the contact offset AND whose foot lies in the triangle (tolerance
+//      MSSIM_PCM_MERGE) -- a point over the neighbouring triangle is that triangle's: no tripping over inner edges;
+//  (2) for a box: the triangle's own corners that lie under the box (a line along the normal through the corner enters the
+//      box within the contact offset) -- a face larger than the triangle, a box lying across a narrow strip or over a rim;
+//  the 4 deepest of (1) and (2), exact gaps. Only when both are empty the generic query runs, with the triangle's point
+//  nearest to A's centre as its interior point: contacts from the side (the rim of a mesh) keep its normal; an answer within
+//  60 degrees of the face normal takes the face normal -- for shapes other than boxes, whose (1) + (2) are complete.
+void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manifold<Real>& m, int& queries) {
+  m.count = 0;
+  const Vec q[3] = {T.c + T.rot * Vec(T.verts[0], T.verts[1], T.verts[2]), T.c + T.rot * Vec(T.verts[3], T.verts[4], T.verts[5]),
+                    T.c + T.rot * Vec(T.verts[6], T.verts[7], T.verts[8])};
+  Vec nf = normalized(cross(q[1] - q[0], q[2] - q[0]));
+  if (dot(nf, A.c - q[0]) < 0) nf = -nf;  // the side A's centre is on
+  const Vec e0 = q[1] - q[0], e1 = q[2] - q[0];
+  const Real d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
+  const Real den = d00 * d11 - d01 * d01, tol = Real(MSSIM_PCM_MERGE) / std::sqrt(std::min(d00, d11));
+  Vec pts[72];
+  Real seps[72];
+  int n = 0;
+  auto add = [&](const Vec& p, Real radius) {
+    const Real s = dot(nf, p - q[0]) - radius;
+    if (!(s < offset) || n >= 64) return;
+    const Vec d = p - nf * (radius + s) - q[0];  // the foot of the surface point on the triangle's plane
+    const Real d20 = dot(d, e0), d21 = dot(d, e1);
+    const Real v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
+    if (v < -tol || w < -tol || v + w > Real(1) + tol) return;
+    pts[n] = p - nf * (radius + Real(0.5) * s);
+    seps[n] = s;
+    n++;
+  };
+  if (A.type == SH_BOX) {
+    for (int i = 0; i < 8; i++)
+      add(A.c + A.rot * Vec((i & 1) ? A.param[0] : -A.param[0], (i & 2) ? A.param[1] : -A.param[1], (i & 4) ? A.param[2] : -A.param[2]), Real(0));
+    // (2) the triangle's corners under the box: the line corner + t nf in the box frame against the three slabs
+    const Vec dl = A.rot.tmul(nf);
+    const Real hb[3] = {A.param[0], A.param[1], A.param[2]}, dv[3] = {dl.x, dl.y, dl.z};
+    for (int i = 0; i < 3; i++) {
+      const Vec ol = A.rot.tmul(q[i] - A.c);
+      const Real ov[3] = {ol.x, ol.y, ol.z};
+      Real t_in = Real(-1e30), t_out = Real(1e30);
+      bool miss = false;
+      for (int a = 0; a < 3; a++) {
+        if (std::fabs(dv[a]) < Real(1e-9)) { miss = miss || std::fabs(ov[a]) > hb[a]; continue; }
+        const Real t0 = (-hb[a] - ov[a]) / dv[a], t1 = (hb[a] - ov[a]) / dv[a];
+        t_in = std::max(t_in, std::min(t0, t1));
+        t_out = std::min(t_out, std::max(t0, t1));
+      }
+      if (miss || t_in > t_out || !(t_in < offset)) continue;
+      pts[n] = q[i] + nf * (Real(0.5) * t_in);
+      seps[n] = t_in;
+      n++;
+    }
+  } else if (A.type == SH_SPHERE) {
+    add(A.c, A.param[0]);
+  } else if (A.type == SH_CAPSULE) {
+    const Vec ax = A.rot.col(0) * A.param[1];
+    add(A.c - ax, A.param[0]);
+    add(A.c + ax, A.param[0]);
+  } else if (A.type == SH_CONVEX) {
+    for (int i = 0; i < A.nverts && i < 64; i++) add(A.c + A.rot * Vec(Real(A.verts[3 * i]), Real(A.verts[3 * i + 1]), Real(A.verts[3 * i + 2])), Real(0));
+  } else {
+    add(support(A, -nf), Real(0));
+  }
+  m.n = nf;
+  keep4_deepest(n, pts, seps, m);
+  if (m.count > 0) return;
+  Vec inside;
+  {
+    Real w[3];
+    closest_on_triangle(q[0] - A.c, q[1] - A.c, q[2] - A.c, w);
+    inside = q[0] * w[0] + q[1] * w[1] + q[2] * w[2];
+  }
+  Manifold<Real> g;
+  queries++;
+  collide_mpr(A, T, offset, g, &inside);
+  if (g.count == 0) return;
+  const bool face = dot(nf, g.n) > Real(0.5);
+  // (a box has no use for a face-normal answer here: its corners and the triangle's corners under it are exact and complete,
+  // and what the query adds next to them -- points just beside the box -- would displace true corners in the patch reduction)
+  if (face && A.type == SH_BOX) return;
+  m.count = 1;
+  m.n = face ? nf : g.n;
+  m.x[0] = g.x[0];
+  m.sep[0] = g.sep[0];
+}
+
 // generic convex pair through the persistent manifold cache (include/mssim.h, MSSIM_PCM_*)
 void pcm_collide(EnvState& E, int p, const Shape<Real>& A, const Shape<Real>& B, Real offset, Manifold<Real>& m) {
   m.count = 0;
@@ -489,9 +578,21 @@ inline Vec shape_obb_half(const Model& M, int s, int e) {
       }
       break;
     }
+    case MSSIM_SHAPE_TRIMESH: {
+      const float* b = &M.shape_bound[4 * s];
+      const int first = (int)M.shape_param[4 * s], count = (int)M.shape_param[4 * s + 1];
+      for (int t = first; t < first + count; t++) {
+        const float* q = &M.tri_soup[12 * (size_t)t];
+        for (int k = 0; k < 3; k++) {
+          const float x = q[0] + q[3 + 3 * k], y = q[1] + q[4 + 3 * k], z = q[2] + q[5 + 3 * k];
+          h.x = std::max(h.x, (Real)std::fabs(x - b[0])); h.y = std::max(h.y, (Real)std::fabs(y - b[1])); h.z = std::max(h.z, (Real)std::fabs(z - b[2]));
+        }
+      }
+      break;
+    }
     default: h = Vec(3e30, 3e30, 3e30);
   }
-  if (slot < 0 && type != MSSIM_SHAPE_CONVEX && type != MSSIM_SHAPE_PLANE) {
+  if (slot < 0 && type != MSSIM_SHAPE_CONVEX && type != MSSIM_SHAPE_PLANE && type != MSSIM_SHAPE_TRIMESH) {
     // primitives are centred on their frame; the box stays valid if the bound centre is offset
     h.x += std::fabs(M.shape_bound[4 * s]); h.y += std::fabs(M.shape_bound[4 * s + 1]); h.z += std::fabs(M.shape_bound[4 * s + 2]);
   }
@@ -526,6 +627,9 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
   for (int s = 0; s < M.n_shape; s++) sh[s] = make_shape(M, E, s, e);
   std::vector<Contact> raw;
   std::vector<RawManifold> man;
+  // (the manifolds of mesh triangles follow those of all other pairs, as in the kernels, which append them to the hit list)
+  std::vector<Contact> raw_tri;
+  std::vector<RawManifold> man_tri;
   E.pcm_tick++;
   E.mpr_queries = 0;
   int hits = 0;  // pairs that survive the cull (the kernels' hit list holds MSSIM_MAX_HITS of them)
@@ -559,6 +663,57 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
       // the persistent manifold cache, so both implementations must apply it alike)
       if (obb_separated(A.rot, shape_obb_half(M, sa, e), B.rot, shape_obb_half(M, sb, e), d, M.contact_offset)) continue;
     }
+    if (B.type == SH_TRIMESH) {
+      // Triangle mesh (include/mssim.h MSSIM_SHAPE_TRIMESH): the triangles whose boxes overlap the convex shape's bounding
+      // box (mesh frame, contact offset added), in index order; each is a 3-vertex hull in a frame at its centroid and
+      // gives a manifold of its own (one MPR point), which the patch pass merges with those of its coplanar neighbours.
+      const Vec cq = B.rot.tmul(ca - B.c);
+      const Real rq = ra + M.contact_offset;
+      const int first = (int)M.shape_param[4 * sb], count = (int)M.shape_param[4 * sb + 1];
+      int found = 0;
+      for (int t = first; t < first + count; t++) {
+        const float* q = &M.tri_soup[12 * (size_t)t];
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+          const float x0 = q[a] + q[3 + a], x1 = q[a] + q[6 + a], x2 = q[a] + q[9 + a];
+          lo[a] = std::min(x0, std::min(x1, x2)); hi[a] = std::max(x0, std::max(x1, x2));
+        }
+        {  // distance from the query sphere's centre to the triangle's box
+          const Real dx = std::max(std::max((Real)lo[0] - cq.x, cq.x - (Real)hi[0]), Real(0)), dy = std::max(std::max((Real)lo[1] - cq.y, cq.y - (Real)hi[1]), Real(0)),
+                     dz = std::max(std::max((Real)lo[2] - cq.z, cq.z - (Real)hi[2]), Real(0));
+          if (dx * dx + dy * dy + dz * dz > rq * rq) continue;
+        }
+        if (found == MSSIM_MAX_TRI_HITS) { E.overflow |= MSSIM_OVERFLOW_TRI; break; }
+        found++;
+        Shape<Real> T;
+        T.type = SH_CONVEX;
+        T.rot = B.rot;
+        T.c = B.c + B.rot * Vec(q[0], q[1], q[2]);
+        T.verts = q + 3;
+        T.nverts = 3;
+        for (int k = 0; k < 4; k++) T.param[k] = 0;
+        Manifold<Real> m;
+        tri_manifold(A, T, M.contact_offset, m, E.mpr_queries);
+        if (m.count <= 0) continue;
+        if ((int)(raw.size() + raw_tri.size()) + m.count > MSSIM_MAX_RAW_POINTS) { E.overflow |= MSSIM_OVERFLOW_RAW; break; }
+        if ((int)(man.size() + man_tri.size()) >= MSSIM_MAX_HITS) { E.overflow |= MSSIM_OVERFLOW_HITS; break; }
+        const Real mu = Real(0.5) * (M.shape_material[4 * sa + 1] + M.shape_material[4 * sb + 1]);
+        man_tri.push_back({(int)raw_tri.size(), m.count, body_id(M.shape_kind[sa], M.shape_index[sa]) * 64 + body_id(M.shape_kind[sb], M.shape_index[sb]), m.n});
+        if (getenv("MSSIM_REF_DEBUG_TRI")) for (int k = 0; k < m.count; k++) fprintf(stderr, "tri %d pt %d x %.4f %.4f %.4f n %.3f %.3f %.3f sep %.5f\n", t, k, (double)m.x[k].x, (double)m.x[k].y, (double)m.x[k].z, (double)m.n.x, (double)m.n.y, (double)m.n.z, (double)m.sep[k]);
+        for (int k = 0; k < m.count; k++) {
+          Contact c;
+          c.pair = p;
+          c.ka = M.shape_kind[sa]; c.ia = M.shape_index[sa];
+          c.kb = M.shape_kind[sb]; c.ib = M.shape_index[sb];
+          c.x = m.x[k]; c.n = m.n; c.sep = m.sep[k] - M.rest_offset; c.mu = mu;
+          c.lam[0] = c.lam[1] = c.lam[2] = 0;
+          c.slot = -1;  // (several manifolds of one pair: no warm-start key)
+          c.tors_mu = 0; c.tors_first = -1; c.tors_n = Vec();
+          raw_tri.push_back(c);
+        }
+      }
+      continue;
+    }
     Manifold<Real> m;
     if (A.type == SH_PLANE || (A.type == SH_BOX && B.type == SH_BOX)) collide(A, B, M.contact_offset, m);
     else pcm_collide(E, p, A, B, M.contact_offset, m);
@@ -580,6 +735,10 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
     }
   }
   (void)hits;
+  for (const RawManifold& mf : man_tri) {
+    man.push_back({(int)raw.size(), mf.count, mf.key, mf.n});
+    for (int k = 0; k < mf.count; k++) raw.push_back(raw_tri[mf.first + k]);
+  }
   // Sleeping free bodies (include/mssim.h sleep_threshold). A "disturber" is an articulation link or a free body that is
   // awake and not calm (energy above the threshold at the start of the substep). A sleeping body touched by a disturber
   // (a manifold with points) wakes; the manifolds of a body that stays asleep are dropped (its partners are fixed,
@@ -978,6 +1137,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   if ((int)E.warm.size() != 4 * M.n_pair) E.warm.assign((size_t)4 * M.n_pair, EnvState::Warm{{0, 0, 0}, -1});
   if (!M.cold)
     for (size_t ci = 0; ci < contacts.size(); ci++) {
+      if (contacts[ci].slot < 0) continue;
       const EnvState::Warm& w = E.warm[4 * contacts[ci].pair + contacts[ci].slot];
       if (w.stamp != E.pcm_tick - 1) continue;
       for (int d = 0; d < 3; d++) {
@@ -1074,6 +1234,7 @@ void substep(mssim_sim* S, EnvState& E, int e) {
   for (int it = 0; it < M.vel_iters; it++) sweep(false);
 
   for (size_t ci = 0; ci < contacts.size(); ci++) {
+    if (contacts[ci].slot < 0) continue;
     EnvState::Warm& w = E.warm[4 * contacts[ci].pair + contacts[ci].slot];
     for (int d = 0; d < 3; d++) w.lam[d] = rows[contact_row[ci] + d].lam;
     w.stamp = E.pcm_tick;
@@ -1160,6 +1321,7 @@ int mssim_ref_create(const mssim_model_desc* d, int32_t num_envs, int32_t device
   M.shape_row = cp(d->shape_row, ns); M.shape_frame = cp(d->shape_frame, 7 * ns); M.shape_param = cp(d->shape_param, 4 * ns);
   M.shape_material = cp(d->shape_material, 4 * ns); M.shape_hull = cp(d->shape_hull, 2 * ns); M.shape_bound = cp(d->shape_bound, 4 * ns);
   M.hull_verts = cp(d->hull_verts, 3 * d->n_hull_verts); M.pair_shape = cp(d->pair_shape, 2 * d->n_pair);
+  M.tri_soup = cp(d->tri_soup, (size_t)12 * d->n_tri);  // (the BVH is an acceleration structure of the kernels: not used here)
   M.N = num_envs;
   M.n_env_shape = d->n_env_shape; M.n_env_free = d->n_env_free;
   if ((d->n_env_shape > 0 || d->n_env_free > 0) && d->num_envs != num_envs) { g_create_error = "per-env arrays were built for a different num_envs"; delete S; return 5; }

@@ -149,6 +149,47 @@ def test_per_env_object_set_from_mesh_files(tmp_path):
     assert env.scene.px.overflow_count() == 0
 
 
+def test_nonconvex_collision_from_file(tmp_path):
+    """`add_nonconvex_collision_from_file` (actor_builder.py:136-150) on a synthetic asset: a ramp with a rim written as an
+    OBJ (quads, fanned by the loader) becomes a static triangle mesh; a box put on it slides down (tan 21.8 deg = 0.4 > mu)
+    and is stopped by the rim -- the same in every env"""
+    import numpy as np
+
+    from maniskill_amd.envs.scene import ManiSkillScene
+    from maniskill_amd.utils.structs.pose import Pose
+    from tests import oracle_backend as ob
+
+    # a 0.3 x 0.2 m ramp falling 0.12 m along x, ending in a 3 cm wall
+    V = [(0, -0.1, 0.12), (0, 0.1, 0.12), (0.3, 0.1, 0.0), (0.3, -0.1, 0.0), (0.3, -0.1, 0.03), (0.3, 0.1, 0.03)]
+    f = tmp_path / "ramp.obj"
+    with open(f, "w") as fh:
+        for v in V:
+            fh.write("v %g %g %g\n" % v)
+        fh.write("f 1 4 3 2\nf 4 5 6 3\n")
+    ob.register("f64", "oracle_f64_env")
+    scene = ManiSkillScene(2, device="cpu", backend_name="oracle_f64_env")
+    b = scene.create_actor_builder()
+    b.add_nonconvex_collision_from_file(str(f))
+    b.initial_pose = Pose.create_from_pq([0.0, 0.0, 0.0])
+    b.build_static("ramp")
+    t = np.arctan2(0.12, 0.3)
+    b = scene.create_actor_builder()
+    b.add_box_collision(half_size=[0.02, 0.02, 0.02])
+    b.initial_pose = Pose.create_from_pq([0.05 + 0.02 * np.sin(t), 0.0, 0.12 - 0.05 * np.tan(t) + 0.02 * np.cos(t) + 0.001], [np.cos(t / 2), 0, np.sin(t / 2), 0])
+    slider = b.build("slider")
+    scene._setup()
+    assert scene.model.arrays["tri_soup"].shape == (4, 12) and scene.model.arrays["tri_bvh"].shape[0] == 1
+    px = scene.px
+    x0 = slider.pose.p[:, 0].clone()
+    for _ in range(12):
+        px.step(10)
+        px.gpu_fetch_all()
+    p = slider.pose.p
+    assert torch.all(p[:, 0] > x0 + 0.1) and torch.all(p[:, 0] < 0.3 - 0.008), p  # slid down and stopped at the rim (tilted: its lower front edge at the wall)
+    assert torch.all(p[:, 2] > 0.015) and torch.all(p[:, 2] < 0.06), p
+    assert torch.allclose(p[0], p[1]) and px.overflow_count() == 0
+
+
 def test_physx_module_config_flow():
     ec.check_physx_module_config(BACKEND)
 

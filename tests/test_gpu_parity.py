@@ -655,3 +655,92 @@ def test_create_rejects_what_the_kernel_cannot_hold():
         MssimSystem(device="cuda:0").gpu_init(model, N)
     par[:] = keep
     MssimSystem(device="cuda:0").gpu_init(model, N)  # (the untouched model is fine)
+
+
+def test_triangle_mesh_matches_oracle():
+    """static triangle meshes on the HIP kernel (the variant with the mesh stage: 16-wide BVH traversal, one multi-point
+    manifold per triangle in range) against the oracle's plain loop over the triangles: cubes dropped on a flat 128-triangle
+    grid and on a 25-degree slope, a ball in a 512-triangle bowl -- same contact counts, same trajectories, the known
+    answers of tests/test_oracle_contacts.py on both sides"""
+    from maniskill_amd.model import geom
+    from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+    from tests.test_oracle_contacts import _grid_mesh, _mesh_scene
+
+    # (1) cubes on a flat grid, different places and yaws: resting flat at their half height
+    N = 12
+    model = _mesh_scene(cube_z=0.03)
+    gpu, cpu = make_pair(model, N)
+    row = model.row_of("cube")
+    g = torch.Generator().manual_seed(0)
+    yaw = 2 * np.pi * torch.rand(N, generator=g)
+    for px in (gpu, cpu):
+        s = px.cuda_rigid_body_data.torch()[row * N : (row + 1) * N]
+        s[:, 0] = (0.4 * torch.rand(N, generator=torch.Generator().manual_seed(1)) - 0.2).to(px.device)
+        s[:, 1] = (0.4 * torch.rand(N, generator=torch.Generator().manual_seed(2)) - 0.2).to(px.device)
+        s[:, 3] = torch.cos(yaw / 2).to(px.device)
+        s[:, 6] = torch.sin(yaw / 2).to(px.device)
+        px.gpu_apply_all()
+        px.wake_all()
+    agree = 0
+    clean = torch.ones(N, dtype=torch.bool)  # envs whose contact counts have agreed in every substep so far
+    for i in range(8):
+        for px in (gpu, cpu):
+            px.step(1)
+        a, b = get_state(gpu, model, N), get_state(cpu, model, N)
+        same = a["cnt"].sum(0) == b["cnt"].sum(0)
+        agree += int(same.sum())
+        err = torch.abs(a["rb"][row, :, :7] - b["rb"][row, :, :7]).max(dim=1).values
+        # (a point whose foot lies on a triangle's edge within rounding is kept by one side and left to the neighbour by the
+        # other: the counts differ by one in such a substep, the states by what one redundant point of a flat patch does)
+        clean &= same & (err < 5e-5)
+        assert torch.all(err < 1e-2), (i, err)
+    # (also with equal counts the patch rule may keep different points of a flat 24-point patch on the two sides -- ties --
+    # which shows as a few 1e-3 of rotation while the cube settles; half of the envs and more stay together to rounding)
+    assert agree >= 0.9 * 8 * N and int(clean.sum()) >= 0.5 * N, (agree, clean)
+    for px in (gpu, cpu):
+        px.step(60)
+    a, b = get_state(gpu, model, N), get_state(cpu, model, N)
+    for st in (a, b):
+        # (four corners on the mesh, plus speculative contacts with the triangles beside the cube)
+        assert torch.all((st["rb"][row, :, 2] - 0.02).abs() < 1e-5) and torch.all(st["cnt"].sum(0) >= 4) and float(st["rb"][row, :, 7:13].abs().max()) < 1e-2
+    assert int((a["cnt"].sum(0) == b["cnt"].sum(0)).sum()) >= N - 1
+    assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
+
+    # (2) a cube sliding down a 25-degree mesh: g (sin - mu cos) on both sides, crossing inner edges without tripping
+    t = np.deg2rad(25.0)
+    model = _mesh_scene(tilt_deg=25.0)
+    gpu, cpu = make_pair(model, 1)
+    for px in (gpu, cpu):
+        rb = px.cuda_rigid_body_data.torch()
+        rb[row, :3] = torch.tensor([0.02 * np.sin(t), 0.0, 0.02 * np.cos(t)], dtype=rb.dtype)
+        rb[row, 3:7] = torch.tensor([np.cos(t / 2), 0.0, np.sin(t / 2), 0.0], dtype=rb.dtype)
+        px.gpu_apply_all()
+        px.wake_all()
+        px.step(30)
+    a, b = get_state(gpu, model, 1), get_state(cpu, model, 1)
+    down = torch.tensor([np.cos(t), 0.0, -np.sin(t)], dtype=torch.float32)
+    expect = 9.81 * (np.sin(t) - 0.3 * np.cos(t)) * 0.3
+    for st in (a, b):
+        assert abs(float(st["rb"][row, 0, 7:10] @ down) - expect) < 0.05 * expect
+    assert torch.max(torch.abs(a["rb"][row, :, :3] - b["rb"][row, :, :3])) < 1e-3
+
+    # (3) a ball in a bowl
+    height = lambda x, y: 0.8 * (x * x + y * y)
+    V, F = _grid_mesh(n=16, height=height)
+    bld = SceneModelBuilder()
+    bld.add_actor(ActorRecord("terrain", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)]))
+    bld.add_actor(ActorRecord("ball", "dynamic", [ShapeRecord("sphere", geom.pose(), radius=0.03)], initial_pose=geom.pose([0.18, 0.1, height(0.18, 0.1) + 0.04])))
+    model = bld.compile(sleep_threshold=0.0)
+    gpu, cpu = make_pair(model, 4)
+    row = model.row_of("ball")
+    for i in range(40):
+        for px in (gpu, cpu):
+            px.step(5)
+        a, b = get_state(gpu, model, 4), get_state(cpu, model, 4)
+        for st in (a, b):
+            p = st["rb"][row, :, :3].double().numpy()
+            assert np.all(p[:, 2] - height(p[:, 0], p[:, 1]) > 0.03 * 0.9), (i, p)
+        if i < 4:
+            assert torch.max(torch.abs(a["rb"][row, :, :3] - b["rb"][row, :, :3])) < 1e-4, i
+    assert torch.max(torch.abs(a["rb"][row, :, :3] - b["rb"][row, :, :3])) < 2e-2  # (rolling: the two stay together to centimetres over 2 s)
+    assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0

@@ -557,3 +557,87 @@ def test_per_env_object_sets_with_different_shape_types():
     assert np.allclose(s[4, :3], [0, 0, 0.08]) and np.allclose(s[4, 7:], 0)  # nothing there: the body stays where it was put
     assert px.read_internal("free_wake", 1).reshape(-1)[4] <= 0
     assert px.overflow_count() == 0
+
+
+def _grid_mesh(n=8, size=0.6, tilt_deg=0.0, height=None):
+    """an n x n grid of quads (2 n^2 triangles) of side `size`, tilted about y, optionally with a height field on top"""
+    xs, ys = np.meshgrid(np.linspace(-size / 2, size / 2, n + 1), np.linspace(-size / 2, size / 2, n + 1), indexing="ij")
+    z = np.zeros_like(xs) if height is None else height(xs, ys)
+    V = np.stack([xs.ravel(), ys.ravel(), z.ravel()], 1)
+    F = []
+    for i in range(n):
+        for j in range(n):
+            a = i * (n + 1) + j
+            F += [[a, a + n + 1, a + 1], [a + 1, a + n + 1, a + n + 2]]
+    t = np.deg2rad(tilt_deg)
+    R = np.array([[np.cos(t), 0, np.sin(t)], [0, 1, 0], [-np.sin(t), 0, np.cos(t)]])
+    return V @ R.T, np.asarray(F)
+
+
+def _mesh_scene(tilt_deg=0.0, cube_z=0.03, height=None, n=8):
+    V, F = _grid_mesh(n=n, tilt_deg=tilt_deg, height=height)
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("terrain", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)], initial_pose=geom.pose([0, 0, 0])))
+    b.add_actor(cube_record(p=(0, 0, cube_z)))
+    return b.compile(sleep_threshold=0.0)  # (awake throughout: the tests look at its contacts)
+
+
+def test_triangle_mesh_floor_and_slopes():
+    """static triangle meshes (the reference's nonconvex collision, actor_builder.py:136-150; MSSIM_SHAPE_TRIMESH): a cube
+    dropped on a flat 128-triangle grid rests at its half height like on a box (the contacts of the coplanar triangles
+    merge into one 4-point patch); on a mesh tilted by 10 degrees it stays (tan 10 < mu = 0.3), tilted by 25 degrees it slides
+    with g (sin - mu cos)"""
+    model = _mesh_scene()
+    px = ob.make_system(model, 1)
+    row = model.row_of("cube")
+    px.step(100)
+    px.gpu_fetch_all()
+    s = px.cuda_rigid_body_data.torch()[row]
+    assert abs(s[2].item() - 0.02) < 2e-4 and s[7:10].abs().max() < 2e-3 and s[10:13].abs().max() < 3e-2, s  # (manifolds rebuilt every substep: a residual rocking of ~1e-2 rad/s)
+    assert px.read_internal("contact_count", model.n_pair).sum().item() == 4  # one patch of four points
+    assert px.overflow_count() == 0
+
+    for tilt, slides in ((10.0, False), (25.0, True)):
+        t = np.deg2rad(tilt)
+        model = _mesh_scene(tilt_deg=tilt)
+        px = ob.make_system(model, 1)
+        rb = px.cuda_rigid_body_data.torch()
+        # the cube lying on the slope: centre 0.02 above the surface along its normal (sin t, 0, cos t), turned with it
+        rb[row, :3] = torch.tensor([0.02 * np.sin(t), 0.0, 0.02 * np.cos(t)], dtype=rb.dtype)
+        rb[row, 3:7] = torch.tensor([np.cos(t / 2), 0.0, np.sin(t / 2), 0.0], dtype=rb.dtype)
+        px.gpu_apply_all()
+        px.wake_all()
+        px.step(30)
+        px.gpu_fetch_all()
+        v = px.cuda_rigid_body_data.torch()[row, 7:10].double().numpy()
+        down = np.array([np.cos(t), 0.0, -np.sin(t)])  # downhill direction of a surface whose normal is (sin t, 0, cos t)
+        if slides:
+            expect = 9.81 * (np.sin(t) - 0.3 * np.cos(t)) * 0.3
+            assert abs(v @ down - expect) < 0.05 * expect, (v, expect)
+        else:
+            assert np.linalg.norm(v) < 2e-3, v
+
+
+def test_triangle_mesh_terrain_holds_a_rolling_ball():
+    """a ball released on the wall of a paraboloid bowl (512 triangles) rolls down, through the bottom and up the other
+    side: it stays on the surface all along -- never sinks in, never trips on an inner edge: its energy only decays"""
+    height = lambda x, y: 0.8 * (x * x + y * y)
+    V, F = _grid_mesh(n=16, height=height)
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("terrain", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)]))
+    b.add_actor(ActorRecord("ball", "dynamic", [ShapeRecord("sphere", geom.pose(), radius=0.03)], initial_pose=geom.pose([0.18, 0.1, height(0.18, 0.1) + 0.04])))
+    model = b.compile(sleep_threshold=0.0)
+    px = ob.make_system(model, 1)
+    row = model.row_of("ball")
+    energy = []
+    for _ in range(80):
+        px.step(5)
+        px.gpu_fetch_all()
+        s = px.cuda_rigid_body_data.torch()[row].double().numpy()
+        p = s[:3]
+        assert p[2] - height(p[0], p[1]) > 0.03 * 0.9, p  # on the surface (vertical clearance >= radius on a slope)
+        assert abs(p[0]) < 0.28 and abs(p[1]) < 0.28, p
+        energy.append(9.81 * p[2] + 0.5 * (s[7:10] @ s[7:10]) + 0.5 * 0.4 * 0.03**2 * (s[10:13] @ s[10:13]))
+    assert max(np.diff(energy)) < 2e-3 * 9.81  # no energy is gained at the edges between triangles (2 mm of height)
+    assert energy[-1] < energy[0]  # (there is no rolling resistance: the ball keeps swinging through the bowl, a little lower each time)
+    assert px.overflow_count() == 0

@@ -111,8 +111,6 @@ def test_component_api_compiles_to_the_builders_model():
 def test_unsupported_shapes_say_so():
     import pytest
 
-    with pytest.raises(NotImplementedError):
-        physx.PhysxCollisionShapeTriangleMesh("x.obj")
     c = physx.PhysxRigidDynamicComponent()
     with pytest.raises(NotImplementedError):
         c.set_locked_motion_axes([True, False, False, False, False, False])
