@@ -1,5 +1,11 @@
-"""BaseAgent: loads the robot articulation and owns its controllers (counterpart of
-mani_skill/agents/base_agent.py:44-390)."""
+"""BaseAgent: the robot of a task -- one batched articulation loaded from its URDF, plus the controllers that turn
+actions into drive targets (API counterpart of mani_skill/agents/base_agent.py:44-390; what a subclass declares --
+`uid`, `urdf_path`, `urdf_config`, `keyframes`, `_controller_configs`, `_sensor_configs` -- keeps the reference's names).
+
+The class is organised around three small tables instead of the reference's per-attribute code: the loader options
+taken from class attributes (`_LOADER_OPTIONS`), the entries of the state dict with their getter / setter on the
+articulation (`_STATE_ENTRIES`), and the controllers built so far, keyed by control mode.
+"""
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Union
@@ -12,7 +18,7 @@ from maniskill_amd.agents.controllers import CombinedController, ControllerConfi
 from maniskill_amd.agents.controllers.base_controller import BaseController
 from maniskill_amd.utils import sapien_utils
 from maniskill_amd.utils.structs.articulation import Articulation
-from maniskill_amd.utils.structs.pose import Pose
+from maniskill_amd.utils.structs.pose import Pose  # noqa: F401  (re-exported for subclasses)
 
 DictControllerConfig = Dict[str, ControllerConfig]
 
@@ -34,62 +40,53 @@ class BaseAgent:
     disable_self_collisions: bool = False
     keyframes: Dict[str, Keyframe] = dict()
 
+    # URDF loader attribute <- class attribute of the agent
+    _LOADER_OPTIONS = (
+        ("fix_root_link", "fix_root_link"),
+        ("load_multiple_collisions_from_file", "load_multiple_collisions"),
+        ("disable_self_collisions", "disable_self_collisions"),
+    )
+    # state-dict key, how to read it, how to write it (reader / writer take the agent)
+    _STATE_ENTRIES = (
+        ("robot_root_pose", lambda a: a._root_link.get_pose(), lambda a, v: a.robot.set_root_pose(v)),
+        ("robot_root_vel", lambda a: a._root_link.get_linear_velocity(), lambda a, v: a.robot.set_root_linear_velocity(v)),
+        ("robot_root_qvel", lambda a: a._root_link.get_angular_velocity(), lambda a, v: a.robot.set_root_angular_velocity(v)),
+        ("robot_qpos", lambda a: a.robot.get_qpos(), lambda a, v: a.robot.set_qpos(v)),
+        ("robot_qvel", lambda a: a.robot.get_qvel(), lambda a, v: a.robot.set_qvel(v)),
+    )
+
     def __init__(self, scene, control_freq: int, control_mode: Optional[str] = None, agent_idx: Optional[str] = None,
                  initial_pose=None, build_separate: bool = False):
-        self.scene = scene
-        self._control_freq = control_freq
-        self._agent_idx = agent_idx
         if build_separate:
             raise NotImplementedError("build_separate (per-env distinct robots) is not supported by this core yet")
-        self.build_separate = build_separate
+        self.scene, self.build_separate = scene, False
+        self._control_freq, self._agent_idx = control_freq, agent_idx
         self.robot: Articulation = None
-        self.controllers: Dict[str, BaseController] = dict()
-        self.sensors = dict()
+        self.controllers: Dict[str, BaseController] = {}
+        self.sensors = {}
+        self._control_mode = None
         self._load_articulation(initial_pose)
         self._after_loading_articulation()
-        self.supported_control_modes = list(self._controller_configs.keys())
-        if control_mode is None:
-            control_mode = self.supported_control_modes[0]
-        self._default_control_mode = control_mode
+        modes = list(self._controller_configs)
+        self.supported_control_modes = modes
+        self._default_control_mode = modes[0] if control_mode is None else control_mode
         self.set_control_mode()
         self._after_init()
 
+    # ------------------------------------------------------------------ what subclasses override
     @property
     def _sensor_configs(self):
         return []
 
     @property
     def _controller_configs(self) -> Dict[str, Union[ControllerConfig, DictControllerConfig]]:
-        names = [j.name for j in self.robot.active_joints]
-        return dict(
-            pd_joint_pos=PDJointPosControllerConfig(names, lower=None, upper=None, stiffness=100, damping=10, normalize_action=False),
-            pd_joint_delta_pos=PDJointPosControllerConfig(names, lower=-0.1, upper=0.1, stiffness=100, damping=10, normalize_action=True, use_delta=True),
-        )
-
-    @property
-    def device(self):
-        return self.scene.device
-
-    def _load_articulation(self, initial_pose=None):
-        if self.urdf_path is None:
-            raise NotImplementedError("only URDF robots are supported (MJCF import is out of scope)")
-        loader = self.scene.create_urdf_loader()
-        loader.name = self.uid if self._agent_idx is None else f"{self.uid}-agent-{self._agent_idx}"
-        loader.fix_root_link = self.fix_root_link
-        loader.load_multiple_collisions_from_file = self.load_multiple_collisions
-        loader.disable_self_collisions = self.disable_self_collisions
-        if self.urdf_config is not None:
-            cfg = sapien_utils.parse_urdf_config(self.urdf_config)
-            sapien_utils.check_urdf_config(cfg)
-            sapien_utils.apply_urdf_config(loader, cfg)
-        path = str(self.urdf_path)
-        if not os.path.exists(path):
-            raise FileNotFoundError(f"Robot {self.uid} definition file not found at {path} (assets cannot be downloaded: no network)")
-        builder = loader.parse(path)["articulation_builders"][0]
-        builder.initial_pose = initial_pose
-        self.robot = builder.build()
-        assert self.robot is not None, f"Fail to load URDF from {path}"
-        self.robot_link_names = [l.name for l in self.robot.get_links()]
+        """default: position control of every active joint, absolute and as +-0.1 rad deltas"""
+        joints = [j.name for j in self.robot.active_joints]
+        common = dict(stiffness=100, damping=10)
+        return {
+            "pd_joint_pos": PDJointPosControllerConfig(joints, lower=None, upper=None, normalize_action=False, **common),
+            "pd_joint_delta_pos": PDJointPosControllerConfig(joints, lower=-0.1, upper=0.1, normalize_action=True, use_delta=True, **common),
+        }
 
     def _after_loading_articulation(self):
         pass
@@ -97,29 +94,69 @@ class BaseAgent:
     def _after_init(self):
         pass
 
+    def is_grasping(self, object=None):
+        raise NotImplementedError()
+
+    def is_static(self, threshold: float):
+        raise NotImplementedError()
+
+    # ------------------------------------------------------------------ loading
+    @property
+    def device(self):
+        return self.scene.device
+
+    @property
+    def _root_link(self):
+        return self.robot.get_links()[0]
+
+    def _load_articulation(self, initial_pose=None):
+        if self.urdf_path is None:
+            raise NotImplementedError("only URDF robots are supported (MJCF import is out of scope)")
+        urdf = str(self.urdf_path)
+        if not os.path.exists(urdf):
+            raise FileNotFoundError(f"Robot {self.uid} definition file not found at {urdf} (assets cannot be downloaded: no network)")
+        loader = self.scene.create_urdf_loader()
+        loader.name = self.uid if self._agent_idx is None else f"{self.uid}-agent-{self._agent_idx}"
+        for loader_attr, own_attr in self._LOADER_OPTIONS:
+            setattr(loader, loader_attr, getattr(self, own_attr))
+        if self.urdf_config is not None:
+            parsed = sapien_utils.parse_urdf_config(self.urdf_config)
+            sapien_utils.check_urdf_config(parsed)
+            sapien_utils.apply_urdf_config(loader, parsed)
+        art_builder = loader.parse(urdf)["articulation_builders"][0]
+        art_builder.initial_pose = initial_pose
+        self.robot = art_builder.build()
+        assert self.robot is not None, f"Fail to load URDF from {urdf}"
+        self.robot_link_names: List[str] = [link.name for link in self.robot.get_links()]
+
+    # ------------------------------------------------------------------ control modes
     @property
     def control_mode(self):
         return self._control_mode
 
+    def _make_controller(self, mode: str) -> BaseController:
+        """build the controller of `mode` from its config; a dict of configs is a CombinedController whose optional
+        `balance_passive_force` entry says whether the robot's links are exempt from gravity (base_agent.py:272-282)"""
+        cfg = self._controller_configs[mode]
+        weightless = True
+        if isinstance(cfg, dict):
+            weightless = cfg.pop("balance_passive_force", True)
+            ctrl = CombinedController(cfg, self.robot, self._control_freq, scene=self.scene)
+        else:
+            ctrl = cfg.controller_cls(cfg, self.robot, self._control_freq, scene=self.scene)
+        ctrl.set_drive_property()
+        if weightless and not self.scene._gpu_sim_initialized:
+            for link in self.robot.links:
+                link.disable_gravity = True
+        return ctrl
+
     def set_control_mode(self, control_mode: str = None):
-        if control_mode is None:
-            control_mode = self._default_control_mode
-        assert control_mode in self.supported_control_modes, f"{control_mode} not in supported modes: {self.supported_control_modes}"
-        self._control_mode = control_mode
-        if control_mode not in self.controllers:
-            config = self._controller_configs[control_mode]
-            balance_passive_force = True
-            if isinstance(config, dict):
-                if "balance_passive_force" in config:
-                    balance_passive_force = config.pop("balance_passive_force")
-                self.controllers[control_mode] = CombinedController(config, self.robot, self._control_freq, scene=self.scene)
-            else:
-                self.controllers[control_mode] = config.controller_cls(config, self.robot, self._control_freq, scene=self.scene)
-            self.controllers[control_mode].set_drive_property()
-            if balance_passive_force and not self.scene._gpu_sim_initialized:
-                # "passive force balance" = gravity off on every robot link (base_agent.py:272-282)
-                for link in self.robot.links:
-                    link.disable_gravity = True
+        mode = self._default_control_mode if control_mode is None else control_mode
+        if mode not in self.supported_control_modes:
+            raise AssertionError(f"{mode} not in supported modes: {self.supported_control_modes}")
+        self._control_mode = mode
+        if mode not in self.controllers:
+            self.controllers[mode] = self._make_controller(mode)
 
     @property
     def controller(self) -> BaseController:
@@ -127,17 +164,18 @@ class BaseAgent:
             raise RuntimeError("Please specify a control mode first")
         return self.controllers[self._control_mode]
 
+    def _space(self, attr: str):
+        if self._control_mode is not None:
+            return getattr(self.controller, attr)
+        return spaces.Dict({mode: getattr(ctrl, attr) for mode, ctrl in self.controllers.items()})
+
     @property
     def action_space(self):
-        if self._control_mode is None:
-            return spaces.Dict({uid: c.action_space for uid, c in self.controllers.items()})
-        return self.controller.action_space
+        return self._space("action_space")
 
     @property
     def single_action_space(self):
-        if self._control_mode is None:
-            return spaces.Dict({uid: c.single_action_space for uid, c in self.controllers.items()})
-        return self.controller.single_action_space
+        return self._space("single_action_space")
 
     def set_action(self, action):
         self.controller.set_action(action)
@@ -145,32 +183,25 @@ class BaseAgent:
     def before_simulation_step(self):
         self.controller.before_simulation_step()
 
+    # ------------------------------------------------------------------ observation / state
     def get_proprioception(self):
-        obs = dict(qpos=self.robot.get_qpos(), qvel=self.robot.get_qvel())
-        cs = self.controller.get_state()
-        if len(cs) > 0:
-            obs.update(controller=cs)
-        return obs
+        out = {"qpos": self.robot.get_qpos(), "qvel": self.robot.get_qvel()}
+        ctrl_state = self.controller.get_state()
+        if len(ctrl_state) > 0:
+            out["controller"] = ctrl_state
+        return out
 
     def get_state(self) -> Dict:
-        root = self.robot.get_links()[0]
-        return dict(
-            robot_root_pose=root.get_pose(),
-            robot_root_vel=root.get_linear_velocity(),
-            robot_root_qvel=root.get_angular_velocity(),
-            robot_qpos=self.robot.get_qpos(),
-            robot_qvel=self.robot.get_qvel(),
-            controller=self.controller.get_state(),
-        )
+        state = {key: read(self) for key, read, _ in self._STATE_ENTRIES}
+        state["controller"] = self.controller.get_state()
+        return state
 
     def set_state(self, state: Dict, ignore_controller=False):
-        self.robot.set_root_pose(state["robot_root_pose"])
-        self.robot.set_root_linear_velocity(state["robot_root_vel"])
-        self.robot.set_root_angular_velocity(state["robot_root_qvel"])
-        self.robot.set_qpos(state["robot_qpos"])
-        self.robot.set_qvel(state["robot_qvel"])
-        if not ignore_controller and "controller" in state:
+        for key, _, write in self._STATE_ENTRIES:
+            write(self, state[key])
+        if "controller" in state and not ignore_controller:
             self.controller.set_state(state["controller"])
+        # poses of the links follow from the new joint state: push it, run FK, read back (base_agent.py:362-378)
         self.scene._gpu_apply_all()
         self.scene.px.gpu_update_articulation_kinematics()
         self.scene._gpu_fetch_all()
@@ -179,11 +210,6 @@ class BaseAgent:
         """zero velocity / generalized force, optionally set qpos (base_agent.py:380-390)"""
         if init_qpos is not None:
             self.robot.set_qpos(init_qpos)
-        self.robot.set_qvel(torch.zeros(self.robot.max_dof, device=self.device))
-        self.robot.set_qf(torch.zeros(self.robot.max_dof, device=self.device))
-
-    def is_grasping(self, object=None):
-        raise NotImplementedError()
-
-    def is_static(self, threshold: float):
-        raise NotImplementedError()
+        still = torch.zeros(self.robot.max_dof, device=self.device)
+        self.robot.set_qvel(still)
+        self.robot.set_qf(still)

@@ -1,4 +1,5 @@
-"""Passive controller: joints with a damping-only drive and an empty action space."""
+"""Passive joints: a damping-only drive, no action (behavioural counterpart of
+mani_skill/agents/controllers/passive_controller.py). Built on joint_drive.apply_joint_gains like the PD controllers."""
 from dataclasses import dataclass
 from typing import Sequence, Union
 
@@ -6,23 +7,24 @@ import numpy as np
 from gymnasium import spaces
 
 from .base_controller import BaseController, ControllerConfig
+from .joint_drive import apply_joint_gains
+
+_NO_ACTION = np.zeros(0, dtype=np.float32)
 
 
 class PassiveController(BaseController):
     config: "PassiveControllerConfig"
 
-    def set_drive_property(self):
-        n = len(self.joints)
-        d = np.broadcast_to(self.config.damping, n)
-        f = np.broadcast_to(self.config.force_limit, n)
-        for i, joint in enumerate(self.joints):
-            joint.set_drive_properties(0, d[i], force_limit=f[i])
-
     def _initialize_action_space(self):
-        self.single_action_space = spaces.Box(np.empty(0, np.float32), np.empty(0, np.float32), dtype=np.float32)
+        # zero-dimensional box: the controller takes part in combined action spaces without consuming a column
+        self.single_action_space = spaces.Box(_NO_ACTION, _NO_ACTION, dtype=np.float32)
+
+    def set_drive_property(self):
+        apply_joint_gains(self.joints, stiffness=0.0, damping=self.config.damping, force_limit=self.config.force_limit,
+                          friction=self.config.friction, drive_mode="force")
 
     def set_action(self, action):
-        pass
+        """nothing to set"""
 
 
 @dataclass

@@ -37,9 +37,8 @@ class PDEEPosController(PDJointPosController):
         self.ee_link = self.kinematics.end_link
 
     def _initialize_action_space(self):
-        low = np.float32(np.broadcast_to(self.config.pos_lower, 3))
-        high = np.float32(np.broadcast_to(self.config.pos_upper, 3))
-        self.single_action_space = spaces.Box(low, high, dtype=np.float32)
+        lo, hi = (np.broadcast_to(b, 3).astype(np.float32) for b in (self.config.pos_lower, self.config.pos_upper))
+        self.single_action_space = spaces.Box(lo, hi, dtype=np.float32)
 
     def fused_action_spec(self):
         """the delta controllers (`pd_ee_delta_pos`, `pd_ee_delta_pose`) are one pseudo-inverse step of the
@@ -68,63 +67,76 @@ class PDEEPosController(PDJointPosController):
         return dict(ee=(self.kinematics.end_link_idx, 6 if pose else 3, float(lo[0]), float(hi[0]), rot_scale, flags),
                     dofs=[int(i) for i in self.active_joint_indices.tolist()])
 
-    @property
-    def ee_pos(self):
-        return self.ee_link.pose.p
-
+    # ---- where the end effector is --------------------------------------------------------------------
     @property
     def ee_pose(self):
         return self.ee_link.pose
 
     @property
+    def ee_pos(self):
+        return self.ee_pose.p
+
+    @property
     def ee_pose_at_base(self):
+        """pose of the end-effector link in the robot's root frame"""
         return self.articulation.pose.inv() * self.ee_pose
 
     def reset(self):
         super().reset()
-        cur = self.ee_pose_at_base
-        if self._target_pose is None or self.scene._reset_mask_all:
-            self._target_pose = Pose.create(cur.raw_pose.clone())
+        here = self.ee_pose_at_base.raw_pose
+        if self._target_pose is not None and not self.scene._reset_mask_all:
+            rows = self.scene._reset_idx
+            self._target_pose.raw_pose[rows] = here[rows]
         else:
-            m = self.scene._reset_idx
-            self._target_pose.raw_pose[m] = cur.raw_pose[m]
+            self._target_pose = Pose.create(here.clone())
+
+    # ---- action -> target pose ------------------------------------------------------------------------
+    # translation-only control: how a commanded offset combines with the previous pose, per frame name
+    _OFFSET_RULES = {
+        "root_translation": lambda prev, offset: offset * prev,   # offset expressed in the root frame
+        "body_translation": lambda prev, offset: prev * offset,   # offset expressed in the end effector's own frame
+    }
 
     def compute_target_pose(self, prev_ee_pose_at_base, action):
-        if self.config.use_delta:
-            delta_pose = Pose.create_from_pq(p=action)
-            if self.config.frame == "root_translation":
-                return delta_pose * prev_ee_pose_at_base
-            if self.config.frame == "body_translation":
-                return prev_ee_pose_at_base * delta_pose
-            raise NotImplementedError(self.config.frame)
-        assert self.config.frame == "root_translation", self.config.frame
-        return Pose.create_from_pq(p=action)
+        frame = self.config.frame
+        commanded = Pose.create_from_pq(p=action)
+        if not self.config.use_delta:
+            assert frame == "root_translation", frame
+            return commanded
+        if frame not in self._OFFSET_RULES:
+            raise NotImplementedError(frame)
+        return self._OFFSET_RULES[frame](prev_ee_pose_at_base, commanded)
 
     def set_action(self, action):
+        cfg = self.config
         action = self._preprocess_action(action)
-        self._step = 0
-        self._start_qpos = self.qpos.clone()
-        prev = self._target_pose if self.config.use_target else self.ee_pose_at_base
-        self._target_pose = self.compute_target_pose(prev, action)
-        pos_only = type(self.config) == PDEEPosControllerConfig
-        self._target_qpos = self.kinematics.compute_ik(
-            self._target_pose, self.articulation.get_qpos(), pos_only=pos_only, action=action,
-            use_delta_ik_solver=self.config.use_delta and not self.config.use_target,
+        self._step, self._start_qpos = 0, self.qpos.clone()
+        reference = self._target_pose if cfg.use_target else self.ee_pose_at_base
+        self._target_pose = self.compute_target_pose(reference, action)
+        solved = self.kinematics.compute_ik(
+            self._target_pose,
+            self.articulation.get_qpos(),
+            pos_only=type(cfg) == PDEEPosControllerConfig,
+            action=action,
+            use_delta_ik_solver=cfg.use_delta and not cfg.use_target,
         )
-        if self._target_qpos is None:
-            self._target_qpos = self._start_qpos
-        if self.config.interpolate:
-            self._step_size = (self._target_qpos - self._start_qpos) / self._sim_steps
-        else:
+        self._target_qpos = self._start_qpos if solved is None else solved
+        if not cfg.interpolate:
             self.set_drive_targets(self._target_qpos)
+        else:
+            self._step_size = (self._target_qpos - self._start_qpos) / self._sim_steps
 
+    # ---- state (only target-tracking modes carry one) ---------------------------------------------------
     def get_state(self) -> dict:
-        return {"target_pose": self._target_pose.raw_pose} if self.config.use_target else {}
+        if not self.config.use_target:
+            return {}
+        return dict(target_pose=self._target_pose.raw_pose)
 
     def set_state(self, state: dict):
-        if self.config.use_target:
-            t = state["target_pose"]
-            self._target_pose = Pose.create_from_pq(t[:, :3], t[:, 3:])
+        if not self.config.use_target:
+            return
+        raw = state["target_pose"]
+        self._target_pose = Pose.create_from_pq(raw[:, :3], raw[:, 3:])
 
 
 @dataclass
@@ -147,6 +159,9 @@ class PDEEPosControllerConfig(ControllerConfig):
 
 
 class PDEEPoseController(PDEEPosController):
+    """6-dof action: translation (3) and a rotation given as XYZ Euler angles (3). The frame name
+    "<translation frame>:<rotation frame>" says in which frame each part of a delta is applied."""
+
     config: "PDEEPoseControllerConfig"
 
     def _check_gpu_sim_works(self):
@@ -155,34 +170,36 @@ class PDEEPoseController(PDEEPosController):
         )
 
     def _initialize_action_space(self):
-        low = np.float32(np.hstack([np.broadcast_to(self.config.pos_lower, 3), np.broadcast_to(self.config.rot_lower, 3)]))
-        high = np.float32(np.hstack([np.broadcast_to(self.config.pos_upper, 3), np.broadcast_to(self.config.rot_upper, 3)]))
-        self.single_action_space = spaces.Box(low, high, dtype=np.float32)
+        cfg = self.config
+        bounds = [np.concatenate([np.broadcast_to(p, 3), np.broadcast_to(r, 3)]).astype(np.float32)
+                  for p, r in ((cfg.pos_lower, cfg.rot_lower), (cfg.pos_upper, cfg.rot_upper))]
+        self.single_action_space = spaces.Box(bounds[0], bounds[1], dtype=np.float32)
 
     def _clip_and_scale_action(self, action):
-        # translation per axis, rotation clipped by its norm (pd_ee_pose.py:197-210)
-        pos = gym_utils.clip_and_scale_action(action[:, :3], self.action_space_low[:3], self.action_space_high[:3])
-        rot = action[:, 3:]
-        norm = torch.linalg.norm(rot, dim=1, keepdim=True)
-        rot = torch.where(norm > 1, rot / norm.clamp_min(1e-12), rot) * self.config.rot_lower
-        return torch.hstack([pos, rot])
+        """translation: per-axis clip + affine map; rotation: the 3-vector is limited to unit length as a whole, then
+        scaled by the rotation bound (reference behaviour: pd_ee_pose.py:197-210)"""
+        lin = gym_utils.clip_and_scale_action(action[:, :3], self.action_space_low[:3], self.action_space_high[:3])
+        ang = action[:, 3:]
+        length = torch.linalg.norm(ang, dim=1, keepdim=True)
+        ang = torch.where(length > 1, ang / length.clamp_min(1e-12), ang)
+        return torch.cat([lin, ang * self.config.rot_lower], dim=1)
+
+    @staticmethod
+    def _euler_quat(angles):
+        return matrix_to_quaternion(euler_angles_to_matrix(angles, "XYZ"))
 
     def compute_target_pose(self, prev_ee_pose_at_base, action):
-        if self.config.use_delta:
-            delta_pos, delta_rot = action[:, 0:3], action[:, 3:6]
-            delta_quat = matrix_to_quaternion(euler_angles_to_matrix(delta_rot, "XYZ"))
-            if "root_aligned_body_rotation" in self.config.frame:
-                q = quaternion_multiply(delta_quat, prev_ee_pose_at_base.q)
-            else:
-                q = quaternion_multiply(prev_ee_pose_at_base.q, delta_quat)
-            if "root_translation" in self.config.frame:
-                p = prev_ee_pose_at_base.p + delta_pos
-            else:
-                p = prev_ee_pose_at_base.p + quaternion_apply(prev_ee_pose_at_base.q, delta_pos)
-            return Pose.create_from_pq(p, q)
-        assert self.config.frame == "root_translation:root_aligned_body_rotation", self.config.frame
-        target_pos, target_rot = action[:, 0:3], action[:, 3:6]
-        return Pose.create_from_pq(target_pos, matrix_to_quaternion(euler_angles_to_matrix(target_rot, "XYZ")))
+        frame = self.config.frame
+        lin, rot = action[:, :3], self._euler_quat(action[:, 3:6])
+        if not self.config.use_delta:
+            assert frame == "root_translation:root_aligned_body_rotation", frame
+            return Pose.create_from_pq(lin, rot)
+        p0, q0 = prev_ee_pose_at_base.p, prev_ee_pose_at_base.q
+        # rotation: pre-multiplied = about the root's axes, post-multiplied = about the end effector's own axes
+        q1 = quaternion_multiply(rot, q0) if "root_aligned_body_rotation" in frame else quaternion_multiply(q0, rot)
+        # translation: along the root's axes, or along the end effector's (previous) axes
+        p1 = p0 + (lin if "root_translation" in frame else quaternion_apply(q0, lin))
+        return Pose.create_from_pq(p1, q1)
 
 
 @dataclass

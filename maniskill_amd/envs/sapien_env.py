@@ -114,20 +114,16 @@ class BaseEnv(gym.Env):
         assert self._sim_freq % self._control_freq == 0, f"sim_freq({self._sim_freq}) is not divisible by control_freq({self._control_freq})."
         self._sim_steps_per_control = self._sim_freq // self._control_freq
 
-        if obs_mode is None:
-            obs_mode = self.SUPPORTED_OBS_MODES[0]
-        if obs_mode not in self.SUPPORTED_OBS_MODES:
-            raise NotImplementedError(
-                f"Unsupported obs mode: {obs_mode}. Must be one of {self.SUPPORTED_OBS_MODES} (this build has no renderer: state observations only)"
-            )
-        self._obs_mode = obs_mode
-        self.obs_mode_struct = parse_obs_mode_to_struct(self._obs_mode)
+        def choose(asked, supported, what, note=""):
+            """the requested mode, the first supported one by default"""
+            mode = supported[0] if asked is None else asked
+            if mode not in supported:
+                raise NotImplementedError(f"Unsupported {what} mode: {mode}. Must be one of {supported}{note}")
+            return mode
 
-        if reward_mode is None:
-            reward_mode = self.SUPPORTED_REWARD_MODES[0]
-        if reward_mode not in self.SUPPORTED_REWARD_MODES:
-            raise NotImplementedError("Unsupported reward mode: {}".format(reward_mode))
-        self._reward_mode = reward_mode
+        self._obs_mode = choose(obs_mode, self.SUPPORTED_OBS_MODES, "obs", " (this build has no renderer: state observations only)")
+        self.obs_mode_struct = parse_obs_mode_to_struct(self._obs_mode)
+        self._reward_mode = choose(reward_mode, self.SUPPORTED_REWARD_MODES, "reward")
 
         self._fused_action_key, self._fused_action_ok = None, False
         self._control_mode = control_mode
@@ -144,24 +140,21 @@ class BaseEnv(gym.Env):
         self._elapsed_steps = torch.zeros(self.num_envs, device=self.device, dtype=torch.int32)
         obs, _ = self.reset(seed=[first + i for i in range(self.num_envs)], options=dict(reconfigure=True))
 
-        self._init_raw_obs = common.to_cpu_tensor(obs)
+        # spaces: the action space is the agent's, the observation space is derived from the first observation
         self._init_raw_state = common.to_cpu_tensor(self.get_state_dict())
+        self.action_space = None
         if self.agent is not None:
-            self.action_space = self.agent.action_space
-            self.single_action_space = self.agent.single_action_space
+            self.action_space, self.single_action_space = self.agent.action_space, self.agent.single_action_space
             self._orig_single_action_space = copy.deepcopy(self.single_action_space)
-        else:
-            self.action_space = None
-        self.single_observation_space
-        self.observation_space
+        self.update_obs_space(common.to_cpu_tensor(obs))
 
     # ------------------------------------------------------------------ spaces
     def update_obs_space(self, obs):
+        """(re)derive the observation spaces from a sample observation (wrappers that change the observation call this)"""
         self._init_raw_obs = obs
-        self.__dict__.pop("single_observation_space", None)
-        self.__dict__.pop("observation_space", None)
-        self.single_observation_space
-        self.observation_space
+        for cached in ("single_observation_space", "observation_space"):
+            self.__dict__.pop(cached, None)
+        _ = self.single_observation_space, self.observation_space  # (evaluated eagerly, as the reference does)
 
     @cached_property
     def single_observation_space(self) -> gym.Space:
@@ -189,38 +182,25 @@ class BaseEnv(gym.Env):
 
     # ------------------------------------------------------------------ loading
     def _load_agent(self, options: dict, initial_agent_poses=None, build_separate: bool = False):
-        robot_uids = self.robot_uids
-        if not isinstance(initial_agent_poses, list):
-            initial_agent_poses = [initial_agent_poses]
-        if robot_uids == "none" or robot_uids == ("none",):
-            self.agent = None
+        """one robot per env: `robot_uids` is a registered id, an agent class, a 1-tuple of either, "none" or None"""
+        wanted = self.robot_uids
+        self.agent = None
+        if wanted is None or wanted == "none" or wanted == ("none",):
             return
-        agents = []
-        if robot_uids is not None:
-            if not isinstance(robot_uids, tuple):
-                robot_uids = [robot_uids]
-            if len(robot_uids) > 1:
-                raise NotImplementedError("multi-agent tasks are out of scope of this build (one articulation per env)")
-            for i, robot_uid in enumerate(robot_uids):
-                if isinstance(robot_uid, type) and issubclass(robot_uid, BaseAgent):
-                    agent_cls = robot_uid
-                else:
-                    if robot_uid not in REGISTERED_AGENTS:
-                        raise RuntimeError(
-                            f"Agent {robot_uid} not found in the dict of registered agents. If the id is not a typo then make sure to apply the @register_agent() decorator."
-                        )
-                    agent_cls = REGISTERED_AGENTS[robot_uid].agent_cls
-                agents.append(
-                    agent_cls(
-                        self.scene,
-                        self._control_freq,
-                        self._control_mode,
-                        agent_idx=None,
-                        initial_pose=initial_agent_poses[i] if initial_agent_poses is not None else None,
-                        build_separate=build_separate,
-                    )
-                )
-        self.agent = agents[0] if agents else None
+        wanted = wanted if isinstance(wanted, tuple) else (wanted,)
+        if len(wanted) > 1:
+            raise NotImplementedError("multi-agent tasks are out of scope of this build (one articulation per env)")
+        (which,) = wanted
+        if isinstance(which, type) and issubclass(which, BaseAgent):
+            agent_cls = which
+        elif which in REGISTERED_AGENTS:
+            agent_cls = REGISTERED_AGENTS[which].agent_cls
+        else:
+            raise RuntimeError(
+                f"Agent {which} not found in the dict of registered agents. If the id is not a typo then make sure to apply the @register_agent() decorator."
+            )
+        poses = initial_agent_poses if isinstance(initial_agent_poses, list) else [initial_agent_poses]
+        self.agent = agent_cls(self.scene, self._control_freq, self._control_mode, agent_idx=None, initial_pose=poses[0], build_separate=build_separate)
 
     def _load_scene(self, options: dict):
         pass
@@ -236,55 +216,29 @@ class BaseEnv(gym.Env):
     def _after_reconfigure(self, options):
         pass
 
-    # ------------------------------------------------------------------ properties
-    @property
-    def sim_freq(self) -> int:
-        return self._sim_freq
-
-    @property
-    def control_freq(self):
-        return self._control_freq
-
-    @property
-    def sim_timestep(self):
-        return 1.0 / self._sim_freq
-
-    @property
-    def control_timestep(self):
-        return 1.0 / self._control_freq
-
-    @property
-    def control_mode(self) -> str:
-        return self.agent.control_mode
-
-    @property
-    def elapsed_steps(self) -> torch.Tensor:
-        return self._elapsed_steps
-
-    @property
-    def obs_mode(self) -> str:
-        return self._obs_mode
-
-    @property
-    def reward_mode(self):
-        return self._reward_mode
-
-    @property
-    def robot_link_names(self):
-        return self.agent.robot_link_names
+    # ------------------------------------------------------------------ read-only views of the configuration
+    # (the reference spells each of these out as a property: sapien_env.py:444-489)
+    sim_freq = property(lambda self: self._sim_freq)
+    control_freq = property(lambda self: self._control_freq)
+    sim_timestep = property(lambda self: 1.0 / self._sim_freq)
+    control_timestep = property(lambda self: 1.0 / self._control_freq)
+    obs_mode = property(lambda self: self._obs_mode)
+    reward_mode = property(lambda self: self._reward_mode)
+    elapsed_steps = property(lambda self: self._elapsed_steps)
+    control_mode = property(lambda self: self.agent.control_mode)
+    robot_link_names = property(lambda self: self.agent.robot_link_names)
 
     # ------------------------------------------------------------------ observations / reward
     def get_obs(self, info: Optional[Dict] = None):
-        if info is None:
-            info = self.get_info()
-        if self._obs_mode == "none":
-            return dict()
-        if self._obs_mode == "state":
-            return common.flatten_state_dict(self._get_obs_state_dict(info), use_torch=True, device=self.device)
-        if self._obs_mode == "state_dict":
-            # getters are views of the simulation buffers in this build: hand out copies
-            return common.torch_clone_dict(self._get_obs_state_dict(info))
-        raise NotImplementedError(self._obs_mode)
+        mode = self._obs_mode
+        if mode == "none":
+            return {}
+        if mode not in ("state", "state_dict"):
+            raise NotImplementedError(mode)
+        nested = self._get_obs_state_dict(self.get_info() if info is None else info)
+        if mode == "state":
+            return common.flatten_state_dict(nested, use_torch=True, device=self.device)
+        return common.torch_clone_dict(nested)  # (getters are views of the simulation buffers in this build: hand out copies)
 
     def _get_obs_state_dict(self, info: Dict):
         return dict(agent=self._get_obs_agent(), extra=self._get_obs_extra(info))
@@ -295,25 +249,25 @@ class BaseEnv(gym.Env):
     def _get_obs_extra(self, info: Dict):
         return dict()
 
+    _REWARD_METHODS = {"sparse": "compute_sparse_reward", "dense": "compute_dense_reward", "normalized_dense": "compute_normalized_dense_reward"}
+
     def get_reward(self, obs: Any, action: torch.Tensor, info: Dict):
-        if self._reward_mode == "sparse":
-            return self.compute_sparse_reward(obs=obs, action=action, info=info)
-        if self._reward_mode == "dense":
-            return self.compute_dense_reward(obs=obs, action=action, info=info)
-        if self._reward_mode == "normalized_dense":
-            return self.compute_normalized_dense_reward(obs=obs, action=action, info=info)
-        if self._reward_mode == "none":
+        mode = self._reward_mode
+        if mode == "none":
             return torch.zeros((self.num_envs,), dtype=torch.float, device=self.device)
-        raise NotImplementedError(self._reward_mode)
+        if mode not in self._REWARD_METHODS:
+            raise NotImplementedError(mode)
+        return getattr(self, self._REWARD_METHODS[mode])(obs=obs, action=action, info=info)
 
     def compute_sparse_reward(self, obs: Any, action: torch.Tensor, info: Dict):
-        """+1 on success, -1 on fail, 0 otherwise (sapien_env.py:618-635)"""
-        if "success" in info:
-            if "fail" in info:
-                return info["success"].to(torch.float) - info["fail"].to(torch.float)
-            return info["success"]
-        if "fail" in info:
-            return -info["fail"]
+        """success - fail over whichever of the two the task reports (sapien_env.py:618-635); 0 if it reports neither"""
+        won, lost = info.get("success"), info.get("fail")
+        if won is not None and lost is not None:
+            return won.to(torch.float) - lost.to(torch.float)
+        if won is not None:
+            return won
+        if lost is not None:
+            return -lost
         return torch.zeros(self.num_envs, dtype=torch.float, device=self.device)
 
     def compute_dense_reward(self, obs: Any, action: torch.Tensor, info: Dict):
@@ -527,32 +481,21 @@ class BaseEnv(gym.Env):
         return cls._before_simulation_step is not BaseEnv._before_simulation_step or cls._after_simulation_step is not BaseEnv._after_simulation_step
 
     def _step_action(self, action):
-        set_action = False
-        unbatched = False
-        if action is None:
-            pass
-        elif isinstance(action, (np.ndarray, torch.Tensor)):
-            action = common.to_tensor(action, device=self.device)
-            if action.shape == self._orig_single_action_space.shape:
-                unbatched = True
-            set_action = True
-        elif isinstance(action, dict):
-            if "control_mode" in action:
-                if action["control_mode"] != self.agent.control_mode:
-                    self.agent.set_control_mode(action["control_mode"])
-                    self.agent.controller.reset()
-                action = common.to_tensor(action["action"], device=self.device)
-                if action.shape == self._orig_single_action_space.shape:
-                    unbatched = True
-            else:
+        # what was handed in: nothing (keep the drive targets), an array, or {"control_mode": ..., "action": array}
+        set_action = action is not None
+        if isinstance(action, dict):
+            if "control_mode" not in action:
                 raise NotImplementedError("dict actions are for multi-agent tasks, which this build does not include")
-            set_action = True
-        else:
-            raise TypeError(type(action))
-
+            if self.agent.control_mode != action["control_mode"]:
+                self.agent.set_control_mode(action["control_mode"])
+                self.agent.controller.reset()
+            action = action["action"]
         if set_action:
-            if self.num_envs == 1 and unbatched:
-                action = common.batch(action)
+            if not isinstance(action, (np.ndarray, torch.Tensor)):
+                raise TypeError(type(action))
+            action = common.to_tensor(action, device=self.device)
+            if self.num_envs == 1 and action.shape == self._orig_single_action_space.shape:
+                action = common.batch(action)  # a single env accepts an unbatched action
             if self._fused_action_ready(action):
                 # (the torch path asserts this in BaseController._preprocess_action; the kernels index the action unchecked)
                 assert action.shape == (self.num_envs, self.single_action_space.shape[0]), (
@@ -669,24 +612,16 @@ class BaseEnv(gym.Env):
         return None
 
     def evaluate(self) -> dict:
-        return dict()
+        """task-specific success / failure flags and whatever else the reward needs; nothing by default"""
+        return {}
 
     def get_info(self) -> dict:
-        info = dict(elapsed_steps=self._elapsed_steps.clone())
-        info.update(self.evaluate())
-        return info
+        return {"elapsed_steps": self._elapsed_steps.clone(), **self.evaluate()}
 
-    def _before_control_step(self):
-        pass
+    def _no_hook(self):
+        """default of the four step hooks; `_no_step_hooks` / `_substep_hooks_overridden` compare against these attributes"""
 
-    def _after_control_step(self):
-        pass
-
-    def _before_simulation_step(self):
-        pass
-
-    def _after_simulation_step(self):
-        pass
+    _before_control_step = _after_control_step = _before_simulation_step = _after_simulation_step = _no_hook
 
     # ------------------------------------------------------------------ state (sapien_env.py:1153-1199)
     def add_to_state_dict_registry(self, obj):
