@@ -744,3 +744,47 @@ def test_triangle_mesh_matches_oracle():
             assert torch.max(torch.abs(a["rb"][row, :, :3] - b["rb"][row, :, :3])) < 1e-4, i
     assert torch.max(torch.abs(a["rb"][row, :, :3] - b["rb"][row, :, :3])) < 2e-2  # (rolling: the two stay together to centimetres over 2 s)
     assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
+
+
+def test_triangle_mesh_next_to_the_panda_matches_oracle():
+    """the Panda variant of the mesh kernel (k_solve16<9, 0, true>): the tabletop scene with a ribbed triangle-mesh mat on the
+    table; the cube dropped on it and the arm lowered onto it (link hulls and finger boxes against triangles) stay with the
+    oracle"""
+    from maniskill_amd.model import geom
+    from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+    from tests.test_oracle_contacts import _grid_mesh
+
+    V, F = _grid_mesh(n=6, size=0.5, height=lambda x, y: 0.004 * np.cos(25 * x))
+    b = SceneModelBuilder()
+    b.set_articulation(panda_record())
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(ActorRecord("mat", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)], initial_pose=geom.pose([0.05, 0, 0.006])))
+    b.add_actor(cube_record(p=(0.05, 0.0, 0.05)))
+    model = b.compile(sleep_threshold=0.0)
+    N = 8
+    gpu, cpu = make_pair(model, N)
+    q = REST.clone().repeat(N, 1)
+    q[:, 1] += torch.linspace(0.0, 0.27, N)  # shoulder lowered more and more: the fingers end just above the mat and are driven onto it
+    tq = q.clone()
+    tq[:, 1] += 0.3
+    cube = torch.zeros(N, 13)
+    cube[:, 0] = 0.05 + torch.linspace(-0.1, 0.1, N)
+    cube[:, 2] = 0.05
+    cube[:, 3] = 1.0
+    for px in (gpu, cpu):
+        set_state(px, model, N, q=q, qd=torch.zeros(N, 9), tq=tq, cube=cube)
+        px.wake_all()
+    row = model.row_of("cube")
+    agree = 0
+    for i in range(25):
+        for px in (gpu, cpu):
+            px.step(1)
+        a, b2 = get_state(gpu, model, N), get_state(cpu, model, N)
+        agree += int((a["cnt"].sum(0) == b2["cnt"].sum(0)).sum())
+        assert torch.max(torch.abs(a["q"] - b2["q"])) < 2e-3 and torch.max(torch.abs(a["rb"][row, :, :3] - b2["rb"][row, :, :3])) < 2e-3, (i, torch.abs(a["q"] - b2["q"]).max(dim=1).values)
+    assert agree >= 0.85 * 25 * N, agree
+    for st in (a, b2):
+        assert torch.all(st["rb"][row, :, 2] > 0.02) and torch.all(st["rb"][row, :, 2] < 0.04)  # the cube lies on the mat (6 mm + ribs above the table)
+        assert float(st["cnt"].sum()) > 4 * N
+    assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
