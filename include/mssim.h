@@ -95,6 +95,7 @@ extern "C" {
 #define MSSIM_MAX_FREE 8        /* max free (dynamic, non-articulated) bodies per env     */
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
 #define MSSIM_MAX_HULL_VERTS 64 /* per convex hull (PhysX GPU-compatible hull limit)      */
+#define MSSIM_TRI_SLACK 4e-3f    /* m: a convex shape's points this much higher above a triangle's plane than its lowest one give no contact */
 #define MSSIM_MAX_TRI_HITS 32   /* triangles of one mesh in range of one convex shape at a time (more: reported overflow) */
 /* Contact patches. A compound body (the Panda finger: 4 boxes, panda_v3.urdf:244-283; the box with a hole: 4 boxes,
  * envs/tasks/tabletop/peg_insertion_side.py:150-181) touching another compound body yields one <= 4-point manifold per
@@ -137,11 +138,15 @@ enum {
                               actor_builder.py:136-150): shape_hull = (root node in tri_bvh, triangle count). Every
                               triangle is a 3-vertex hull; a convex shape near the mesh is tested against the triangles
                               whose boxes lie within its bounding sphere + contact offset (found through the 16-wide BVH),
-                              in index order; each gives a manifold of up to 4 points (the plain query + three queries
-                              with the convex shape tilted by MSSIM_PCM_TILT about three axes in the contact plane) with
-                              the triangle's FACE normal whenever the query's normal is within 60 degrees of it (no
-                              tripping over inner edges), points whose foot lies outside the triangle left to its
-                              neighbour; the contact patches merge the manifolds of coplanar triangles. At most
+                              in index order. A triangle is a bounded piece of its plane (face normal on the side of the
+                              convex shape's centre): the shape's plane-contact points (box corners, capsule ends, hull
+                              vertices, ...) whose gap is within the contact offset and within MSSIM_TRI_SLACK of the
+                              shape's lowest point and whose foot lies in the triangle, plus -- for a box -- the
+                              triangle's corners under the box; the 4 deepest, exact gaps, no tripping over inner edges
+                              (a point over the neighbouring triangle is that triangle's). Only when there is no such
+                              point the generic query runs (interior point: the triangle's point nearest to the shape's
+                              centre): from the side it keeps its normal, within 60 degrees of the face normal it takes
+                              the face normal. The contact patches merge the manifolds of coplanar triangles. At most
                               MSSIM_MAX_TRI_HITS triangles per shape pair.                                          */
 };
 /* what a shape / body row is attached to */

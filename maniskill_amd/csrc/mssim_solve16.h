@@ -1281,11 +1281,30 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const f3 e0 = q1 - q0, e1 = q2 - q0;
           const float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
           const float den = d00 * d11 - d01 * d01, tol = MSSIM_PCM_MERGE * rsq_f(fminf(d00, d11));
+          // (box A) where the line o + t nf enters the box, in the box frame against its three slabs: the gap between a point
+          // o of the triangle's plane and the box above it; false: the line misses the box or the gap is beyond the offset
+          auto box_above = [&](f3 o, float& t_in) __attribute__((always_inline)) {
+            const f3 dl = mtmulv(A.rot, nf), ol = mtmulv(A.rot, o - A.c);
+            float t_out = 1e30f;
+            bool miss = false;
+            t_in = -1e30f;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              const float hb = a == 0 ? A.p0 : (a == 1 ? A.p1 : A.p2), ov = comp(ol, a), dv = comp(dl, a);
+              const bool par = fabsf(dv) < 1e-9f;
+              miss = miss || (par && fabsf(ov) > hb);
+              const float t0 = (-hb - ov) / dv, t1 = (hb - ov) / dv;
+              t_in = par ? t_in : fmaxf(t_in, fminf(t0, t1));
+              t_out = par ? t_out : fminf(t_out, fmaxf(t0, t1));
+            }
+            return !miss && t_in <= t_out && t_in < offset;
+          };
           // candidates of this lane, at most 4 (hull vertices c, c + 16, ..); id = their place in the oracle's order:
           // (1) A's plane-contact points over the triangle, 0..63; (2) the triangle's corners under a box, 64..66
           f3 X[4];
           float Sp[4];
           bool ok[4];
+          float s_low = 3e38f;  // gap of A's lowest plane-contact point (this lane's share; reduced over the group below)
 #pragma unroll
           for (int k = 0; k < 4; k++) { X[k] = f3{0, 0, 0}; Sp[k] = 3e38f; ok[k] = false; }
           auto cand1 = [&](int k, f3 p, float radius, bool exists) __attribute__((always_inline)) {
@@ -1296,24 +1315,16 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             ok[k] = exists && sgap < offset && !(v < -tol || w < -tol || v + w > 1.f + tol);
             X[k] = p - nf * (radius + 0.5f * sgap);
             Sp[k] = sgap;
+            s_low = fminf(s_low, exists ? sgap : 3e38f);
           };
           if (A.type == SH_BOX) {
             cand1(0, A.c + mmulv(A.rot, f3{(c & 1) ? A.p0 : -A.p0, (c & 2) ? A.p1 : -A.p1, (c & 4) ? A.p2 : -A.p2}), 0.f, c < 8);
-            // the triangle's corner (c - 8) under the box: the line corner + t nf in the box frame against the three slabs
+            // the triangle's corner (c - 8) under the box
             const f3 qc = c == 8 ? q0 : (c == 9 ? q1 : q2);
-            const f3 ol = mtmulv(A.rot, qc - A.c), dl = mtmulv(A.rot, nf);
-            float t_in = -1e30f, t_out = 1e30f;
-            bool miss = false;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const float hb = a == 0 ? A.p0 : (a == 1 ? A.p1 : A.p2), ov = comp(ol, a), dv = comp(dl, a);
-                if (fabsf(dv) < 1e-9f) { miss = miss || fabsf(ov) > hb; continue; }
-                const float t0 = (-hb - ov) / dv, t1 = (hb - ov) / dv;
-                t_in = fmaxf(t_in, fminf(t0, t1));
-                t_out = fminf(t_out, fmaxf(t0, t1));
-            }
+            float t_in;
+            const bool above = box_above(qc, t_in);
             if (c >= 8 && c < 11) {
-              ok[1] = !(miss || t_in > t_out || !(t_in < offset));
+              ok[1] = above;
               X[1] = qc + nf * (0.5f * t_in);
               Sp[1] = t_in;
             }
@@ -1328,6 +1339,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           } else {
             cand1(0, support(A, -nf), 0.f, c == 0);
           }
+          // points much higher above the plane than A's lowest one give no contact (MSSIM_TRI_SLACK, see the oracle); the
+          // triangle's corners under a box (slot 1 of lanes 8..10) are held to the same bound
+          s_low = -gmax16(-s_low);
+#pragma unroll
+          for (int k = 0; k < 4; k++) ok[k] = ok[k] && Sp[k] <= s_low + MSSIM_TRI_SLACK;
           // candidate ids: (1) box corner / capsule end / hull vertex index; (2) 64 + corner
           auto cid = [&](int k) __attribute__((always_inline)) { return (A.type == SH_BOX && k == 1) ? 64 + (c - 8) : c + 16 * k; };
           // the 4 deepest, the lowest id among equals first (the oracle's keep4_deepest)
@@ -1372,10 +1388,19 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             if (has && cnt == 0) collide_mpr_t(A, Tr, offset, gq, sup, true, inside);
             if (has && cnt == 0 && gq.count > 0) {
               const bool face = dot(nf, gq.n) > 0.5f;
-              if (!(face && A.type == SH_BOX)) {  // (a box's corners and the corners under it are complete: see the oracle)
-                nrm = face ? nf : gq.n;
-                mx[0] = gq.x[0]; msep[0] = gq.sep[0];
-                cnt = 1;
+              nrm = face ? nf : gq.n;
+              mx[0] = gq.x[0]; msep[0] = gq.sep[0];
+              cnt = 1;
+              if (face && A.type == SH_BOX) {
+                // a box face across an edge of the mesh: the query's point is approximate; its foot on the triangle's plane,
+                // if in the triangle, is measured against the box exactly (see the oracle)
+                const f3 foot = gq.x[0] - nf * dot(gq.x[0] - q0, nf), dd = foot - q0;
+                const float d20 = dot(dd, e0), d21 = dot(dd, e1);
+                const float v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
+                float t_in;
+                const bool above = box_above(foot, t_in);
+                if (v < -tol || w < -tol || v + w > 1.f + tol || !above) cnt = 0;
+                mx[0] = foot + nf * (0.5f * t_in); msep[0] = t_in;
               }
             }
           }

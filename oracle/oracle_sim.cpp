@@ -326,7 +326,7 @@ void select4(int n, const Vec* x, const Real* sep, const Vec& na, char* keep) {
 //      box within the contact offset) -- a face larger than the triangle, a box lying across a narrow strip or over a rim;
 //  the 4 deepest of (1) and (2), exact gaps. Only when both are empty the generic query runs, with the triangle's point
 //  nearest to A's centre as its interior point: contacts from the side (the rim of a mesh) keep its normal; an answer within
-//  60 degrees of the face normal takes the face normal -- for shapes other than boxes, whose (1) + (2) are complete.
+//  60 degrees of the face normal takes the face normal (for a box with the gap measured exactly at the point's foot).
 void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manifold<Real>& m, int& queries) {
   m.count = 0;
   const Vec q[3] = {T.c + T.rot * Vec(T.verts[0], T.verts[1], T.verts[2]), T.c + T.rot * Vec(T.verts[3], T.verts[4], T.verts[5]),
@@ -339,9 +339,32 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
   Vec pts[72];
   Real seps[72];
   int n = 0;
+  // (box A) where the line o + t nf enters the box, in the box frame against its three slabs: the gap between a point o of
+  // the triangle's plane and the box above it; false if the line misses the box or the gap is beyond the contact offset
+  auto box_above = [&](const Vec& o, Real& t_in) {
+    const Vec dl = A.rot.tmul(nf), ol = A.rot.tmul(o - A.c);
+    const Real hb[3] = {A.param[0], A.param[1], A.param[2]}, dv[3] = {dl.x, dl.y, dl.z}, ov[3] = {ol.x, ol.y, ol.z};
+    Real t_out = Real(1e30);
+    t_in = Real(-1e30);
+    for (int a = 0; a < 3; a++) {
+      if (std::fabs(dv[a]) < Real(1e-9)) {
+        if (std::fabs(ov[a]) > hb[a]) return false;
+        continue;
+      }
+      const Real t0 = (-hb[a] - ov[a]) / dv[a], t1 = (hb[a] - ov[a]) / dv[a];
+      t_in = std::max(t_in, std::min(t0, t1));
+      t_out = std::min(t_out, std::max(t0, t1));
+    }
+    return t_in <= t_out && t_in < offset;
+  };
+  // Points much higher above the plane than A's lowest one are left out (MSSIM_TRI_SLACK): the contact offset would admit
+  // them as speculative contacts, but in the patch reduction -- which goes by extent, not by depth -- they would crowd out
+  // the points that carry the load. A's lowest point itself is always a candidate: the first touch stays speculative.
+  Real s_low = Real(1e30);
+  auto lowest = [&](const Vec& p, Real radius) { s_low = std::min(s_low, dot(nf, p - q[0]) - radius); };
   auto add = [&](const Vec& p, Real radius) {
     const Real s = dot(nf, p - q[0]) - radius;
-    if (!(s < offset) || n >= 64) return;
+    if (!(s < offset) || !(s <= s_low + Real(MSSIM_TRI_SLACK)) || n >= 64) return;
     const Vec d = p - nf * (radius + s) - q[0];  // the foot of the surface point on the triangle's plane
     const Real d20 = dot(d, e0), d21 = dot(d, e1);
     const Real v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
@@ -351,36 +374,35 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
     n++;
   };
   if (A.type == SH_BOX) {
-    for (int i = 0; i < 8; i++)
-      add(A.c + A.rot * Vec((i & 1) ? A.param[0] : -A.param[0], (i & 2) ? A.param[1] : -A.param[1], (i & 4) ? A.param[2] : -A.param[2]), Real(0));
-    // (2) the triangle's corners under the box: the line corner + t nf in the box frame against the three slabs
-    const Vec dl = A.rot.tmul(nf);
-    const Real hb[3] = {A.param[0], A.param[1], A.param[2]}, dv[3] = {dl.x, dl.y, dl.z};
+    Vec corner[8];
+    for (int i = 0; i < 8; i++) {
+      corner[i] = A.c + A.rot * Vec((i & 1) ? A.param[0] : -A.param[0], (i & 2) ? A.param[1] : -A.param[1], (i & 4) ? A.param[2] : -A.param[2]);
+      lowest(corner[i], Real(0));
+    }
+    for (int i = 0; i < 8; i++) add(corner[i], Real(0));
+    // (2) the triangle's corners under the box
     for (int i = 0; i < 3; i++) {
-      const Vec ol = A.rot.tmul(q[i] - A.c);
-      const Real ov[3] = {ol.x, ol.y, ol.z};
-      Real t_in = Real(-1e30), t_out = Real(1e30);
-      bool miss = false;
-      for (int a = 0; a < 3; a++) {
-        if (std::fabs(dv[a]) < Real(1e-9)) { miss = miss || std::fabs(ov[a]) > hb[a]; continue; }
-        const Real t0 = (-hb[a] - ov[a]) / dv[a], t1 = (hb[a] - ov[a]) / dv[a];
-        t_in = std::max(t_in, std::min(t0, t1));
-        t_out = std::min(t_out, std::max(t0, t1));
-      }
-      if (miss || t_in > t_out || !(t_in < offset)) continue;
+      Real t_in;
+      if (!box_above(q[i], t_in) || !(t_in <= s_low + Real(MSSIM_TRI_SLACK))) continue;
       pts[n] = q[i] + nf * (Real(0.5) * t_in);
       seps[n] = t_in;
       n++;
     }
   } else if (A.type == SH_SPHERE) {
+    lowest(A.c, A.param[0]);
     add(A.c, A.param[0]);
   } else if (A.type == SH_CAPSULE) {
     const Vec ax = A.rot.col(0) * A.param[1];
+    lowest(A.c - ax, A.param[0]);
+    lowest(A.c + ax, A.param[0]);
     add(A.c - ax, A.param[0]);
     add(A.c + ax, A.param[0]);
   } else if (A.type == SH_CONVEX) {
-    for (int i = 0; i < A.nverts && i < 64; i++) add(A.c + A.rot * Vec(Real(A.verts[3 * i]), Real(A.verts[3 * i + 1]), Real(A.verts[3 * i + 2])), Real(0));
+    const int nv = A.nverts < 64 ? A.nverts : 64;
+    for (int i = 0; i < nv; i++) lowest(A.c + A.rot * Vec(Real(A.verts[3 * i]), Real(A.verts[3 * i + 1]), Real(A.verts[3 * i + 2])), Real(0));
+    for (int i = 0; i < nv; i++) add(A.c + A.rot * Vec(Real(A.verts[3 * i]), Real(A.verts[3 * i + 1]), Real(A.verts[3 * i + 2])), Real(0));
   } else {
+    lowest(support(A, -nf), Real(0));
     add(support(A, -nf), Real(0));
   }
   m.n = nf;
@@ -397,13 +419,23 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
   collide_mpr(A, T, offset, g, &inside);
   if (g.count == 0) return;
   const bool face = dot(nf, g.n) > Real(0.5);
-  // (a box has no use for a face-normal answer here: its corners and the triangle's corners under it are exact and complete,
-  // and what the query adds next to them -- points just beside the box -- would displace true corners in the patch reduction)
-  if (face && A.type == SH_BOX) return;
-  m.count = 1;
   m.n = face ? nf : g.n;
   m.x[0] = g.x[0];
   m.sep[0] = g.sep[0];
+  if (face && A.type == SH_BOX) {
+    // a box face across an edge of the mesh (no corner of either over / under the other): the query's point is only
+    // approximate -- next to exact corner points of the neighbouring triangles it would displace them in the patch
+    // reduction with a gap that is off by millimetres. Its foot on the triangle's plane, if in the triangle, is measured
+    // against the box exactly instead.
+    const Vec foot = g.x[0] - nf * dot(g.x[0] - q[0], nf), d = foot - q[0];
+    const Real d20 = dot(d, e0), d21 = dot(d, e1);
+    const Real v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
+    Real t_in;
+    if (v < -tol || w < -tol || v + w > Real(1) + tol || !box_above(foot, t_in)) return;
+    m.x[0] = foot + nf * (Real(0.5) * t_in);
+    m.sep[0] = t_in;
+  }
+  m.count = 1;
 }
 
 // generic convex pair through the persistent manifold cache (include/mssim.h, MSSIM_PCM_*)

@@ -788,3 +788,80 @@ def test_triangle_mesh_next_to_the_panda_matches_oracle():
         assert torch.all(st["rb"][row, :, 2] > 0.02) and torch.all(st["rb"][row, :, 2] < 0.04)  # the cube lies on the mat (6 mm + ribs above the table)
         assert float(st["cnt"].sum()) > 4 * N
     assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_object_sets_on_random_terrain_stay_finite_and_close_to_the_oracle(seed):
+    """stress of the round-2 geometry paths together: a random height-field mesh, a merged object whose shape type / size /
+    hull / presence is drawn per env (box, sphere, capsule, hull, two-box compound, nothing), random drops. Both sides stay
+    finite, report no overflow, keep every existing object above the terrain, leave absent objects where they were put, and
+    the HIP kernel stays close to the oracle for the first substeps (before tumbling amplifies rounding)"""
+    from scipy.spatial import ConvexHull
+
+    from maniskill_amd.model import geom
+    from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+    from tests.test_oracle_contacts import _grid_mesh
+
+    rng = np.random.default_rng(100 + seed)
+    N = 16
+    amp, kx, ky = 0.02 * rng.random(), 6 + 6 * rng.random(), 6 + 6 * rng.random()
+    height = lambda x, y: amp * (np.sin(kx * x) + np.cos(ky * y))
+    V, F = _grid_mesh(n=10, size=0.8, height=height)
+
+    def random_shapes():
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            return [ShapeRecord("box", geom.pose(), half_size=0.015 + 0.02 * rng.random(3))]
+        if kind == 1:
+            return [ShapeRecord("sphere", geom.pose(), radius=0.02 + 0.02 * rng.random())]
+        if kind == 2:
+            return [ShapeRecord("capsule", geom.pose(), radius=0.015 + 0.01 * rng.random(), half_length=0.02 + 0.03 * rng.random())]
+        if kind == 3:
+            pts = rng.normal(size=(20, 3))
+            pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * (0.02 + 0.02 * rng.random(3))
+            return [ShapeRecord("convex", geom.pose(), vertices=np.ascontiguousarray(pts[ConvexHull(pts).vertices]))]
+        if kind == 4:
+            return [ShapeRecord("box", geom.pose(), half_size=np.array([0.04, 0.012, 0.012])),
+                    ShapeRecord("box", geom.pose([0, 0, 0.024]), half_size=np.array([0.012, 0.012, 0.012]))]
+        return []
+
+    env_shapes = [random_shapes() for _ in range(N)]
+    if not env_shapes[0]:
+        env_shapes[0] = [ShapeRecord("sphere", geom.pose(), radius=0.03)]
+    present = torch.tensor([len(s) > 0 for s in env_shapes])
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("terrain", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)]))
+    b.add_actor(ActorRecord("obj", "dynamic", list(env_shapes[0]), initial_pose=geom.pose([0, 0, 0.15]), env_shapes=env_shapes))
+    model = b.compile(num_envs=N)
+    gpu, cpu = make_pair(model, N)
+    row = model.row_of("obj")
+    g = torch.Generator().manual_seed(seed)
+    quat = torch.randn(N, 4, generator=g)
+    quat = quat / quat.norm(dim=1, keepdim=True)
+    xy = 0.5 * torch.rand(N, 2, generator=g) - 0.25
+    for px in (gpu, cpu):
+        s = px.cuda_rigid_body_data.torch()[row * N : (row + 1) * N]
+        s[:, :2] = xy.to(px.device)
+        s[:, 2] = 0.12
+        s[:, 3:7] = quat.to(px.device)
+        px.gpu_apply_all()
+        px.wake_all()
+    start = get_state(cpu, model, N)["rb"][row].clone()
+    for i in range(12):
+        for px in (gpu, cpu):
+            px.step(1)
+        a, b2 = get_state(gpu, model, N), get_state(cpu, model, N)
+        assert torch.isfinite(a["rb"]).all() and torch.isfinite(b2["rb"]).all()
+        if i < 6:
+            assert torch.max(torch.abs(a["rb"][row, :, :3] - b2["rb"][row, :, :3])) < 1e-3, i
+    for px in (gpu, cpu):
+        px.step(150)
+    for px in (gpu, cpu):
+        st = get_state(px, model, N)
+        p = st["rb"][row, :, :3].double().numpy()
+        assert np.isfinite(p).all()
+        on_mesh = (np.abs(p[:, 0]) < 0.4) & (np.abs(p[:, 1]) < 0.4) & present.numpy()
+        assert np.all(p[on_mesh, 2] > height(p[on_mesh, 0], p[on_mesh, 1]) + 0.005), p  # resting on the terrain, not in it
+        gone = ~present
+        assert torch.allclose(st["rb"][row, gone, :7], start[gone, :7])  # an object that is not there does not move
+        assert px.overflow_count() == 0

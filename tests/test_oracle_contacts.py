@@ -641,3 +641,35 @@ def test_triangle_mesh_terrain_holds_a_rolling_ball():
     assert max(np.diff(energy)) < 2e-3 * 9.81  # no energy is gained at the edges between triangles (2 mm of height)
     assert energy[-1] < energy[0]  # (there is no rolling resistance: the ball keeps swinging through the bowl, a little lower each time)
     assert px.overflow_count() == 0
+
+
+def test_hull_comes_to_rest_on_a_triangle_mesh():
+    """a tumbling convex polyhedron dropped on a flat triangle mesh must end up lying ON it: within the contact offset a hull
+    has many vertices above the plane, and before MSSIM_TRI_SLACK kept them out, those speculative points crowded the
+    load-carrying ones out of the 4-point patch and the hull sank a centimetre into the mesh"""
+    from scipy.spatial import ConvexHull
+
+    rng = np.random.default_rng(7)
+    pts = rng.normal(size=(24, 3))
+    pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * np.array([0.035, 0.025, 0.02])
+    hull = np.ascontiguousarray(pts[ConvexHull(pts).vertices])
+    V, F = _grid_mesh(n=8)
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("terrain", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)]))
+    b.add_actor(ActorRecord("rock", "dynamic", [ShapeRecord("convex", geom.pose(), vertices=hull)], initial_pose=geom.pose([0.03, -0.02, 0.1], [0.8, 0.3, -0.4, 0.33166])))
+    model = b.compile(sleep_threshold=0.0)
+    px = ob.make_system(model, 1)
+    row = model.row_of("rock")
+    from maniskill_amd.utils.geometry.rotation_conversions import quaternion_to_matrix
+
+    worst = 1.0
+    for _ in range(150):
+        px.step(1)
+        px.gpu_fetch_all()
+        s = px.cuda_rigid_body_data.torch()[row].double()
+        R = quaternion_to_matrix(s[3:7][None] / s[3:7].norm()).numpy()[0]
+        worst = min(worst, float((hull @ R.T + s[:3].numpy())[:, 2].min()))
+    assert worst > -2.5e-3, worst  # (the landing at 1.3 m/s dips 1-2 mm)
+    low = float((hull @ R.T + s[:3].numpy())[:, 2].min())
+    assert abs(low) < 1e-3 and float(s[7:10].abs().max()) < 0.02, (low, s)
+    assert px.overflow_count() == 0
