@@ -96,7 +96,15 @@ extern "C" {
 #define MSSIM_MAX_POINTS 4      /* contact points kept per shape pair (PCM-style cap)     */
 #define MSSIM_MAX_HULL_VERTS 64 /* per convex hull (PhysX GPU-compatible hull limit)      */
 #define MSSIM_TRI_SLACK 4e-3f    /* m: a convex shape's points this much higher above a triangle's plane than its lowest one give no contact */
+#define MSSIM_TRI_TIE 1e-5f      /* m: candidates of a triangle whose gaps differ by less are equally deep (the first in order is kept) */
 #define MSSIM_MAX_TRI_HITS 32   /* triangles of one mesh in range of one convex shape at a time (more: reported overflow) */
+#define MSSIM_MAX_TRI_TASKS 56  /* triangles in range over all (convex shape, mesh) pairs of an env (they also share MSSIM_MAX_HITS) */
+/* The range in which triangles are looked for is the contact offset. When that finds more triangles than there is room
+ * for (either capacity above, or the hit list), the env's search is repeated with the range halved, quartered and finally
+ * zero (triangles the convex shape's oriented box touches): the speculative contacts furthest out are given up first and
+ * the triangles that carry load stay. Only a search that does not fit at range zero either is cut off in index order and
+ * reported (MSSIM_OVERFLOW_TRI). The manifold of a triangle that is kept does not depend on the range it was found with. */
+#define MSSIM_TRI_RANGE_STEPS 4
 /* Contact patches. A compound body (the Panda finger: 4 boxes, panda_v3.urdf:244-283; the box with a hole: 4 boxes,
  * envs/tasks/tabletop/peg_insertion_side.py:150-181) touching another compound body yields one <= 4-point manifold per
  * SHAPE pair -- 16 shape pairs x 4 points for one finger inside the hole. Before the solver the manifolds of one BODY
@@ -107,7 +115,9 @@ extern "C" {
 #define MSSIM_PATCH_COS 0.985f     /* cos of the patch cone half angle (~10 degrees)          */
 /* The four selection scans take the FIRST candidate (pair order, then point order) within a tolerance of the
  * extremum: flat contacts put many points at equal depth / distance / area, and a bare "first extremum" would be decided
- * by rounding noise (a different point set in f32 and f64, and from one substep to the next). */
+ * by rounding noise (a different point set in f32 and f64, and from one substep to the next). The 4th point (largest
+ * area on the other side of the edge) is only taken if its area exceeds MSSIM_PATCH_TIE_REL of the 3rd point's: a point
+ * on the edge itself up to rounding adds nothing and would be there or not by the sign of a rounding error. */
 #define MSSIM_PATCH_TIE_SEP 1e-5f  /* separations within 10 micrometres of the deepest count as equal */
 #define MSSIM_PATCH_TIE_REL 1e-3f  /* squared distances / areas within 0.1 % of the largest count as equal */
 #define MSSIM_MAX_CONTACTS 52      /* contact points per env fed to the solver, after the patch reduction */
@@ -137,12 +147,16 @@ enum {
   MSSIM_SHAPE_TRIMESH = 7  /* triangle mesh of a fixed or kinematic body (the reference's nonconvex collision,
                               actor_builder.py:136-150): shape_hull = (root node in tri_bvh, triangle count). Every
                               triangle is a 3-vertex hull; a convex shape near the mesh is tested against the triangles
-                              whose boxes lie within its bounding sphere + contact offset (found through the 16-wide BVH),
-                              in index order. A triangle is a bounded piece of its plane (face normal on the side of the
+                              in range (found through the 16-wide BVH: the triangle's box within the shape's bounding
+                              sphere and within the bounds of its oriented box, the oriented box within range of the
+                              triangle's plane; range = contact offset, see MSSIM_TRI_RANGE_STEPS), in index order. A triangle is a bounded piece of its plane (face normal on the side of the
                               convex shape's centre): the shape's plane-contact points (box corners, capsule ends, hull
                               vertices, ...) whose gap is within the contact offset and within MSSIM_TRI_SLACK of the
                               shape's lowest point and whose foot lies in the triangle, plus -- for a box -- the
-                              triangle's corners under the box; the 4 deepest, exact gaps, no tripping over inner edges
+                              triangle's corners under the box and the points where its edges enter and leave the box's
+                              shadow along the normal (or come nearest to the box in between): together the outline of
+                              (box footprint) x (triangle), as in face clipping; the 4 deepest (gaps within MSSIM_TRI_TIE
+                              are equal: first in that order), exact gaps, no tripping over inner edges
                               (a point over the neighbouring triangle is that triangle's). Only when there is no such
                               point the generic query runs (interior point: the triangle's point nearest to the shape's
                               centre): from the side it keeps its normal, within 60 degrees of the face normal it takes

@@ -94,6 +94,7 @@
 static_assert(S16_NP_BOUT + 20 <= S16_NP_SCR + 896, "narrowphase staging exceeds the scratch area");
 static_assert(S16_NP_SLOT + 16 <= S16_REC, "narrowphase lists run into the contact records");
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
+static_assert(MSSIM_MAX_TRI_TASKS + MSSIM_MAX_TRI_HITS <= S16_NP_KEY - S16_NP_BSCR, "triangle task list + candidates exceed the scratch they borrow (BSCR + KEEP)");
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const float ar = dot(cross(ed, x - p0), nw);
           const int i2 = first_near_max(fabsf(ar), in5 && c != i0 && c != i1, -1.f);
           const float sgn2 = gbc(ar, i2);
-          const int i3 = first_near_max(sgn2 >= 0.f ? -ar : ar, in5 && c != i0 && c != i1 && c != i2, 0.f);
+          const int i3 = first_near_max(sgn2 >= 0.f ? -ar : ar, in5 && c != i0 && c != i1 && c != i2, MSSIM_PATCH_TIE_REL * fabsf(sgn2));  // (the 4th point has to add area)
           const unsigned keep = (1u << i0) | (1u << i1) | (1u << i2) | (i3 >= 0 ? 1u << i3 : 0u);
           int src = 0;
           {
@@ -1178,8 +1179,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         // T0, the env's own group: BVH traversal. A node is 16 child boxes, one per lane; children in range of the convex
         // shape's bounding sphere (+ contact offset, mesh frame) are pushed (nodes) or collected (triangles). The triangles
         // are then ranked by index (the order of the oracle's plain loop): rank r becomes hit nh + r and task ntask + r.
-        int* const tl = reinterpret_cast<int*>(L + S16_NP_BSCR);         // [56] tasks: triangle | hit index << 24 (BSCR + KEEP, both idle here)
-        int* const cand = reinterpret_cast<int*>(L + S16_NP_BSCR) + 56;  // [32] triangles of the pair being traversed
+        int* const tl = reinterpret_cast<int*>(L + S16_NP_BSCR);         // [MSSIM_MAX_TRI_TASKS] tasks: triangle | hit index << 24 (BSCR + KEEP, both idle here)
+        int* const cand = reinterpret_cast<int*>(L + S16_NP_BSCR) + MSSIM_MAX_TRI_TASKS;  // [32] triangles of the pair being traversed
         int* const stack = reinterpret_cast<int*>(L + S16_NP_BOUT);      // [20] nodes to visit
         int* const hitw = reinterpret_cast<int*>(L) + S16_NP_HIT;
         int* const cntw = reinterpret_cast<int*>(L) + S16_NP_CNT;
@@ -1187,6 +1188,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         int ntask = 0;
         bool tri_over = false;
         const int nh0 = nh;
+        // (the search range: the contact offset, narrowed while the triangles found do not fit -- MSSIM_TRI_RANGE_STEPS)
+        float range = M.contact_offset;
+#pragma unroll 1
+        for (int step = 0; step < MSSIM_TRI_RANGE_STEPS; step++) {
+        nh = nh0; ntask = 0; tri_over = false;
         for (int idx = 0; idx < nh0; idx++) {  // (group-uniform)
           const int pk = hitw[idx];
           const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
@@ -1194,7 +1200,13 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
           const m3 RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
           const f3 cq = mtmulv(RB, f3{ta_[10], ta_[11], ta_[12]} - f3{tb_[0], tb_[1], tb_[2]});
-          const float rq = ta_[13] + M.contact_offset;
+          const float rq = ta_[13] + range;
+          // (the convex shape's oriented box in the mesh frame: axes scaled by the half extents, and its bounds)
+          const m3 RA = qmat(q4{ta_[3], ta_[4], ta_[5], ta_[6]});
+          const f3 un0 = mtmulv(RB, mcol(RA, 0)), un1 = mtmulv(RB, mcol(RA, 1)), un2 = mtmulv(RB, mcol(RA, 2));
+          const f3 ax0 = un0 * ta_[16], ax1 = un1 * ta_[17], ax2 = un2 * ta_[18];
+          const f3 ext = f3{fabsf(ax0.x) + fabsf(ax1.x) + fabsf(ax2.x), fabsf(ax0.y) + fabsf(ax1.y) + fabsf(ax2.y), fabsf(ax0.z) + fabsf(ax1.z) + fabsf(ax2.z)};
+          const float off_ = range;
           int sp = 1, ncand = 0;
           if (c == 0) stack[0] = (int)(__float_as_uint(tb_[14]) >> 15);
           WSYNC();
@@ -1206,7 +1218,36 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             const float lx = nd[6 * c], ly = nd[6 * c + 1], lz = nd[6 * c + 2], hx = nd[6 * c + 3], hy = nd[6 * c + 4], hz = nd[6 * c + 5];
             const int ref = __float_as_int(nd[96 + c]);
             const float dx = fmaxf(fmaxf(lx - cq.x, cq.x - hx), 0.f), dy = fmaxf(fmaxf(ly - cq.y, cq.y - hy), 0.f), dz = fmaxf(fmaxf(lz - cq.z, cq.z - hz), 0.f);
-            const bool in = lx <= hx && dx * dx + dy * dy + dz * dz <= rq * rq;
+            bool in = lx <= hx && dx * dx + dy * dy + dz * dz <= rq * rq;
+            in = in && !(lx - (cq.x + ext.x) > off_ || (cq.x - ext.x) - hx > off_ || ly - (cq.y + ext.y) > off_ || (cq.y - ext.y) - hy > off_ ||
+                         lz - (cq.z + ext.z) > off_ || (cq.z - ext.z) - hz > off_);
+            if (in && ref >= 0) {  // a node: the child's box along the oriented box's own axes
+              const f3 bc = f3{0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz)} - cq, bh = f3{0.5f * (hx - lx), 0.5f * (hy - ly), 0.5f * (hz - lz)};
+              auto apart = [&](f3 u, float h) __attribute__((always_inline)) {
+                return fabsf(dot(u, bc)) - (fabsf(u.x) * bh.x + fabsf(u.y) * bh.y + fabsf(u.z) * bh.z) > h + off_;
+              };
+              in = !(apart(un0, ta_[16]) || apart(un1, ta_[17]) || apart(un2, ta_[18]));
+            }
+            if (in && ref < 0) {  // a triangle: its corners along the oriented box's own axes, then the box against its plane
+              const float* tq = M.tri_soup + (size_t)(~ref) * 12;
+              const f3 cen = f3{tq[0], tq[1], tq[2]} - cq;
+              const f3 k0 = cen + f3{tq[3], tq[4], tq[5]}, k1 = cen + f3{tq[6], tq[7], tq[8]}, k2 = cen + f3{tq[9], tq[10], tq[11]};
+              auto apart = [&](f3 u, float h) __attribute__((always_inline)) {
+                const float d0 = dot(u, k0), d1 = dot(u, k1), d2 = dot(u, k2);
+                return fminf(d0, fminf(d1, d2)) > h + off_ || fmaxf(d0, fmaxf(d1, d2)) < -(h + off_);
+              };
+              in = !(apart(un0, ta_[16]) || apart(un1, ta_[17]) || apart(un2, ta_[18]));
+            }
+            if (in && ref < 0) {
+              const float* tq = M.tri_soup + (size_t)(~ref) * 12;
+              const f3 v0 = f3{tq[3], tq[4], tq[5]}, nn = cross(f3{tq[6], tq[7], tq[8]} - v0, f3{tq[9], tq[10], tq[11]} - v0);
+              const float len = sqrtf(dot(nn, nn));
+              if (len > 0.f) {
+                const float dist = dot(nn, cq - (f3{tq[0], tq[1], tq[2]} + v0));
+                const float rad = fabsf(dot(nn, ax0)) + fabsf(dot(nn, ax1)) + fabsf(dot(nn, ax2));
+                in = !(fabsf(dist) - rad > off_ * len);
+              }
+            }
             const unsigned mn = b16(in && ref >= 0), ml2 = b16(in && ref < 0), lt = (1u << c) - 1u;
             if (in && ref >= 0) {
               const int at = sp + __popc(mn & lt);
@@ -1228,7 +1269,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               const int t = cand[i];
               int rank = 0;
               for (int j = 0; j < ncand; j++) rank += cand[j] < t ? 1 : 0;
-              if (nh + rank < S16_MAX_HIT && ntask + rank < 56) {
+              if (nh + rank < S16_MAX_HIT && ntask + rank < MSSIM_MAX_TRI_TASKS) {
                 tl[ntask + rank] = t | ((nh + rank) << 24);
                 hitw[nh + rank] = pk;
                 cntw[nh + rank] = 0;
@@ -1237,12 +1278,16 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               }
             }
           }
-          const int room = min(S16_MAX_HIT - nh, 56 - ntask);
+          const int room = min(S16_MAX_HIT - nh, MSSIM_MAX_TRI_TASKS - ntask);
           const int take = min(ncand, room);
           nh += take; ntask += take;
           WSYNC();
         }
-        if (__any(tri_over) && tri_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_TRI);
+        tri_over = b16(tri_over) != 0u;  // (group-uniform from here)
+        if (!tri_over) break;
+        range = step == MSSIM_TRI_RANGE_STEPS - 2 ? 0.f : 0.5f * range;
+        }
+        if (tri_over && live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_TRI);
         // T1: the wave's tasks, one per 16-lane group at a time
         int tcum[S16_ENVS_PER_BLOCK + 1];
         tcum[0] = 0;
@@ -1300,7 +1345,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             return !miss && t_in <= t_out && t_in < offset;
           };
           // candidates of this lane, at most 4 (hull vertices c, c + 16, ..); id = their place in the oracle's order:
-          // (1) A's plane-contact points over the triangle, 0..63; (2) the triangle's corners under a box, 64..66
+          // (1) A's plane-contact points over the triangle, 0..63; (2) the triangle's corners under a box, 64..66; (3) the
+          // triangle's edges under a box, 67..75
           f3 X[4];
           float Sp[4];
           bool ok[4];
@@ -1328,6 +1374,66 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               X[1] = qc + nf * (0.5f * t_in);
               Sp[1] = t_in;
             }
+            // (3) lanes 11..13, the triangle's edge (c - 11) under the box: entry and exit of the box's shadow along nf and the
+            // nearest point in between (see the oracle's tri_manifold): slots 1..3
+            {
+              const int ei = c == 12 ? 1 : (c == 13 ? 2 : 0);
+              const f3 qa = ei == 0 ? q0 : (ei == 1 ? q1 : q2), qb = ei == 0 ? q1 : (ei == 1 ? q2 : q0);
+              const f3 dl = mtmulv(A.rot, nf), Pv = mtmulv(A.rot, qa - A.c), Qv = mtmulv(A.rot, qb - qa);
+              float s0 = 0.f, s1 = 1.f, al[3], be[3], wid[3];
+              bool par[3], empty = false;
+              auto clip = [&](float a0, float b0) __attribute__((always_inline)) {  // a0 + b0 s <= 0
+                if (b0 > 0.f) s1 = fminf(s1, -a0 / b0);
+                else if (b0 < 0.f) s0 = fmaxf(s0, -a0 / b0);
+                else if (a0 > 0.f) empty = true;
+              };
+#pragma unroll
+              for (int a = 0; a < 3; a++) {
+                const float hb = a == 0 ? A.p0 : (a == 1 ? A.p1 : A.p2), dv = comp(dl, a), P = comp(Pv, a), Q = comp(Qv, a);
+                par[a] = fabsf(dv) < 1e-9f;
+                if (par[a]) {
+                  clip(P - hb, Q);
+                  clip(-P - hb, -Q);
+                  al[a] = be[a] = wid[a] = 0.f;
+                } else {
+                  al[a] = (-(dv > 0.f ? hb : -hb) - P) / dv;
+                  be[a] = -Q / dv;
+                  wid[a] = 2.f * hb / fabsf(dv);
+                }
+              }
+#pragma unroll
+              for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+                  if (a != b && !par[a] && !par[b]) clip(al[a] - al[b] - wid[b], be[a] - be[b]);
+              auto t_in_at = [&](float sv) __attribute__((always_inline)) {
+                float t = -1e30f;
+#pragma unroll
+                for (int a = 0; a < 3; a++) t = par[a] ? t : fmaxf(t, al[a] + be[a] * sv);
+                return t;
+              };
+              const float f0 = t_in_at(s0), f1 = t_in_at(s1);
+              float sm = s0, fm = fminf(f0, f1);
+              bool inner = false;
+#pragma unroll
+              for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = a + 1; b < 3; b++) {
+                  if (par[a] || par[b] || be[a] == be[b]) continue;
+                  const float sx = (al[b] - al[a]) / (be[a] - be[b]);
+                  if (!(sx > s0 && sx < s1)) continue;
+                  const float fx = t_in_at(sx);
+                  if (fx < fm - 1e-6f) { fm = fx; sm = sx; inner = true; }
+                }
+              if (c >= 11 && c < 14 && !empty && s0 <= s1) {
+                ok[1] = s0 > 0.f && f0 < offset;
+                X[1] = qa + (qb - qa) * s0 + nf * (0.5f * f0); Sp[1] = f0;
+                ok[2] = s1 < 1.f && s1 > s0 && f1 < offset;
+                X[2] = qa + (qb - qa) * s1 + nf * (0.5f * f1); Sp[2] = f1;
+                ok[3] = inner && fm < offset;
+                X[3] = qa + (qb - qa) * sm + nf * (0.5f * fm); Sp[3] = fm;
+              }
+            }
           } else if (A.type == SH_SPHERE) {
             cand1(0, A.c, A.p0, c == 0);
           } else if (A.type == SH_CAPSULE) {
@@ -1345,8 +1451,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll
           for (int k = 0; k < 4; k++) ok[k] = ok[k] && Sp[k] <= s_low + MSSIM_TRI_SLACK;
           // candidate ids: (1) box corner / capsule end / hull vertex index; (2) 64 + corner
-          auto cid = [&](int k) __attribute__((always_inline)) { return (A.type == SH_BOX && k == 1) ? 64 + (c - 8) : c + 16 * k; };
-          // the 4 deepest, the lowest id among equals first (the oracle's keep4_deepest)
+          auto cid = [&](int k) __attribute__((always_inline)) {
+            if (A.type == SH_BOX && k >= 1) return c < 11 ? 64 + (c - 8) : 67 + 3 * (c - 11) + (k - 1);
+            return c + 16 * k;
+          };
+          // the 4 deepest, the lowest id among equals first (the oracle's rule in tri_manifold)
           f3 mx[4];
           float msep[4];
           int cnt = 0;
@@ -1359,15 +1468,17 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             if (!(best < 3e38f)) break;  // (group-uniform)
             int id = 1 << 20;
 #pragma unroll
-            for (int k = 3; k >= 0; k--) id = (ok[k] && Sp[k] == best) ? min(id, cid(k)) : id;
+            for (int k = 3; k >= 0; k--) id = (ok[k] && Sp[k] <= best + MSSIM_TRI_TIE) ? min(id, cid(k)) : id;  // (gaps within MSSIM_TRI_TIE are equal)
             id = gmin16i(id);
             // the owner lane and slot of that id
-            const int owner = id >= 64 ? 8 + (id - 64) : (id & 15), slot = id >= 64 ? 1 : (id >> 4);
+            const int owner = id >= 67 ? 11 + (id - 67) / 3 : (id >= 64 ? 8 + (id - 64) : (id & 15));
+            const int slot = id >= 67 ? 1 + (id - 67) % 3 : (id >= 64 ? 1 : (id >> 4));
             const f3 mine = slot == 0 ? X[0] : (slot == 1 ? X[1] : (slot == 2 ? X[2] : X[3]));
             const f3 px = f3{gbc(mine.x, owner), gbc(mine.y, owner), gbc(mine.z, owner)};
+            const float psep = gbc(slot == 0 ? Sp[0] : (slot == 1 ? Sp[1] : (slot == 2 ? Sp[2] : Sp[3])), owner);
 #pragma unroll
             for (int t2 = 0; t2 < 4; t2++)
-              if (t2 == cnt) { mx[t2] = px; msep[t2] = best; }
+              if (t2 == cnt) { mx[t2] = px; msep[t2] = psep; }
             if (c == owner) {
 #pragma unroll
               for (int k = 0; k < 4; k++) ok[k] = ok[k] && k != slot;
@@ -1386,7 +1497,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             manifold_t gq;
             manifold_clear(gq);
             if (has && cnt == 0) collide_mpr_t(A, Tr, offset, gq, sup, true, inside);
-            if (has && cnt == 0 && gq.count > 0) {
+            if (has && cnt == 0 && gq.count > 0 && !(gq.sep[0] < s_low - 1e-3f)) {  // (an answer far below A's lowest gap over the plane: a ray out of the side, see the oracle)
               const bool face = dot(nf, gq.n) > 0.5f;
               nrm = face ? nf : gq.n;
               mx[0] = gq.x[0]; msep[0] = gq.sep[0];
@@ -1645,7 +1756,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               }
               best = gmax16(best);
               int q3 = -1;
-              if (best > 0.f) {
+              if (best > MSSIM_PATCH_TIE_REL * fabsf(sgn2)) {  // (the 4th point has to add area: not one on the edge i0-i1 up to rounding)
 #pragma unroll
                 for (int k = 0; k < 4; k++) ok[k] = has[k] && v[k] >= best - MSSIM_PATCH_TIE_REL * best;
                 q3 = first_pos(ok);
@@ -1701,7 +1812,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
                 const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
                 if (id != i0 && id != i1 && id != i2) best = fmaxf(best, sgn2 >= 0.f ? -ar : ar);
               });
-              if (best > 0.f)
+              if (best > MSSIM_PATCH_TIE_REL * fabsf(sgn2))
                 scan([&](int id, float4 P) {
                   const float ar = dot(cross(ed, f3{P.x, P.y, P.z} - p0), na);
                   const float v = sgn2 >= 0.f ? -ar : ar;

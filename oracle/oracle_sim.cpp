@@ -285,7 +285,9 @@ void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Conta
     auto area = [&](int i) { return dot(cross(ed, raw[pts[i]].x - p0), na); };
     const int i2 = first_near_max([&](int i) { return std::fabs(area(i)); }, [&](int i) { return i != i0 && i != i1; }, Real(-1));
     const Real sgn2 = area(i2);
-    const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, Real(0));
+    // (the 4th point has to add area: one on the edge i0-i1 up to rounding -- candidates along one line, the edge of a box
+    // over several triangles -- would be there or not by the sign of a rounding error)
+    const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, Real(MSSIM_PATCH_TIE_REL) * std::fabs(sgn2));
     for (int i = 0; i < n; i++) keep[pts[i]] = (i == i0 || i == i1 || i == i2 || i == i3) ? 1 : 0;
   }
 }
@@ -313,7 +315,7 @@ void select4(int n, const Vec* x, const Real* sep, const Vec& na, char* keep) {
   auto area = [&](int i) { return dot(cross(ed, x[i] - p0), na); };
   const int i2 = first_near_max([&](int i) { return std::fabs(area(i)); }, [&](int i) { return i != i0 && i != i1; }, Real(-1));
   const Real sgn2 = area(i2);
-  const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, Real(0));
+  const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, Real(MSSIM_PATCH_TIE_REL) * std::fabs(sgn2));
   for (int i = 0; i < n; i++) keep[i] = (i == i0 || i == i1 || i == i2 || i == i3) ? 1 : 0;
 }
 
@@ -388,6 +390,66 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
       seps[n] = t_in;
       n++;
     }
+    // (3) the triangle's edges under the box: where edge i enters and leaves the box's shadow along nf, and -- if deeper than
+    // both -- the point in between where the box comes nearest (an edge of the box across the triangle). In the box frame a
+    // point of the edge is P + s Q; the line through it along nf meets slab a for t in [al_a + be_a s, al_a + be_a s + wid_a].
+    {
+      const Vec dl = A.rot.tmul(nf);
+      const Real hb[3] = {A.param[0], A.param[1], A.param[2]}, dv[3] = {dl.x, dl.y, dl.z};
+      for (int i = 0; i < 3; i++) {
+        const Vec qa = q[i], qb = q[(i + 1) % 3];
+        const Vec Pv = A.rot.tmul(qa - A.c), Qv = A.rot.tmul(qb - qa);
+        const Real P[3] = {Pv.x, Pv.y, Pv.z}, Q[3] = {Qv.x, Qv.y, Qv.z};
+        Real s0 = 0, s1 = 1, al[3], be[3], wid[3];
+        bool par[3], empty = false;
+        auto clip = [&](Real a0, Real b0) {  // a0 + b0 s <= 0
+          if (b0 > 0) s1 = std::min(s1, -a0 / b0);
+          else if (b0 < 0) s0 = std::max(s0, -a0 / b0);
+          else if (a0 > 0) empty = true;
+        };
+        for (int a = 0; a < 3; a++) {
+          par[a] = std::fabs(dv[a]) < Real(1e-9);
+          if (par[a]) {
+            clip(P[a] - hb[a], Q[a]);
+            clip(-P[a] - hb[a], -Q[a]);
+            al[a] = be[a] = wid[a] = 0;
+          } else {
+            al[a] = (-(dv[a] > 0 ? hb[a] : -hb[a]) - P[a]) / dv[a];
+            be[a] = -Q[a] / dv[a];
+            wid[a] = 2 * hb[a] / std::fabs(dv[a]);
+          }
+        }
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++)
+            if (a != b && !par[a] && !par[b]) clip(al[a] - al[b] - wid[b], be[a] - be[b]);
+        if (empty || !(s0 <= s1)) continue;
+        auto t_in_at = [&](Real sv) {
+          Real t = Real(-1e30);
+          for (int a = 0; a < 3; a++)
+            if (!par[a]) t = std::max(t, al[a] + be[a] * sv);
+          return t;
+        };
+        const Real f0 = t_in_at(s0), f1 = t_in_at(s1);
+        Real sm = s0, fm = std::min(f0, f1);
+        bool inner = false;
+        for (int a = 0; a < 3; a++)
+          for (int b = a + 1; b < 3; b++) {
+            if (par[a] || par[b] || be[a] == be[b]) continue;
+            const Real sx = (al[b] - al[a]) / (be[a] - be[b]);
+            if (!(sx > s0 && sx < s1)) continue;
+            const Real fx = t_in_at(sx);
+            if (fx < fm - Real(1e-6)) { fm = fx; sm = sx; inner = true; }
+          }
+        const Real sv[3] = {s0, s1, sm}, fv[3] = {f0, f1, fm};
+        const bool use[3] = {s0 > 0, s1 < 1 && s1 > s0, inner};
+        for (int k = 0; k < 3; k++) {
+          if (!use[k] || !(fv[k] < offset) || !(fv[k] <= s_low + Real(MSSIM_TRI_SLACK))) continue;
+          pts[n] = qa + (qb - qa) * sv[k] + nf * (Real(0.5) * fv[k]);
+          seps[n] = fv[k];
+          n++;
+        }
+      }
+    }
   } else if (A.type == SH_SPHERE) {
     lowest(A.c, A.param[0]);
     add(A.c, A.param[0]);
@@ -406,7 +468,23 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
     add(support(A, -nf), Real(0));
   }
   m.n = nf;
-  keep4_deepest(n, pts, seps, m);
+  // the 4 deepest; gaps within MSSIM_TRI_TIE of the deepest count as equal and the first in the order above is taken (a face
+  // lying on a triangle: all its candidates tie up to rounding)
+  {
+    bool used[72] = {false};
+    for (int k = 0; k < 4 && k < n; k++) {
+      Real lowest_gap = Real(1e30);
+      for (int i = 0; i < n; i++)
+        if (!used[i]) lowest_gap = std::min(lowest_gap, seps[i]);
+      int best = -1;
+      for (int i = 0; i < n && best < 0; i++)
+        if (!used[i] && seps[i] <= lowest_gap + Real(MSSIM_TRI_TIE)) best = i;
+      used[best] = true;
+      m.x[m.count] = pts[best];
+      m.sep[m.count] = seps[best];
+      m.count++;
+    }
+  }
   if (m.count > 0) return;
   Vec inside;
   {
@@ -418,6 +496,9 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
   queries++;
   collide_mpr(A, T, offset, g, &inside);
   if (g.count == 0) return;
+  // (A shifted along nf by -s_low clears the triangle's plane, so no true gap is below s_low: an answer far below it comes
+  // from an origin ray that left the difference body through a side -- A's centre far off to the side of the triangle)
+  if (g.sep[0] < s_low - Real(1e-3)) return;
   const bool face = dot(nf, g.n) > Real(0.5);
   m.n = face ? nf : g.n;
   m.x[0] = g.x[0];
@@ -665,58 +746,136 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
   E.pcm_tick++;
   E.mpr_queries = 0;
   int hits = 0;  // pairs that survive the cull (the kernels' hit list holds MSSIM_MAX_HITS of them)
-  for (int p = 0; p < M.n_pair; p++) {
+  // the cull of pair p; for a survivor also the world centres of the two bounding spheres and A's radius
+  auto survives = [&](int p, Vec& ca, Vec& cb, Real& ra) {
     int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
     const Shape<Real>&A = sh[sa], &B = sh[sb];
     // a pair of bodies that cannot move in this substep -- fixed in the env frame or asleep at its start -- needs no
     // manifold (a sleeping body woken later in the substep gets its contacts with the static scene back in the next one)
-    {
-      auto inactive = [&](int s) {
-        return M.shape_kind[s] == MSSIM_BODY_WORLD || (M.shape_kind[s] == MSSIM_BODY_FREE && E.free_wake[M.shape_index[s]] <= 0);
-      };
-      if (inactive(sa) && inactive(sb)) continue;
-      if (A.type == MSSIM_SHAPE_NONE || B.type == MSSIM_SHAPE_NONE) continue;  // no shape in this env's slot
-    }
+    auto inactive = [&](int s) {
+      return M.shape_kind[s] == MSSIM_BODY_WORLD || (M.shape_kind[s] == MSSIM_BODY_FREE && E.free_wake[M.shape_index[s]] <= 0);
+    };
+    if (inactive(sa) && inactive(sb)) return false;
+    if (A.type == MSSIM_SHAPE_NONE || B.type == MSSIM_SHAPE_NONE) return false;  // no shape in this env's slot
     // bounding-sphere cull
-    Real ra, rb;
+    Real rb;
     Vec cla, clb;
     shape_bound_body(M, sa, e, cla, ra);
     shape_bound_body(M, sb, e, clb, rb);
     Pose<Real> PA = body_world_pose(M, E, M.shape_kind[sa], M.shape_index[sa]), PB = body_world_pose(M, E, M.shape_kind[sb], M.shape_index[sb]);
-    Vec ca = PA.p + qrot(PA.q, cla);
-    Vec cb = PB.p + qrot(PB.q, clb);
-    if (A.type == SH_PLANE) {
-      if (dot(A.rot.col(0), cb - A.c) > rb + M.contact_offset) continue;
-    } else {
-      Vec d = cb - ca;
-      Real rr = ra + rb + M.contact_offset;
-      if (dot(d, d) > rr * rr) continue;
-      // second stage, as the kernels: oriented boxes of the two shapes (conservative; it decides which pairs reach
-      // the persistent manifold cache, so both implementations must apply it alike)
-      if (obb_separated(A.rot, shape_obb_half(M, sa, e), B.rot, shape_obb_half(M, sb, e), d, M.contact_offset)) continue;
+    ca = PA.p + qrot(PA.q, cla);
+    cb = PB.p + qrot(PB.q, clb);
+    if (A.type == SH_PLANE) return !(dot(A.rot.col(0), cb - A.c) > rb + M.contact_offset);
+    Vec d = cb - ca;
+    Real rr = ra + rb + M.contact_offset;
+    if (dot(d, d) > rr * rr) return false;
+    // second stage, as the kernels: oriented boxes of the two shapes (conservative; it decides which pairs reach
+    // the persistent manifold cache, so both implementations must apply it alike)
+    return !obb_separated(A.rot, shape_obb_half(M, sa, e), B.rot, shape_obb_half(M, sb, e), d, M.contact_offset);
+  };
+  // Triangle mesh (include/mssim.h MSSIM_SHAPE_TRIMESH): the triangles of pair p's mesh in `range` of its convex shape, in
+  // index order -- the triangle's box against the shape's bounding sphere and against the bounds of its oriented box (mesh
+  // frame), the triangle's corners along the oriented box's own axes, then the oriented box against the triangle's plane
+  auto triangles_in_range = [&](int p, const Vec& ca, Real ra, Real range, std::vector<int>& found) {
+    found.clear();
+    int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+    const Shape<Real>&A = sh[sa], &B = sh[sb];
+    const Vec cq = B.rot.tmul(ca - B.c);
+    const Real rq = ra + range;
+    const Vec hA = shape_obb_half(M, sa, e);
+    Vec un[3], ax[3];
+    for (int i = 0; i < 3; i++) { un[i] = B.rot.tmul(A.rot.col(i)); ax[i] = un[i] * (i == 0 ? hA.x : i == 1 ? hA.y : hA.z); }
+    const Vec ext(std::fabs(ax[0].x) + std::fabs(ax[1].x) + std::fabs(ax[2].x), std::fabs(ax[0].y) + std::fabs(ax[1].y) + std::fabs(ax[2].y),
+                  std::fabs(ax[0].z) + std::fabs(ax[1].z) + std::fabs(ax[2].z));
+    const int first = (int)M.shape_param[4 * sb], count = (int)M.shape_param[4 * sb + 1];
+    for (int t = first; t < first + count; t++) {
+      const float* q = &M.tri_soup[12 * (size_t)t];
+      float lo[3], hi[3];
+      for (int a = 0; a < 3; a++) {
+        const float x0 = q[a] + q[3 + a], x1 = q[a] + q[6 + a], x2 = q[a] + q[9 + a];
+        lo[a] = std::min(x0, std::min(x1, x2)); hi[a] = std::max(x0, std::max(x1, x2));
+      }
+      const Real dx = std::max(std::max((Real)lo[0] - cq.x, cq.x - (Real)hi[0]), Real(0)), dy = std::max(std::max((Real)lo[1] - cq.y, cq.y - (Real)hi[1]), Real(0)),
+                 dz = std::max(std::max((Real)lo[2] - cq.z, cq.z - (Real)hi[2]), Real(0));
+      if (dx * dx + dy * dy + dz * dz > rq * rq) continue;
+      if ((Real)lo[0] - (cq.x + ext.x) > range || (cq.x - ext.x) - (Real)hi[0] > range || (Real)lo[1] - (cq.y + ext.y) > range || (cq.y - ext.y) - (Real)hi[1] > range ||
+          (Real)lo[2] - (cq.z + ext.z) > range || (cq.z - ext.z) - (Real)hi[2] > range) continue;
+      {  // the triangle's corners along the oriented box's own axes
+        const Real hv[3] = {hA.x, hA.y, hA.z};
+        bool apart = false;
+        for (int i = 0; i < 3; i++) {
+          Real dmin = Real(1e30), dmax = Real(-1e30);
+          for (int k = 0; k < 3; k++) {
+            const Real d = dot(un[i], Vec((Real)q[0] + (Real)q[3 + 3 * k], (Real)q[1] + (Real)q[4 + 3 * k], (Real)q[2] + (Real)q[5 + 3 * k]) - cq);
+            dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+          }
+          apart = apart || dmin > hv[i] + range || dmax < -(hv[i] + range);
+        }
+        if (apart) continue;
+      }
+      const Vec e1((Real)q[6] - (Real)q[3], (Real)q[7] - (Real)q[4], (Real)q[8] - (Real)q[5]), e2((Real)q[9] - (Real)q[3], (Real)q[10] - (Real)q[4], (Real)q[11] - (Real)q[5]);
+      const Vec nn = cross(e1, e2);
+      const Real len = std::sqrt(dot(nn, nn));
+      if (len > Real(0)) {
+        const Real dist = dot(nn, cq - Vec((Real)q[0] + (Real)q[3], (Real)q[1] + (Real)q[4], (Real)q[2] + (Real)q[5]));
+        const Real rad = std::fabs(dot(nn, ax[0])) + std::fabs(dot(nn, ax[1])) + std::fabs(dot(nn, ax[2]));
+        if (std::fabs(dist) - rad > range * len) continue;
+      }
+      found.push_back(t);
     }
+  };
+  // the search range of this env's mesh pairs (MSSIM_TRI_RANGE_STEPS): the largest of offset, offset/2, offset/4, 0 whose
+  // triangles fit -- per pair, in the task list, and in what the surviving pairs leave of the hit list
+  std::vector<std::vector<int>> tri_found(!M.tri_soup.empty() ? M.n_pair : 0);
+  if (!M.tri_soup.empty()) {
+    int nh0 = 0;
+    std::vector<int> mesh_pairs;
+    std::vector<Vec> mesh_ca;
+    std::vector<Real> mesh_ra;
+    for (int p = 0; p < M.n_pair; p++) {
+      Vec ca, cb;
+      Real ra;
+      if (!survives(p, ca, cb, ra)) continue;
+      nh0++;
+      if (sh[M.pair_shape[2 * p + 1]].type == SH_TRIMESH) { mesh_pairs.push_back(p); mesh_ca.push_back(ca); mesh_ra.push_back(ra); }
+    }
+    nh0 = std::min(nh0, (int)MSSIM_MAX_HITS);
+    Real range = M.contact_offset;
+    for (int step = 0; step < MSSIM_TRI_RANGE_STEPS; step++) {
+      int total = 0;
+      bool fits = true;
+      for (size_t i = 0; i < mesh_pairs.size(); i++) {
+        std::vector<int>& f = tri_found[mesh_pairs[i]];
+        triangles_in_range(mesh_pairs[i], mesh_ca[i], mesh_ra[i], range, f);
+        fits = fits && (int)f.size() <= MSSIM_MAX_TRI_HITS;
+        total += (int)f.size();
+      }
+      fits = fits && total <= std::min((int)MSSIM_MAX_HITS - nh0, (int)MSSIM_MAX_TRI_TASKS);
+      if (fits) break;
+      if (step == MSSIM_TRI_RANGE_STEPS - 1) {  // cut off in index order, pair after pair
+        E.overflow |= MSSIM_OVERFLOW_TRI;
+        int room = std::min((int)MSSIM_MAX_HITS - nh0, (int)MSSIM_MAX_TRI_TASKS);
+        for (int p : mesh_pairs) {
+          std::vector<int>& f = tri_found[p];
+          if ((int)f.size() > MSSIM_MAX_TRI_HITS) f.resize(MSSIM_MAX_TRI_HITS);
+          if ((int)f.size() > room) f.resize(room);
+          room -= (int)f.size();
+        }
+      }
+      range = step == MSSIM_TRI_RANGE_STEPS - 2 ? Real(0) : Real(0.5) * range;
+    }
+  }
+  for (int p = 0; p < M.n_pair; p++) {
+    int sa = M.pair_shape[2 * p], sb = M.pair_shape[2 * p + 1];
+    const Shape<Real>&A = sh[sa], &B = sh[sb];
+    Vec ca, cb;
+    Real ra;
+    if (!survives(p, ca, cb, ra)) continue;
     if (B.type == SH_TRIMESH) {
-      // Triangle mesh (include/mssim.h MSSIM_SHAPE_TRIMESH): the triangles whose boxes overlap the convex shape's bounding
-      // box (mesh frame, contact offset added), in index order; each is a 3-vertex hull in a frame at its centroid and
-      // gives a manifold of its own (one MPR point), which the patch pass merges with those of its coplanar neighbours.
-      const Vec cq = B.rot.tmul(ca - B.c);
-      const Real rq = ra + M.contact_offset;
-      const int first = (int)M.shape_param[4 * sb], count = (int)M.shape_param[4 * sb + 1];
-      int found = 0;
-      for (int t = first; t < first + count; t++) {
+      // each triangle in range is a 3-vertex hull in a frame at its centroid and gives a manifold of its own, which the
+      // patch pass merges with those of its coplanar neighbours
+      for (int t : tri_found[p]) {
         const float* q = &M.tri_soup[12 * (size_t)t];
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; a++) {
-          const float x0 = q[a] + q[3 + a], x1 = q[a] + q[6 + a], x2 = q[a] + q[9 + a];
-          lo[a] = std::min(x0, std::min(x1, x2)); hi[a] = std::max(x0, std::max(x1, x2));
-        }
-        {  // distance from the query sphere's centre to the triangle's box
-          const Real dx = std::max(std::max((Real)lo[0] - cq.x, cq.x - (Real)hi[0]), Real(0)), dy = std::max(std::max((Real)lo[1] - cq.y, cq.y - (Real)hi[1]), Real(0)),
-                     dz = std::max(std::max((Real)lo[2] - cq.z, cq.z - (Real)hi[2]), Real(0));
-          if (dx * dx + dy * dy + dz * dz > rq * rq) continue;
-        }
-        if (found == MSSIM_MAX_TRI_HITS) { E.overflow |= MSSIM_OVERFLOW_TRI; break; }
-        found++;
         Shape<Real> T;
         T.type = SH_CONVEX;
         T.rot = B.rot;

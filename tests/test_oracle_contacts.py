@@ -673,3 +673,36 @@ def test_hull_comes_to_rest_on_a_triangle_mesh():
     low = float((hull @ R.T + s[:3].numpy())[:, 2].min())
     assert abs(low) < 1e-3 and float(s[7:10].abs().max()) < 0.02, (low, s)
     assert px.overflow_count() == 0
+
+
+def _bar_on_fine_mesh():
+    """a 0.30 x 0.036 x 0.04 bar lying along one row of a 5 cm grid: within the contact offset (2 cm) of its oriented box lie
+    3 rows x 8 cells = 48 triangles -- more than MSSIM_MAX_TRI_HITS; within a quarter of it only its own row's 16"""
+    V, F = _grid_mesh(n=12, size=0.6)
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("terrain", "static", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)], initial_pose=geom.pose([0, 0, 0])))
+    b.add_actor(ActorRecord("bar", "dynamic", [ShapeRecord("box", geom.pose(), half_size=np.array([0.15, 0.018, 0.02]))], initial_pose=geom.pose([0, 0.025, 0.03])))
+    model = b.compile(sleep_threshold=0.0)
+    lo, hi = V[F].min(1), V[F].max(1)
+    c, h = np.array([0, 0.025, 0.02]), np.array([0.15, 0.018, 0.02])
+
+    def in_range(r):
+        return int(np.all((lo - (c + h) <= r) & ((c - h) - hi <= r), axis=1).sum())
+
+    assert in_range(0.02) == 48 and in_range(0.01) == 48 and in_range(0.005) == 16
+    return model
+
+
+def test_triangle_search_range_narrows_before_anything_is_dropped():
+    """MSSIM_TRI_RANGE_STEPS: more triangles within the contact offset than one shape pair holds -- the search is repeated
+    with half, then a quarter of the range, which keeps the row the bar lies on; nothing is reported, the bar rests on its
+    four corners (plus the mesh vertices under it) at its half height"""
+    model = _bar_on_fine_mesh()
+    px = ob.make_system(model, 1)
+    row = model.row_of("bar")
+    px.step(60)
+    px.gpu_fetch_all()
+    s = px.cuda_rigid_body_data.torch()[row]
+    assert abs(s[2].item() - 0.02) < 2e-4 and s[7:13].abs().max() < 2e-2, s
+    assert px.read_internal("contact_count", model.n_pair).sum().item() >= 4
+    assert px.overflow_count() == 0
