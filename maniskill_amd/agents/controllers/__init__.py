@@ -1,5 +1,6 @@
 from .base_controller import BaseController, CombinedController, ControllerConfig, DictController
 from .passive_controller import PassiveController, PassiveControllerConfig
+from .pd_base_vel import PDBaseForwardVelController, PDBaseForwardVelControllerConfig, PDBaseVelController, PDBaseVelControllerConfig
 from .pd_ee_pose import PDEEPosController, PDEEPosControllerConfig, PDEEPoseController, PDEEPoseControllerConfig
 from .pd_joint_pos import (
     PDJointPosController,

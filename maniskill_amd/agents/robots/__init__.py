@@ -1,1 +1,2 @@
 from .panda import Panda, PandaWristCam
+from .fetch import Fetch

@@ -1,1 +1,2 @@
 from .tabletop import PegInsertionSideEnv, PickCubeEnv, PushCubeEnv
+from .empty_env import EmptyEnv

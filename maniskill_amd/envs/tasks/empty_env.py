@@ -1,0 +1,51 @@
+"""Empty-v1 (mani_skill/envs/tasks/empty_env.py:17-51): a robot on a ground plane and nothing else -- no task, no
+reward; the place to look at a robot and its controllers. `robot_uids` selects the robot ("panda" by default, "fetch").
+The ground carries the collision bit of the Fetch's wheels so that a base whose height is fixed by its root joints does
+not rest on it as well."""
+from typing import Dict
+
+import numpy as np
+import sapien
+import torch
+
+from maniskill_amd.agents.robots.fetch import FETCH_WHEELS_COLLISION_BIT
+from maniskill_amd.envs.sapien_env import BaseEnv
+from maniskill_amd.sensors.camera import CameraConfig
+from maniskill_amd.utils import sapien_utils
+from maniskill_amd.utils.building.ground import build_ground
+from maniskill_amd.utils.registration import register_env
+
+
+@register_env("Empty-v1", max_episode_steps=200000)
+class EmptyEnv(BaseEnv):
+    SUPPORTED_REWARD_MODES = ["none"]
+    SUPPORTED_ROBOTS = ["panda", "fetch"]
+
+    def __init__(self, *args, robot_uids="panda", **kwargs):
+        super().__init__(*args, robot_uids=robot_uids, **kwargs)
+
+    @property
+    def _default_sensor_configs(self):
+        return [CameraConfig("base_camera", sapien_utils.look_at([1.25, -1.25, 1.5], [0.0, 0.0, 0.2]), 128, 128, np.pi / 2, 0.01, 100)]
+
+    @property
+    def _default_human_render_camera_configs(self):
+        return CameraConfig("render_camera", sapien_utils.look_at([1.25, -1.25, 1.5], [0.0, 0.0, 0.2]), 2048, 2048, 1, 0.01, 100)
+
+    def _load_agent(self, options: dict):
+        super()._load_agent(options, sapien.Pose())
+
+    def _load_scene(self, options: dict):
+        self.ground = build_ground(self.scene)
+        self.ground.set_collision_group_bit(group=2, bit_idx=FETCH_WHEELS_COLLISION_BIT, bit=1)
+
+    def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
+        rest = self.agent.keyframes.get("rest")
+        if rest is not None and rest.qpos is not None:
+            self.agent.reset(torch.as_tensor(rest.qpos, dtype=torch.float32, device=self.device).repeat(len(env_idx), 1))
+
+    def evaluate(self):
+        return {}
+
+    def _get_obs_extra(self, info: Dict):
+        return dict()

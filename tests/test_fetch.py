@@ -1,0 +1,97 @@
+"""Fetch (mani_skill/agents/robots/fetch/fetch.py) in Empty-v1 (envs/tasks/empty_env.py) on the oracle back end: the
+mobile base as three root joints driven by ego-centric velocity actions (agents/controllers/pd_base_vel.py), 15 velocity
+components in one env. The HIP side of the same env is tests/test_gpu_env.py::test_fetch_empty_env_matches_oracle."""
+import numpy as np
+import pytest
+import torch
+
+import maniskill_amd.envs  # noqa: F401
+import gymnasium as gym
+from tests import oracle_backend as ob
+
+BACKEND = "oracle_f64_fetch"
+
+
+@pytest.fixture(scope="module")
+def env():
+    ob.register("f64", BACKEND)
+    e = gym.make("Empty-v1", robot_uids="fetch", num_envs=3, obs_mode="state", sim_backend=BACKEND)
+    yield e
+    e.close()
+
+
+def test_fetch_spaces_and_rest_pose(env):
+    obs, _ = env.reset(seed=0)
+    base = env.unwrapped
+    agent = base.agent
+    assert agent.robot.max_dof == 15 and obs.shape == (3, 30)
+    # arm 7 + gripper 1 (mimic) + head / torso 3 + base (forward, turn) 2
+    assert base.single_action_space.shape == (13,)
+    assert agent.controller.action_mapping == {"arm": (0, 7), "gripper": (7, 8), "body": (8, 11), "base": (11, 13)}
+    assert set(agent.supported_control_modes) >= {"pd_joint_delta_pos", "pd_joint_pos", "pd_ee_delta_pos", "pd_ee_delta_pose", "pd_joint_target_delta_pos",
+                                                   "pd_ee_target_delta_pos", "pd_ee_target_delta_pose", "pd_joint_vel", "pd_joint_pos_vel", "pd_joint_delta_pos_vel",
+                                                   "pd_joint_delta_pos_stiff_body"}
+    rest = torch.as_tensor(agent.keyframes["rest"].qpos, dtype=torch.float32)
+    hold = torch.zeros(3, 13)
+    hold[:, 7] = -0.1666667  # the gripper target that equals the rest opening (0.015 in [-0.01, 0.05])
+    for _ in range(20):
+        env.step(hold)
+    q = agent.robot.get_qpos()
+    assert torch.allclose(q[:, 3:13], rest[3:13].expand(3, -1), atol=2e-3), q[0]  # (gravity is balanced: the links are weightless)
+    assert float(q[:, :3].abs().max()) < 1e-4 and torch.allclose(q[:, 13:], torch.full((3, 2), 0.015), atol=1e-3)
+    # the wheels share a collision bit with the ground (empty_env.py:41); the base's hull hovers within the contact offset
+    # of it and carries nothing (its height is fixed by the root joints)
+    for contact in base.scene.get_contacts(0):
+        assert {b.name for b in contact.bodies} == {"ground", "base_link"}
+        assert all(float(np.abs(p.impulse).max()) < 1e-6 for p in contact.points)
+    # the gripper frame sits in front of the torso at the rest pose
+    p = agent.tcp.pose.p[0]
+    assert 0.3 < float(p[0]) < 1.0 and abs(float(p[1])) < 0.3 and 0.3 < float(p[2]) < 1.3, p
+
+
+def test_base_actions_are_ego_centric(env):
+    env.reset(seed=0)
+    agent = env.unwrapped.agent
+    a = torch.zeros(3, 13)
+    a[:, 7] = -0.1666667
+    a[0, 11] = 1.0   # env 0: forward at the upper bound, 1 m/s
+    a[1, 12] = 0.5   # env 1: turn at half the bound, 1.57 rad/s
+    for _ in range(20):  # 1 s
+        env.step(a)
+    q = agent.robot.get_qpos()
+    assert 0.85 < float(q[0, 0]) < 1.0 and abs(float(q[0, 1])) < 1e-3 and abs(float(q[0, 2])) < 1e-3, q[0, :3]
+    assert abs(float(q[1, 2]) - np.pi / 2) < 0.12 and float(q[1, :2].abs().max()) < 1e-2, q[1, :3]  # (the arm's mass off the turning axis pulls the base a few mm against its velocity drives)
+    assert float(q[2, :3].abs().max()) < 1e-4
+    # env 1 now faces +y: "forward" moves it along y
+    b = torch.zeros(3, 13)
+    b[:, 7] = -0.1666667
+    b[1, 11] = 1.0
+    y0 = float(q[1, 1])
+    for _ in range(10):
+        env.step(b)
+    q2 = agent.robot.get_qpos()
+    yaw = float(q2[1, 2])
+    dx, dy = float(q2[1, 0] - q[1, 0]), float(q2[1, 1]) - y0
+    assert dy > 0.35 and abs(np.arctan2(dy, dx) - yaw) < 0.15, (dx, dy, yaw)
+    assert agent.is_static().tolist() == [False, False, True] or agent.is_static()[2]
+
+
+def test_fetch_arm_reaches_joint_targets(env):
+    env.reset(seed=0)
+    agent = env.unwrapped.agent
+    q0 = agent.robot.get_qpos().clone()
+    a = torch.zeros(3, 13)
+    a[:, 7] = -0.1666667
+    a[:, 0] = 1.0    # shoulder pan +0.1 rad per step
+    a[:, 10] = 1.0   # torso lift +0.1 m per step (limit 0.386 -> stays at the limit)
+    for _ in range(5):
+        env.step(a)
+    for _ in range(15):
+        b = torch.zeros(3, 13)
+        b[:, 7] = -0.1666667
+        env.step(b)
+    q = agent.robot.get_qpos()
+    # (a delta is added to the joint's current position, not to the previous target: a lagging joint covers less than 5 x 0.1)
+    moved = q[:, 5] - q0[:, 5]
+    assert torch.all(moved > 0.1) and torch.all(moved < 0.5), moved
+    assert torch.all(q[:, 3] <= 0.39)

@@ -443,3 +443,40 @@ def test_ee_modes_contact_overflow_is_rare(control_mode):
         env.step(2 * torch.rand(N, adim, device="cuda", generator=g) - 1)
     assert env.unwrapped.scene.px.overflow_count() < N // 200
     env.close()
+
+
+def test_fetch_empty_env_matches_oracle():
+    """Empty-v1 with the Fetch (15 velocity components: planar base as three root joints, torso, head, 7-joint arm, gripper;
+    the generic-topology kernel) against the oracle-backed env: same actions -- arm / body deltas, ego-centric base
+    velocities through `PDBaseForwardVelController`, which has no native action map -- same joint states; the base drives
+    where its yaw points."""
+    import gymnasium as gym
+
+    ob.register("f64", "oracle_f64_env")
+    N = 16
+    g = torch.Generator().manual_seed(3)
+    acts = [2 * torch.rand(N, 13, generator=g) - 1 for _ in range(12)]
+    for a in acts:
+        a[:, 11] = a[:, 11].abs()  # forward
+    outs = []
+    for backend in ("oracle_f64_env", BACKEND):
+        env = gym.make("Empty-v1", robot_uids="fetch", num_envs=N, obs_mode="state", sim_backend=backend)
+        env.reset(seed=5)
+        base = env.unwrapped
+        assert base.single_action_space.shape == (13,) and base.agent.robot.max_dof == 15
+        traj = []
+        for a in acts:
+            obs, *_ = env.step(a.to(base.device))
+            traj.append(obs.cpu().clone())
+        q = base.agent.robot.get_qpos().cpu()
+        tcp = base.agent.tcp.pose.raw_pose.cpu()
+        outs.append((traj, q, tcp))
+        if backend == BACKEND:
+            assert base.scene.px.overflow_count() == 0
+        env.close()
+    (ta, qa, pa), (tb, qb, pb) = outs
+    for a, b in zip(ta, tb):
+        assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
+    assert torch.allclose(pa, pb, atol=2e-3)
+    # 0.6 s of forward driving while turning: every base has moved, along its own heading on average
+    assert torch.all(torch.linalg.norm(qb[:, :2], dim=1) > 0.05)
