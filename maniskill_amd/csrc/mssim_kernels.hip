@@ -925,10 +925,25 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
           const float* src = d->env_shape_param;
           const int tcode = (int)src[(size_t)(4 * slot + 3) * NE + e];
           const int type = tcode > 0 ? tcode - 1 : d->shape_type[s2];
-          if (type < MSSIM_SHAPE_BOX || type > MSSIM_SHAPE_NONE) { g_create_error = "per-env shape type out of range (planes cannot be per-env shapes)"; mssim_destroy(S); return 8; }
+          // (a triangle mesh only as "this env has the slot's mesh": the slot's own type is TRIMESH and the env's triangle range is the slot's)
+          const bool env_mesh = type == MSSIM_SHAPE_TRIMESH && d->shape_type[s2] == MSSIM_SHAPE_TRIMESH &&
+                                src[(size_t)(4 * slot) * NE + e] == d->shape_param[4 * s2] && src[(size_t)(4 * slot + 1) * NE + e] == d->shape_param[4 * s2 + 1];
+          if ((type < MSSIM_SHAPE_BOX || type > MSSIM_SHAPE_NONE) && !env_mesh) { g_create_error = "per-env shape type out of range (planes cannot be per-env shapes; a triangle mesh only where the slot itself is that mesh)"; mssim_destroy(S); return 8; }
           int32_t word = type;
           float rows[3] = {src[(size_t)(4 * slot) * NE + e], src[(size_t)(4 * slot + 1) * NE + e], src[(size_t)(4 * slot + 2) * NE + e]};
           if (type == MSSIM_SHAPE_NONE) rows[0] = rows[1] = rows[2] = 0.f;
+          if (env_mesh) {  // root node of the BVH in the word's upper bits, the mesh's half extents about its bound centre in the rows
+            const int first = (int)d->shape_param[4 * s2], count = (int)d->shape_param[4 * s2 + 1];
+            if (first < 0 || count < 0 || first + count > d->n_tri) { g_create_error = "triangle mesh: triangle range out of tri_soup"; mssim_destroy(S); return 8; }
+            const float* b = d->shape_bound + 4 * s2;
+            rows[0] = rows[1] = rows[2] = 0.f;
+            for (int t = first; t < first + count; t++) {
+              const float* q = d->tri_soup + 12 * (size_t)t;
+              for (int c3 = 0; c3 < 3; c3++)
+                for (int k = 0; k < 3; k++) rows[k] = std::max(rows[k], std::fabs(q[k] + q[3 + 3 * c3 + k] - b[k]));
+            }
+            word |= d->shape_hull[2 * s2] << 10;
+          }
           if (type == MSSIM_SHAPE_CONVEX) {
             const int st = (int)rows[0], cnt = (int)rows[1];
             if (cnt < 1 || cnt > MSSIM_MAX_HULL_VERTS || st < 0 || st + cnt > d->n_hull_verts) { g_create_error = "per-env hull reference out of range"; mssim_destroy(S); return 8; }

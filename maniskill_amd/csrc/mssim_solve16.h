@@ -658,8 +658,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               const float* bb = M.env_shape_bound + (size_t)(4 * slot) * N + e;
               shBc[k] = f3{bb[0], bb[(size_t)N], bb[2 * (size_t)N]};
               shBr[k] = bb[3 * (size_t)N];
-              // per-env primitives are centred on their frame: box of the type's extents; a per-env hull brings its own
-              shH[k] = (ty == SH_BOX || ty == SH_CONVEX) ? f3{shP[k][0], shP[k][1], shP[k][2]}
+              // per-env primitives are centred on their frame: box of the type's extents; a per-env hull / mesh brings its own
+              shH[k] = (ty == SH_BOX || ty == SH_CONVEX || ty == SH_TRIMESH) ? f3{shP[k][0], shP[k][1], shP[k][2]}
                      : ty == SH_SPHERE ? f3{shP[k][0], shP[k][0], shP[k][0]}
                      : ty == SH_CAPSULE ? f3{shP[k][1] + shP[k][0], shP[k][0], shP[k][0]}
                      : f3{shP[k][1], shP[k][0], shP[k][0]};

@@ -443,6 +443,10 @@ class SceneModelBuilder:
                             env_hulls[key] = (len(hull_verts), len(v))
                             hull_verts.extend(v.tolist())
                         pr.append([float(env_hulls[key][0]), float(env_hulls[key][1]), 0.0, float(SHAPE_CONVEX + 1)])
+                    elif r_e.type == "trimesh":
+                        # (one mesh per slot -- envs either have it or not; its triangle range is filled in below)
+                        assert r_e is s["rec"] or (r_e.vertices is s["rec"].vertices and r_e.triangles is s["rec"].triangles), f"{s['owner']}: a slot holds one triangle mesh"
+                        pr.append([0.0, 0.0, 0.0, float(SHAPE_TRIMESH + 1)])
                     else:
                         pr.append([*r_e.param()[:3], float(_SHAPE_NAMES[r_e.type] + 1)])  # [3]: this env's shape type + 1
                     bd.append([*geom.transform_point(f_e, c_e), rad_e])
@@ -482,6 +486,10 @@ class SceneModelBuilder:
                 refs[leaf] = ~((~refs[leaf]) + n_tri0)     # leaf references: global triangle index
                 shull.append([n_nodes0, len(soup)])
                 sparam[-1] = np.array([float(n_tri0), float(len(soup)), 0.0, 0.0])  # its triangles: tri_soup[first .. first + count)
+                if s.get("env") is not None:
+                    rows = env_param[shape_env_slot[-1]]
+                    has = rows[3] == float(SHAPE_TRIMESH + 1)
+                    rows[0, has], rows[1, has] = float(n_tri0), float(len(soup))
                 tri_soup.append(soup)
                 tri_nodes.append(nodes)  # (kept as float32 arrays: the references are int32 bit patterns)
             else:

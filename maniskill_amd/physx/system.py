@@ -413,14 +413,20 @@ class MssimSystem:
         by_row = {}
         for c in lists["links"] + lists["dynamic"]:
             by_row[c.gpu_pose_index // max(self.num_envs, 1)] = c
+        # (a static body has no row: it is found by the name of its shape's owner)
+        statics = {c.name: c for c in lists["static"]}
         world = lists["static"][0] if lists["static"] else None
         out = []
         pair_shape, shape_row = m.arrays["pair_shape"], m.arrays["shape_row"]
+
+        def body_of(shape):
+            row = int(shape_row[shape])
+            return by_row[row] if row in by_row else statics.get(m.shape_owner[shape], world)
+
         for p in range(m.n_pair):
             if cnt[p] <= 0:
                 continue
-            ra, rb = int(shape_row[int(pair_shape[p][0])]), int(shape_row[int(pair_shape[p][1])])
-            out.append(PhysxContact(by_row.get(ra, world), by_row.get(rb, world), [PhysxContactPoint(impulse=imp[p].copy())]))
+            out.append(PhysxContact(body_of(int(pair_shape[p][0])), body_of(int(pair_shape[p][1])), [PhysxContactPoint(impulse=imp[p].copy())]))
         return out
 
     def sync_poses_gpu_to_cpu(self):

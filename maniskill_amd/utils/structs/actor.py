@@ -54,7 +54,8 @@ class Actor(_RigidBase):
         covered = sorted(by_env)
         first = by_env[covered[0]]
         assert all(by_env[i].px_body_type == first.px_body_type for i in covered)
-        assert first.px_body_type == "dynamic" or covered == list(range(N)), "only dynamic objects may exist in a subset of the envs"
+        # (a kinematic body is a row of the state in every env; a static one is geometry only, a dynamic one has mass 0 where it is absent)
+        assert first.px_body_type != "kinematic" or covered == list(range(N)), "a kinematic object has to exist in every env"
         name = name if name is not None else first.name
         # (an env without the object still has the body's row: it keeps this pose, has mass 0 there and takes part in nothing)
         raw = torch.cat([by_env.get(i, first).initial_pose.raw_pose[:1] for i in range(N)], dim=0)

@@ -95,3 +95,25 @@ def test_fetch_arm_reaches_joint_targets(env):
     moved = q[:, 5] - q0[:, 5]
     assert torch.all(moved > 0.1) and torch.all(moved < 0.5), moved
     assert torch.all(q[:, 3] <= 0.39)
+
+
+def test_fetch_in_rooms_that_differ_from_env_to_env(tmp_path):
+    """static triangle-mesh scenery per sub-scene: every env's Fetch is stopped by the wall of its own room"""
+    from tests.fetch_rooms import make_rooms_env
+
+    ob.register("f64", BACKEND)
+    env = make_rooms_env(str(tmp_path), 4, BACKEND)
+    env.reset(seed=0)
+    assert [w._own_idx.tolist() for w in env.walls] == [[0, 2], [1, 3]]
+    a = torch.zeros(4, 13)
+    a[:, 7] = -0.1666667
+    a[:, 11] = 1.0
+    for _ in range(50):
+        env.step(a)
+    q = env.agent.robot.get_qpos()
+    # the base (0.3 m radius, the folded arm reaching a little further) stands in front of its own wall
+    assert torch.all((q[0::2, 0] > 0.35) & (q[0::2, 0] < 0.6)) and torch.all((q[1::2, 0] > 0.95) & (q[1::2, 0] < 1.2)), q[:, 0]
+    assert float(q[:, 1:3].abs().max()) < 0.02 and env.scene.px.overflow_count() == 0
+    names = [{b.name for b in c.bodies} for c in env.scene.get_contacts(0)]
+    assert any("wall_0" in n for n in names) and not any("wall_1" in n for n in names)
+    env.close()

@@ -480,3 +480,33 @@ def test_fetch_empty_env_matches_oracle():
     assert torch.allclose(pa, pb, atol=2e-3)
     # 0.6 s of forward driving while turning: every base has moved, along its own heading on average
     assert torch.all(torch.linalg.norm(qb[:, :2], dim=1) > 0.05)
+
+
+def test_fetch_in_per_env_mesh_rooms_matches_oracle(tmp_path):
+    """BASELINE config 5's ingredients on synthetic scenery (tests/fetch_rooms.py): the Fetch, static triangle meshes that
+    exist in some sub-scenes only (per-env shape type TRIMESH / NONE on the mesh variant of the generic-topology kernel).
+    Every base is stopped by the wall of its own room, as on the oracle."""
+    from tests.fetch_rooms import make_rooms_env
+
+    ob.register("f64", "oracle_f64_env")
+    N = 6
+    a = torch.zeros(N, 13)
+    a[:, 7] = -0.1666667
+    a[:, 11] = 1.0
+    a[:, 12] = torch.linspace(-0.05, 0.05, N)  # (slightly different headings)
+    out = []
+    for backend in ("oracle_f64_env", BACKEND):
+        env = make_rooms_env(str(tmp_path), N, backend)
+        env.reset(seed=0)
+        traj = []
+        for _ in range(50):
+            obs, *_ = env.step(a.to(env.device))
+            traj.append(obs.cpu().clone())
+        assert env.scene.px.overflow_count() == 0
+        out.append((traj, env.agent.robot.get_qpos().cpu()))
+        env.close()
+    (ta, qa), (tb, qb) = out
+    assert torch.all((qb[0::2, 0] > 0.35) & (qb[0::2, 0] < 0.6)) and torch.all((qb[1::2, 0] > 0.95) & (qb[1::2, 0] < 1.2)), qb[:, 0]
+    for i, (x, y) in enumerate(zip(ta, tb)):
+        # (joint positions; velocities while the arm is pressed against a wall differ more)
+        assert torch.allclose(x[:, :15], y[:, :15], atol=5e-3), (i, (x[:, :15] - y[:, :15]).abs().max())
