@@ -373,6 +373,9 @@ int MSSIM_FN(overflow_count)(mssim_handle h, void* stream);
  *   target[j] = (flags[j] & 1 ? qpos[j] : 0) + a        (column[j] < 0: joint left untouched)
  *   flags[j] & 8: a is the joint's velocity drive target instead (pd_joint_vel.py:31-33); flags[j] & 4: the joint
  *   is driven by the end-effector block (set_ee_action_map)
+ *   flags[j] & 16 / & 32: a is multiplied by cos / sin of qpos[(flags[j] >> 8) & 31] -- the forward velocity of a planar
+ *   base whose x, y and yaw are joints of the articulation, given in the base's own frame
+ *   (agents/controllers/pd_base_vel.py:43-70: x joint: 16, y joint: 32, both on the forward column, yaw index in bits 8..12)
  * writes both the user-visible target_qpos buffer and the simulation state. All arrays [n_dof], host.
  * apply_action / step_action / defer_step_action fail (non-zero, last_error) when `action_dim` does not cover every
  * mapped column (the reference asserts action.shape == (num_envs, action_dim), base_controller.py:120-133). */

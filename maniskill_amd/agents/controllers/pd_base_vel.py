@@ -6,8 +6,10 @@ joints' velocity-drive targets by the current yaw.
 * `PDBaseVelController`: action = (forward, left, turn [, further joints]) velocities;
 * `PDBaseForwardVelController`: action = (forward, turn): a differential-drive base that cannot move sideways.
 
-Neither is an affine action -> target map (the yaw enters), so there is no native action map for them
-(`fused_action_spec` is None: the env applies the action through this class and then launches the step).
+The yaw enters, so this is not the affine map of the joint controllers; the native action map has two flags for the
+forward-only controller (include/mssim.h set_action_map: the x / y joint take the forward column times cos / sin of the
+yaw joint's position). The three-column controller has no native map (`fused_action_spec` None: the env applies the
+action through this class and then launches the step).
 """
 from dataclasses import dataclass
 
@@ -58,6 +60,22 @@ class PDBaseForwardVelController(PDBaseVelController):
         action = action.float()
         vx, vy = _base_frame_to_world(action[:, 0], torch.zeros_like(action[:, 0]), self.qpos[:, 2])
         return torch.cat([vx[:, None], vy[:, None], action[:, 1:]], dim=1)
+
+    def fused_action_spec(self):
+        """rows (dof, action column, low, high, flags) of the native action map: flag 8 = velocity target, 2 = clip + scale,
+        16 / 32 = times cos / sin of the yaw joint (its index in bits 8..12)"""
+        if len(self.joints) != 3:
+            return None
+        jx, jy, jyaw = self.active_joint_indices.tolist()
+        norm = self._normalize_action
+        lo = self.action_space_low.tolist() if norm else [0.0, 0.0]
+        hi = self.action_space_high.tolist() if norm else [0.0, 0.0]
+        base = 8 | (2 if norm else 0)
+        return [
+            (jx, 0, lo[0], hi[0], base | 16 | (jyaw << 8)),
+            (jy, 0, lo[0], hi[0], base | 32 | (jyaw << 8)),
+            (jyaw, 1, lo[1], hi[1], base),
+        ]
 
 
 @dataclass

@@ -391,6 +391,11 @@ __global__ void k_apply_action(DevModel M, DevState S, mssim_buffers B, const fl
       a = fminf(fmaxf(a, -1.f), 1.f);
       a = 0.5f * (hi[j] + lo[j]) + 0.5f * (hi[j] - lo[j]) * a;
     }
+    if (flags[j] & 48) {  // forward velocity of a planar base in its own frame (include/mssim.h set_action_map)
+      const int jy = (flags[j] >> 8) & 31;
+      const float yaw = B.art_qpos ? B.art_qpos[(size_t)e * n + jy] : SOA(S.q, jy);
+      a *= (flags[j] & 16) ? cosf(yaw) : sinf(yaw);
+    }
     if (flags[j] & 8) {  // velocity drive target (pd_joint_vel, agents/controllers/pd_joint_vel.py:31-33)
       SOA(S.qdt, j) = a;
       if (B.art_target_qvel) B.art_target_qvel[(size_t)e * n + j] = a;
@@ -1328,6 +1333,8 @@ int mssim_set_action_map(mssim_handle h, const int32_t* column, const float* low
   flush_deferred(h, h->deferred_stream);
   HIPCHK(h, hipSetDevice(h->device));
   const int n = h->M.n_dof > 0 ? h->M.n_dof : 1;
+  for (int j = 0; j < h->M.n_dof; j++)
+    if ((flags[j] & 48) && (((flags[j] >> 8) & 31) >= h->M.n_dof || (flags[j] & 48) == 48)) { h->err = "set_action_map: base-frame flags need one of cos / sin and a yaw joint of the articulation"; return 1; }
   if (!h->d_act_col) {
     int rc;
     if ((rc = dalloc(h, n, &h->d_act_col)) || (rc = dalloc(h, n, &h->d_act_lo)) || (rc = dalloc(h, n, &h->d_act_hi)) || (rc = dalloc(h, n, &h->d_act_flags))) return rc;

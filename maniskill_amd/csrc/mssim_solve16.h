@@ -549,6 +549,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         a = fminf(fmaxf(a, -1.f), 1.f);
         a = 0.5f * (S.act_hi[c] + S.act_lo[c]) + 0.5f * (S.act_hi[c] - S.act_lo[c]) * a;
       }
+      if (fl & 48) {  // forward velocity of a planar base, given in its own frame: x / y joint get its cos / sin share
+        const int jy = (fl >> 8) & 31;
+        const float yaw = S.act_qpos ? S.act_qpos[(size_t)e * n + jy] : SOA(S.q, jy);
+        a *= (fl & 16) ? cosf(yaw) : sinf(yaw);
+      }
       const float qj = S.act_qpos ? S.act_qpos[(size_t)e * n + c] : q_c;
       const float t = ((fl & 1) ? qj : 0.f) + a;
       if (live) {

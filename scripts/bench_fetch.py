@@ -14,12 +14,21 @@ env.reset(seed=0)
 acts = [2 * torch.rand(N, 13, device="cuda") - 1 for _ in range(16)]
 for i in range(20):
     env.step(acts[i % 16])
+px = env.unwrapped.scene.px
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(K):
     env.step(acts[i % 16])
+t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-px = env.unwrapped.scene.px
-print(f"Empty-v1 fetch N={N}: {N * K / dt / 1e6:.3f} M env-steps/s ({1e3 * dt / K:.3f} ms per env.step), overflow envs {px.overflow_count()}, "
+px.profile_enable(True)
+px.profile_read()
+for i in range(50):
+    env.step(acts[i % 16])
+torch.cuda.synchronize()
+prof = px.profile_read()
+px.profile_enable(False)
+kernel_ms = prof["solve"][0] / max(prof["solve"][1], 1)
+print(f"Empty-v1 fetch N={N}: {N * K / dt / 1e6:.3f} M env-steps/s ({1e3 * dt / K:.3f} ms per env.step), host issue {1e3 * t_issue / K:.3f} ms, control-step kernel {kernel_ms:.3f} ms, overflow envs {px.overflow_count()}, "
       f"finite {bool(torch.isfinite(env.unwrapped.agent.robot.get_qpos()).all())}")

@@ -21,14 +21,14 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 env_id = args[0] if len(args) > 0 else "PickCube-v1"
 N = int(args[1]) if len(args) > 1 else 4096
 steps = int(args[2]) if len(args) > 2 else 100
-env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos")
+env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos", **({"robot_uids": os.environ["MS_ROBOT"]} if os.environ.get("MS_ROBOT") else {}))  # (MS_ROBOT=fetch with Empty-v1)
 env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
 nb = min(2048, 4 * 8 * (((N + 15) // 16 + 7) // 8))  # one record per wave (4 envs); blocks are 4 waves
 arr = (ctypes.c_uint * (nb * 32))()
 for rep in range(3):
     for _ in range(steps):
-        env.step(2 * torch.rand(N, 8, device="cuda") - 1)
+        env.step(2 * torch.rand(N, env.unwrapped.single_action_space.shape[0], device="cuda") - 1)
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_blocks(arr, nb)
     a = np.frombuffer(arr, dtype=np.uint32).reshape(nb, 32).astype(np.int64)

@@ -19,7 +19,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 env_id = args[0] if len(args) > 0 else "PickCube-v1"
 N = int(args[1]) if len(args) > 1 else 4096
 steps = int(args[2]) if len(args) > 2 else 100
-env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos")
+env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode="pd_joint_delta_pos", **({"robot_uids": os.environ["MS_ROBOT"]} if os.environ.get("MS_ROBOT") else {}))  # (MS_ROBOT=fetch with Empty-v1)
 env.reset(seed=0)
 dbg = ctypes.CDLL(lib)
 buf = (ctypes.c_ulonglong * 32)()
@@ -32,7 +32,7 @@ for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" 
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
     for _ in range(k):
-        env.step(2 * torch.rand(N, 8, device="cuda") - 1)
+        env.step(2 * torch.rand(N, env.unwrapped.single_action_space.shape[0], device="cuda") - 1)
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)
     tot = sum(buf[i] for i in range(32))

@@ -87,7 +87,8 @@ def test_env_rollout_matches_oracle_backend(env_id):
         assert torch.allclose(a, b, atol=2e-3), (a - b).abs().max()
 
 
-@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos", "PickCube-v1:pd_ee_delta_pose", "PickCube-v1:pd_joint_vel"])
+@pytest.mark.parametrize("env_id", ["PickCube-v1", "PushCube-v1", "PegInsertionSide-v1", "PickCube-v1:pd_ee_delta_pos", "PickCube-v1:pd_ee_delta_pose", "PickCube-v1:pd_joint_vel",
+                                    "Empty-v1:fetch"])
 def test_fused_callers_match_torch_path(monkeypatch, env_id):
     """the fused native action map (joint-space map, and the end-effector block of pd_ee_delta_pos) + task
     epilogue give the same step outputs as the torch path"""
@@ -95,10 +96,12 @@ def test_fused_callers_match_torch_path(monkeypatch, env_id):
 
     env_id, _, control_mode = env_id.partition(":")
     kw = dict(control_mode=control_mode) if control_mode else {}
+    if control_mode == "fetch":  # (the Fetch in Empty-v1: the ego-centric base columns of the action map; reward mode "none")
+        kw = dict(robot_uids="fetch")
 
     N = 256
     g = torch.Generator().manual_seed(3)
-    adim = {"pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7}.get(control_mode, 8)
+    adim = {"pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7, "fetch": 13}.get(control_mode, 8)
     acts = [2 * torch.rand(N, adim, generator=g) - 1 for _ in range(12)]
     outs = []
     for fused in ("1", "0"):
