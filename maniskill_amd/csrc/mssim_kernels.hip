@@ -1230,8 +1230,10 @@ static void launch_control_step(mssim_handle h, const DevState& S, int n_substep
   const dim3 grid = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), block(64 * S16_WAVES);
   if (h->has_tri) {  // models with triangle meshes: the variant that carries the mesh stage (never with a task tail)
     if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
+    else if (h->M.n_dof == 15) hipLaunchKernelGGL((k_solve16<15, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
     else hipLaunchKernelGGL((k_solve16<0, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
   } else if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, TASK>), grid, block, 0, st, h->M, S, n_substeps);
+  else if (h->M.n_dof == 15) hipLaunchKernelGGL((k_solve16<15, 0>), grid, block, 0, st, h->M, S, n_substeps);  // (the Fetch)
   else hipLaunchKernelGGL((k_solve16<0, 0>), grid, block, 0, st, h->M, S, n_substeps);
   prof_mark(h, 0, st);
 }
