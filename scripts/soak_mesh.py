@@ -51,6 +51,8 @@ def reset():
 torch.manual_seed(0)
 reset()
 bad = 0
+px.profile_enable(True)
+px.profile_read()
 t0 = time.perf_counter()
 for k in range(1, K + 1):
     tq = px.cuda_articulation_target_qpos.torch()
@@ -66,7 +68,8 @@ for k in range(1, K + 1):
         reasons = {b: int(((ov & b) != 0).sum()) for b in (1, 2, 4, 8, 16)}
         print("   overflow reasons (bit: envs)", reasons)
         cz = px.cuda_rigid_body_data.torch()[row * N : (row + 1) * N, 2]
-        print(f"steps {k - 99:5d}-{k:5d}: {100 * N / (time.perf_counter() - t0) / 1e6:.2f} M env-steps/s, non-finite {bad}, overflow envs {px.overflow_count()}, "
+        prof = px.profile_read()
+        print(f"steps {k - 99:5d}-{k:5d}: {100 * N / (time.perf_counter() - t0) / 1e6:.2f} M env-steps/s, control-step kernel {prof['solve'][0] / max(prof['solve'][1], 1):.3f} ms, non-finite {bad}, overflow envs {px.overflow_count()}, "
               f"cube z min {float(cz.min()):.3f} max {float(cz.max()):.3f}, cubes below the table {int((cz < -0.05).sum())}")
         t0 = time.perf_counter()
     if k % 200 == 0:
