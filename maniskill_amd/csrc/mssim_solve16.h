@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
   __shared__ __attribute__((aligned(16))) float sm[S16_WAVES * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
   __shared__ int blk_nml[S16_WAVES * S16_ENVS_PER_BLOCK];  // generic-convex pairs of every env of the block (stage B task list)
   __shared__ int blk_nbl[S16_WAVES * S16_ENVS_PER_BLOCK];  // its box-box pairs that go to 16-lane groups (stage C task list)
+  __shared__ int blk_ntl[S16_WAVES * S16_ENVS_PER_BLOCK];  // its mesh-triangle tasks (stage T task list; TRI variants only)
   const int N = S.N;
   constexpr int BLK_ENVS = S16_WAVES * S16_ENVS_PER_BLOCK;
   const int wv = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
@@ -1181,6 +1182,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       // in range; a task gives a manifold of its own -- a new entry of the env's hit list -- which the patch pass merges with
       // those of the coplanar neighbours (include/mssim.h MSSIM_SHAPE_TRIMESH).
       if (TRI) {
+        PH(25);
         // T0, the env's own group: BVH traversal. A node is 16 child boxes, one per lane; children in range of the convex
         // shape's bounding sphere (+ contact offset, mesh frame) are pushed (nodes) or collected (triangles). The triangles
         // are then ranked by index (the order of the oracle's plain loop): rank r becomes hit nh + r and task ntask + r.
@@ -1293,21 +1295,26 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         range = step == MSSIM_TRI_RANGE_STEPS - 2 ? 0.f : 0.5f * range;
         }
         if (tri_over && live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_TRI);
-        // T1: the wave's tasks, one per 16-lane group at a time
-        int tcum[S16_ENVS_PER_BLOCK + 1];
-        tcum[0] = 0;
+        // T1: the triangle tasks of all the block's envs form one list that its 16 groups take round-robin, like the
+        // generic-convex pairs of stage B (an env with the whole arm on a mesh has 40-56 of them, its neighbours none)
+        if (c == 0) blk_ntl[gb] = ntask;
+        BSYNC();  // every env's task list is complete
+        int TT = 0;
 #pragma unroll
-        for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) tcum[j + 1] = tcum[j] + __shfl(ntask, 16 * j);
-        const int TT = tcum[S16_ENVS_PER_BLOCK];
-        WSYNC();
-        for (int t0 = 0; t0 < TT; t0 += S16_ENVS_PER_BLOCK) {
-          const bool has = t0 + g < TT;
-          const int t = has ? t0 + g : t0;
-          int ge = 0;
+        for (int j = 0; j < BLK_ENVS; j++) TT += blk_ntl[j];
+        for (int t0 = 0; t0 < TT; t0 += BLK_ENVS) {
+          const bool has = t0 + gb < TT;
+          const int t = has ? t0 + gb : t0;
+          int ge = 0, kt = t;
 #pragma unroll
-          for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += t >= tcum[j] ? 1 : 0;
-          float* Lg = smw + ge * S16_ENV_FLOATS;
-          const int tw = reinterpret_cast<const int*>(Lg + S16_NP_BSCR)[t - tcum[ge]];
+          for (int j = 0; j < BLK_ENVS - 1; j++) {
+            const int nj = blk_ntl[j];
+            const bool past = ge == j && kt >= nj;
+            kt -= past ? nj : 0;
+            ge += past ? 1 : 0;
+          }
+          float* Lg = sm + ge * S16_ENV_FLOATS;
+          const int tw = reinterpret_cast<const int*>(Lg + S16_NP_BSCR)[kt];
           const int tri = tw & 0xFFFFFF, idx = tw >> 24;
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
@@ -1491,7 +1498,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             cnt++;
           }
           f3 nrm = nf;
-          if (__any(has && cnt == 0)) {
+          // (no part of A is nearer to the triangle than its lowest point is to the triangle's plane: beyond the offset, no query)
+          const bool ask = has && cnt == 0 && s_low < offset;
+          if (__any(ask)) {
             // nothing over or under the triangle: the generic query (from the side, or a round shape next to / across it)
             f3 inside;
             {
@@ -1501,8 +1510,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             }
             manifold_t gq;
             manifold_clear(gq);
-            if (has && cnt == 0) collide_mpr_t(A, Tr, offset, gq, sup, true, inside);
-            if (has && cnt == 0 && gq.count > 0 && !(gq.sep[0] < s_low - 1e-3f)) {  // (an answer far below A's lowest gap over the plane: a ray out of the side, see the oracle)
+            if (ask) collide_mpr_t(A, Tr, offset, gq, sup, true, inside);
+            if (ask && gq.count > 0 && !(gq.sep[0] < s_low - 1e-3f)) {  // (an answer far below A's lowest gap over the plane: a ray out of the side, see the oracle)
               const bool face = dot(nf, gq.n) > 0.5f;
               nrm = face ? nf : gq.n;
               mx[0] = gq.x[0]; msep[0] = gq.sep[0];
@@ -1539,7 +1548,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             }
           }
         }
-        WSYNC();
+        BSYNC();  // the task lists lie in scratch that stage C uses next; manifolds written for other waves' envs are in place
+        PH(31);
       }
       BT_T(22);
       PH(25);

@@ -486,6 +486,7 @@ void tri_manifold(const Shape<Real>& A, const Shape<Real>& T, Real offset, Manif
     }
   }
   if (m.count > 0) return;
+  if (!(s_low < offset)) return;  // no part of A is nearer to the triangle than its lowest point is to the triangle's plane
   Vec inside;
   {
     Real w[3];

@@ -27,7 +27,7 @@ names = ["state load", "RNEA+CRBA tail", "Gauss-Jordan", "free bodies", "row bui
          "tail: copy-out + task epilogue", "#launches with a patch > 4 points", "np: task setup (shapes from LDS)", "np: plane", "np: box-box (one lane per pair)", "np: stage A rounds (plane / one-lane box-box) + staging",
          "#coop MPR task slots (max over groups)", "end: FK + carry", "end: velocity sum", "pgs: integrate/loop head", "pgs: limit rows", "pgs: contacts (LDS)", "pgs: contacts (global)",
          "np: contact patches + records", "np: shape table", "np: cull", "np: coop box-box (stage C)", "np: coop MPR (stage B)",
-         "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", ""]
+         "#survivor tasks per wave", "#plane tasks", "#box-box tasks", "#max contacts in block", "#contacts in block (4 envs)", "np: mesh triangles (stage T)"]
 for phase_name, k in (("fresh episodes", steps), ("after %d more unreset steps" % steps, steps)):
     torch.cuda.synchronize()
     dbg.mssim_debug_phase_clocks(buf, 1)

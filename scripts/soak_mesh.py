@@ -75,4 +75,12 @@ for k in range(1, K + 1):
     if k % 200 == 0:
         reset()
 assert bad == 0
+if os.environ.get("MSSIM_LIB", "").endswith("_clk.so"):  # (phase-clock build, scripts/phase_clocks.py --build: cycles per phase over the run)
+    import ctypes
+    dbg = ctypes.CDLL(os.environ["MSSIM_LIB"])
+    buf = (ctypes.c_ulonglong * 32)()
+    torch.cuda.synchronize()
+    dbg.mssim_debug_phase_clocks(buf, 1)
+    tot = sum(buf[i] for i in range(32))
+    print("phase clocks (slot: share of the summed wave cycles):", {i: round(100.0 * buf[i] / tot, 1) for i in range(32) if buf[i] > 0.003 * tot})
 print("soak ok")
