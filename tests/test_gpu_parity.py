@@ -790,6 +790,37 @@ def test_triangle_mesh_next_to_the_panda_matches_oracle():
     assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
 
 
+def test_kinematic_triangle_mesh_that_moves_matches_oracle():
+    """a triangle mesh on a KINEMATIC body (include/mssim.h: fixed or kinematic bodies carry meshes): a tray that is moved
+    up 2 mm per control step (and sideways in every other env) carries a cube up; kernel and oracle agree"""
+    from maniskill_amd.model import geom
+    from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+    from tests.test_oracle_contacts import _grid_mesh
+
+    V, F = _grid_mesh(n=4, size=0.4)
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("tray", "kinematic", [ShapeRecord("trimesh", geom.pose(), vertices=V, triangles=F)], initial_pose=geom.pose([0, 0, 0.1])))
+    b.add_actor(cube_record(p=(0.02, 0.01, 0.12)))
+    model = b.compile(sleep_threshold=0.0)
+    N = 4
+    gpu, cpu = make_pair(model, N)
+    tr, cu = model.row_of("tray"), model.row_of("cube")
+    for i in range(40):
+        for px in (gpu, cpu):
+            rb = px.cuda_rigid_body_data.torch()
+            rb[tr * N : (tr + 1) * N, 2] = 0.1 + 0.002 * (i + 1)
+            rb[tr * N : (tr + 1) * N, 0] = 0.001 * (i + 1) * torch.tensor([0.0, 1.0, 0.0, 1.0], device=px.device)
+            px.gpu_apply_rigid_dynamic_data()
+            px.step(1)
+            px.gpu_fetch_all()  # (the whole buffer is applied above: it has to hold the cube's current state)
+    a, b2 = get_state(gpu, model, N), get_state(cpu, model, N)
+    assert torch.allclose(a["rb"][cu, :, :7], b2["rb"][cu, :, :7], atol=1e-4), (a["rb"][cu, :, :7] - b2["rb"][cu, :, :7]).abs().max()
+    for st in (a, b2):
+        z = st["rb"][cu, :, 2]
+        assert torch.all(z > 0.185) and torch.all(z < 0.201), z  # carried up with the tray (0.18 + half a cube, minus what the position correction lags)
+    assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
+
+
 def test_bar_across_small_triangles_and_narrowed_search_range_match_oracle():
     """a long bar over a mesh finer than itself: most triangles under it see neither a corner of the bar nor have a corner
     under it -- their contacts are where their edges pass under the bar's outline (tri_manifold (3)); and within the contact
