@@ -2,8 +2,6 @@
 reward; the place to look at a robot and its controllers. `robot_uids` selects the robot ("panda" by default, "fetch").
 The ground carries the collision bit of the Fetch's wheels so that a base whose height is fixed by its root joints does
 not rest on it as well."""
-from typing import Dict
-
 import numpy as np
 import sapien
 import torch
@@ -15,37 +13,42 @@ from maniskill_amd.utils import sapien_utils
 from maniskill_amd.utils.building.ground import build_ground
 from maniskill_amd.utils.registration import register_env
 
+# both cameras look at the robot's base from the same corner (inert records: this build does not render)
+_EYE, _TARGET = [1.25, -1.25, 1.5], [0.0, 0.0, 0.2]
+
+
+def _camera(uid: str, size: int, fov: float) -> CameraConfig:
+    return CameraConfig(uid, sapien_utils.look_at(_EYE, _TARGET), size, size, fov, 0.01, 100)
+
 
 @register_env("Empty-v1", max_episode_steps=200000)
 class EmptyEnv(BaseEnv):
-    SUPPORTED_REWARD_MODES = ["none"]
     SUPPORTED_ROBOTS = ["panda", "fetch"]
+    SUPPORTED_REWARD_MODES = ["none"]
 
     def __init__(self, *args, robot_uids="panda", **kwargs):
         super().__init__(*args, robot_uids=robot_uids, **kwargs)
 
-    @property
-    def _default_sensor_configs(self):
-        return [CameraConfig("base_camera", sapien_utils.look_at([1.25, -1.25, 1.5], [0.0, 0.0, 0.2]), 128, 128, np.pi / 2, 0.01, 100)]
-
-    @property
-    def _default_human_render_camera_configs(self):
-        return CameraConfig("render_camera", sapien_utils.look_at([1.25, -1.25, 1.5], [0.0, 0.0, 0.2]), 2048, 2048, 1, 0.01, 100)
+    _default_sensor_configs = property(lambda self: [_camera("base_camera", 128, np.pi / 2)])
+    _default_human_render_camera_configs = property(lambda self: _camera("render_camera", 2048, 1))
 
     def _load_agent(self, options: dict):
-        super()._load_agent(options, sapien.Pose())
+        super()._load_agent(options, sapien.Pose())  # (the robot's root at the origin)
 
     def _load_scene(self, options: dict):
-        self.ground = build_ground(self.scene)
-        self.ground.set_collision_group_bit(group=2, bit_idx=FETCH_WHEELS_COLLISION_BIT, bit=1)
+        ground = build_ground(self.scene)
+        ground.set_collision_group_bit(group=2, bit_idx=FETCH_WHEELS_COLLISION_BIT, bit=1)
+        self.ground = ground
 
     def _initialize_episode(self, env_idx: torch.Tensor, options: dict):
         rest = self.agent.keyframes.get("rest")
-        if rest is not None and rest.qpos is not None:
-            self.agent.reset(torch.as_tensor(rest.qpos, dtype=torch.float32, device=self.device).repeat(len(env_idx), 1))
+        if rest is None or rest.qpos is None:
+            return
+        qpos = torch.as_tensor(rest.qpos, dtype=torch.float32, device=self.device)
+        self.agent.reset(qpos.repeat(len(env_idx), 1))
 
     def evaluate(self):
-        return {}
+        return dict()
 
-    def _get_obs_extra(self, info: Dict):
+    def _get_obs_extra(self, info: dict):
         return dict()
