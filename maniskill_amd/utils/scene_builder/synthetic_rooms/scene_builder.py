@@ -1,0 +1,125 @@
+"""SyntheticRooms: procedurally generated rooms for `SceneManipulation-v1`, standing in for the ReplicaCAD apartments of
+the reference (utils/scene_builder/replicacad/scene_builder.py:65-300), whose assets cannot be had here.
+
+What it keeps of the original: several static layouts (`build_configs`), one per sub-scene, chosen per env when the scene
+is built; scenery as static TRIANGLE MESHES (one mesh for a layout's walls, one for its furniture -- the collision meshes
+of ReplicaCAD are triangle meshes too), built with `set_scene_idxs` so that every piece exists only in the sub-scenes of
+its layout; start arrangements of the robot (`init_configs`: base position and heading, inside the room); navigable
+positions per env. What it does not have: objects to manipulate (a free body next to the Fetch's 15 joints is more than an
+env's 16 velocity components) and articulated furniture.
+
+A layout is a list of boxes (lo, hi) for its walls and another for its furniture; each list becomes one OBJ file in a
+scratch directory, loaded through `ActorBuilder.add_nonconvex_collision_from_file` like any asset.
+"""
+import os
+import tempfile
+from typing import List
+
+import numpy as np
+import sapien
+import torch
+
+from maniskill_amd.agents.robots.fetch import FETCH_WHEELS_COLLISION_BIT
+from maniskill_amd.utils.building.ground import build_ground
+from maniskill_amd.utils.scene_builder.registration import register_scene_builder
+from maniskill_amd.utils.scene_builder.scene_builder import SceneBuilder
+
+_FACES = np.array([[0, 2, 3], [0, 3, 1], [4, 5, 7], [4, 7, 6], [0, 1, 5], [0, 5, 4], [2, 6, 7], [2, 7, 3], [0, 4, 6], [0, 6, 2], [1, 3, 7], [1, 7, 5]])
+
+
+def _walls(x0, x1, y0, y1, height=1.2, thickness=0.1, door=None):
+    """four walls around [x0, x1] x [y0, y1]; `door` = (y_from, y_to) leaves a gap in the wall at x1"""
+    t = thickness
+    boxes = [((x0 - t, y0 - t, 0), (x0, y1 + t, height)), ((x0, y0 - t, 0), (x1, y0, height)), ((x0, y1, 0), (x1, y1 + t, height))]
+    if door is None:
+        boxes.append(((x1, y0 - t, 0), (x1 + t, y1 + t, height)))
+    else:
+        boxes += [((x1, y0 - t, 0), (x1 + t, door[0], height)), ((x1, door[1], 0), (x1 + t, y1 + t, height))]
+    return boxes
+
+
+# name -> (walls, furniture, navigable box (x0, x1, y0, y1) for the base, start arrangements (x, y, yaw))
+LAYOUTS = {
+    "study": (
+        _walls(-1.5, 1.5, -1.5, 1.5),
+        [((0.9, -0.6, 0.0), (1.5, 0.6, 0.75)), ((-1.5, 0.9, 0.0), (-0.9, 1.5, 0.45))],  # a desk against the far wall, a low cabinet in a corner
+        (-0.9, 0.3, -0.9, 0.5),
+        [(-0.6, 0.0, 0.0), (0.0, -0.6, np.pi / 2)],
+    ),
+    "corridor": (
+        _walls(-1.0, 3.0, -0.7, 0.7, door=(-0.45, 0.45)),
+        [((1.6, 0.35, 0.0), (2.2, 0.7, 0.9))],  # a shelf along one side
+        (-0.5, 2.4, -0.2, 0.1),
+        [(-0.5, 0.0, 0.0), (2.0, -0.1, np.pi)],
+    ),
+    "kitchen": (
+        _walls(-1.2, 1.8, -1.8, 1.2),
+        [((-1.2, -1.8, 0.0), (1.8, -1.2, 0.9)), ((0.2, -0.3, 0.0), (1.0, 0.5, 0.9))],  # a counter along one wall, an island
+        (-0.7, 1.3, -0.6, 0.7),
+        [(-0.6, 0.4, -np.pi / 2), (-0.6, -0.5, 0.0)],
+    ),
+}
+
+
+def _write_boxes_obj(path: str, boxes) -> None:
+    with open(path, "w") as fh:
+        for b, (lo, hi) in enumerate(boxes):
+            for i in range(8):
+                fh.write("v %.6f %.6f %.6f\n" % tuple((hi if (i >> k) & 1 else lo)[k] for k in range(3)))
+        for b in range(len(boxes)):
+            for tri in _FACES + 8 * b + 1:
+                fh.write("f %d %d %d\n" % tuple(tri))
+
+
+@register_scene_builder("SyntheticRooms")
+class SyntheticRoomsSceneBuilder(SceneBuilder):
+    build_configs = list(LAYOUTS)
+    init_configs = [0, 1]  # which of a layout's start arrangements
+    robot_initial_pose = sapien.Pose()
+
+    def __init__(self, env, robot_init_qpos_noise=0.02):
+        super().__init__(env, robot_init_qpos_noise)
+        self._mesh_dir = tempfile.mkdtemp(prefix="synthetic_rooms_")
+
+    def build(self, build_config_idxs: List[int] = None):
+        n = self.env.num_envs
+        if build_config_idxs is None:
+            build_config_idxs = [i % len(self.build_configs) for i in range(n)]
+        if len(build_config_idxs) == 1:
+            build_config_idxs = list(build_config_idxs) * n
+        assert len(build_config_idxs) == n, f"one layout per sub-scene: {n} envs, {len(build_config_idxs)} indices"
+        self.build_config_idxs = [int(i) for i in build_config_idxs]
+        self.scene_objects, self.movable_objects, self.articulations = {}, {}, {}
+        self.ground = build_ground(self.scene)
+        self.ground.set_collision_group_bit(group=2, bit_idx=FETCH_WHEELS_COLLISION_BIT, bit=1)
+        self.scene_objects["ground"] = self.ground
+        for li, name in enumerate(self.build_configs):
+            envs = [e for e, i in enumerate(self.build_config_idxs) if i == li]
+            if not envs:
+                continue
+            walls, furniture = LAYOUTS[name][0], LAYOUTS[name][1]
+            for part, boxes in (("walls", walls), ("furniture", furniture)):
+                path = os.path.join(self._mesh_dir, f"{name}_{part}.obj")
+                _write_boxes_obj(path, [(np.asarray(lo, float), np.asarray(hi, float)) for lo, hi in boxes])
+                b = self.scene.create_actor_builder()
+                b.add_nonconvex_collision_from_file(path)
+                b.set_scene_idxs(envs)
+                b.initial_pose = sapien.Pose()
+                self.scene_objects[f"{name}_{part}"] = b.build_static(name=f"{name}_{part}")
+        self.navigable_positions = [LAYOUTS[self.build_configs[i]][2] for i in self.build_config_idxs]
+
+    def initialize(self, env_idx: torch.Tensor, init_config_idxs: List[int] = None):
+        agent = self.env.agent
+        dev = self.env.device
+        idx = env_idx.tolist() if isinstance(env_idx, torch.Tensor) else list(env_idx)
+        if init_config_idxs is None:
+            init_config_idxs = [0] * self.env.num_envs
+        if len(init_config_idxs) == 1:
+            init_config_idxs = list(init_config_idxs) * self.env.num_envs
+        rest = torch.as_tensor(agent.keyframes["rest"].qpos, dtype=torch.float32, device=dev).repeat(len(idx), 1)
+        if agent.uid == "fetch":  # the base joints are the robot's place in the room
+            for row, e in enumerate(idx):
+                starts = LAYOUTS[self.build_configs[self.build_config_idxs[e]]][3]
+                x, y, yaw = starts[int(init_config_idxs[e]) % len(starts)]
+                rest[row, 0], rest[row, 1], rest[row, 2] = x, y, yaw
+        agent.reset(rest)

@@ -117,3 +117,44 @@ def test_fetch_in_rooms_that_differ_from_env_to_env(tmp_path):
     names = [{b.name for b in c.bodies} for c in env.scene.get_contacts(0)]
     assert any("wall_0" in n for n in names) and not any("wall_1" in n for n in names)
     env.close()
+
+
+def test_scene_manipulation_env_with_synthetic_rooms():
+    """SceneManipulation-v1 (envs/scenes/base_env.py) with the SyntheticRooms scene builder: one of three static layouts
+    per sub-scene (triangle-mesh walls and furniture that exist in that layout's envs only), start arrangements chosen at
+    reset, build configs only changeable with reconfigure"""
+    from maniskill_amd.utils.scene_builder import REGISTERED_SCENE_BUILDERS
+
+    ob.register("f64", BACKEND)
+    assert "SyntheticRooms" in REGISTERED_SCENE_BUILDERS
+    env = gym.make("SceneManipulation-v1", num_envs=6, obs_mode="state", sim_backend=BACKEND, build_config_idxs=[0, 1, 2, 0, 1, 2])
+    base = env.unwrapped
+    sb = base.scene_builder
+    assert sb.build_configs == ["study", "corridor", "kitchen"] and sb.build_config_names_to_idxs["kitchen"] == 2
+    assert base.agent.uid == "fetch" and base.scene.model.scalars["n_shape"] <= 28
+    assert sorted(sb.scene_objects) == ["corridor_furniture", "corridor_walls", "ground", "kitchen_furniture", "kitchen_walls", "study_furniture", "study_walls"]
+    assert sb.scene_objects["corridor_walls"]._own_idx.tolist() == [1, 4] and len(sb.navigable_positions) == 6
+    env.reset(seed=0, options=dict(init_config_idxs=[0, 0, 0, 1, 1, 1]))
+    q = base.agent.robot.get_qpos()
+    expect = torch.tensor([[-0.6, 0.0, 0.0], [-0.5, 0.0, 0.0], [-0.6, 0.4, -np.pi / 2], [0.0, -0.6, np.pi / 2], [2.0, -0.1, np.pi], [-0.6, -0.5, 0.0]])
+    assert torch.allclose(q[:, :3], expect, atol=1e-5), q[:, :3]
+    with pytest.raises(AssertionError):
+        env.reset(options=dict(build_config_idxs=[0] * 6))
+    # drive forward for 3 s: every base ends in front of what its own room has there
+    a = torch.zeros(6, 13)
+    a[:, 7] = -0.1666667
+    a[:, 11] = 1.0
+    for _ in range(60):
+        env.step(a)
+    q = base.agent.robot.get_qpos()
+    assert 0.45 < float(q[0, 0]) < 0.7        # study, facing the desk at x = 0.9
+    assert 2.0 < float(q[1, 0]) < 2.7         # corridor from its closed end: past the shelf (it leaves 0.35 m beside the axis), towards the door
+    assert -1.4 < float(q[2, 1]) < -0.6       # kitchen, facing the counter along y = -1.2
+    assert 0.9 < float(q[3, 1]) < 1.3         # study, facing the wall at y = 1.5
+    assert -0.8 < float(q[4, 0]) < -0.55      # corridor from the far end, back to the wall at x = -1
+    assert -0.2 < float(q[5, 0]) < 0.2        # kitchen, facing the island at x = 0.2
+    assert base.scene.px.overflow_count() == 0
+    # a new set of layouts needs a rebuild
+    env.reset(seed=1, options=dict(reconfigure=True, build_config_idxs=[2, 2, 2, 1, 1, 1]))
+    assert base.scene_builder.scene_objects["kitchen_walls"]._own_idx.tolist() == [0, 1, 2] and "study_walls" not in base.scene_builder.scene_objects
+    env.close()
