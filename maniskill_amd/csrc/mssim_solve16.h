@@ -1195,6 +1195,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         int ntask = 0;
         bool tri_over = false;
         const int nh0 = nh;
+        int nc_node[2] = {-1, -1}, nc_ref[2] = {0, 0}, nc_victim = 0;  // (node cache of the traversal, see below)
+        float nc_box[2][6];
+#pragma unroll
+        for (int w = 0; w < 2; w++)
+#pragma unroll
+          for (int k = 0; k < 6; k++) nc_box[w][k] = 0.f;
         // (the search range: the contact offset, narrowed while the triangles found do not fit -- MSSIM_TRI_RANGE_STEPS)
         float range = M.contact_offset;
 #pragma unroll 1
@@ -1221,9 +1227,24 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             const int node = stack[sp - 1];
             sp--;
             WSYNC();
-            const float* nd = M.tri_bvh + (size_t)node * 112;
-            const float lx = nd[6 * c], ly = nd[6 * c + 1], lz = nd[6 * c + 2], hx = nd[6 * c + 3], hy = nd[6 * c + 4], hz = nd[6 * c + 5];
-            const int ref = __float_as_int(nd[96 + c]);
+            // (this lane's child box and reference; the two nodes visited last are kept in registers: the pairs of an env mostly
+            // walk the same few nodes -- the roots of its one or two meshes --, and a node is an L2 round trip away)
+            float lx, ly, lz, hx, hy, hz;
+            int ref;
+            if (node == nc_node[0] || node == nc_node[1]) {  // (group-uniform)
+              const int w = node == nc_node[0] ? 0 : 1;
+              lx = nc_box[w][0]; ly = nc_box[w][1]; lz = nc_box[w][2]; hx = nc_box[w][3]; hy = nc_box[w][4]; hz = nc_box[w][5];
+              ref = nc_ref[w];
+              nc_victim = 1 - w;
+            } else {
+              const float* nd = M.tri_bvh + (size_t)node * 112;
+              lx = nd[6 * c]; ly = nd[6 * c + 1]; lz = nd[6 * c + 2]; hx = nd[6 * c + 3]; hy = nd[6 * c + 4]; hz = nd[6 * c + 5];
+              ref = __float_as_int(nd[96 + c]);
+#pragma unroll
+              for (int w = 0; w < 2; w++)
+                if (w == nc_victim) { nc_node[w] = node; nc_box[w][0] = lx; nc_box[w][1] = ly; nc_box[w][2] = lz; nc_box[w][3] = hx; nc_box[w][4] = hy; nc_box[w][5] = hz; nc_ref[w] = ref; }
+              nc_victim = 1 - nc_victim;
+            }
             const float dx = fmaxf(fmaxf(lx - cq.x, cq.x - hx), 0.f), dy = fmaxf(fmaxf(ly - cq.y, cq.y - hy), 0.f), dz = fmaxf(fmaxf(lz - cq.z, cq.z - hz), 0.f);
             bool in = lx <= hx && dx * dx + dy * dy + dz * dz <= rq * rq;
             in = in && !(lx - (cq.x + ext.x) > off_ || (cq.x - ext.x) - hx > off_ || ly - (cq.y + ext.y) > off_ || (cq.y - ext.y) - hy > off_ ||
