@@ -42,6 +42,7 @@ struct DevModel {
   const float* shape_half;    // [n_shape][3] half extents of a box in the SHAPE frame, centred at the bound centre, that contains the shape
   const float* tri_soup;      // [n_tri][12] triangle meshes: centroid, three corners relative to it (include/mssim.h)
   const float* tri_bvh;       // [n_tri_node][112] their 16-wide BVH
+  const int* pair_mesh_slot;  // [n_pair] ordinal of the pair among those whose second shape is a triangle mesh, else -1 (rows of DevState::tri_clear)
   // per-env overrides ([items][N], env fastest); slot < 0 = shared value
   const int *shape_env_slot, *free_env_slot;
   const float *env_shape_frame, *env_shape_param, *env_shape_bound, *env_free_inertial;
@@ -57,6 +58,8 @@ struct DevState {
   float* pcm;                                   // [N][MSSIM_PCM_SLOTS][48] persistent contact manifolds (mssim_solve16.h S16_PCM_LEN)
   int* pcm_tick;                                // [N] substep counter of the cache
   float* warm;                                  // [4 n_pair][N][4] contact multipliers (n, t1, t2) + substep stamp per (pair, manifold slot)
+  float* tri_clear;                             // [4 n_mesh_pair][N] per (convex shape, mesh) pair: the shape's bounding-sphere centre in the mesh frame at its last
+                                                // full BVH traversal and how far it may move from there before a triangle can be in range (<= 0: traverse)
   float *bodypose, *bodyvel;                    // [n_dof*7][N], [n_dof*6][N] (velocity about O = root position)
   float* bodyaux;                               // [n_dof*6][N] world joint axis (3) + joint anchor (3)
   int* pair_cnt;                                // [n_pair][N] contact points of the pair in the last substep (after the patch reduction)
@@ -1104,6 +1107,17 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
     const size_t nw = (size_t)4 * (d->n_pair > 0 ? d->n_pair : 1) * N * 4;
     if ((rc = dalloc(S, nw, &D.warm))) { mssim_destroy(S); return rc; }
     HIPCHK(S, hipMemset(D.warm, 0xFF, nw * sizeof(float)));  // stamp -1: nothing to start from
+  }
+  {
+    // clearance of every (convex shape, mesh) pair (mssim_solve16.h stage T0); NaN bit pattern = no clearance known
+    std::vector<int32_t> slot((size_t)(d->n_pair > 0 ? d->n_pair : 1), -1);
+    int n_mesh_pair = 0;
+    for (int p = 0; p < d->n_pair; p++)
+      if (d->shape_type[d->pair_shape[2 * p + 1]] == MSSIM_SHAPE_TRIMESH) slot[p] = n_mesh_pair++;
+    if ((rc = upload(S, slot.data(), slot.size(), &M.pair_mesh_slot))) { mssim_destroy(S); return rc; }
+    const size_t nc = (size_t)4 * (n_mesh_pair > 0 ? n_mesh_pair : 1) * N;
+    if ((rc = dalloc(S, nc, &D.tri_clear))) { mssim_destroy(S); return rc; }
+    HIPCHK(S, hipMemset(D.tri_clear, 0xFF, nc * sizeof(float)));
   }
 #undef AL
   // identity quaternions

@@ -1195,6 +1195,29 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         int ntask = 0;
         bool tri_over = false;
         const int nh0 = nh;
+        // Clearance of a (convex shape, mesh) pair: its last full traversal left the centre of the shape's bounding sphere
+        // (mesh frame) and the distance that centre may move before any triangle's box can come into range. While it has not,
+        // the pair is not traversed at all -- an arm in the middle of a room has 40 such pairs and is near nothing. The
+        // result is that of a traversal (every triangle lies in a box the traversal rejected by the same sphere test).
+        unsigned long long clear_mask = 0ull;  // bit idx: hit idx is a mesh pair known to be out of range
+        for (int base = 0; base < nh; base += 16) {
+          const int idx = base + c;
+          bool clear_ = false;
+          if (idx < nh) {
+            const int pk = hitw[idx];
+            const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
+            const int slot = (int)(__float_as_uint(tb_[14]) & 7u) == SH_TRIMESH ? M.pair_mesh_slot[pk & 0xFFFF] : -1;
+            if (slot >= 0) {
+              const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
+              const f3 cq = mtmulv(qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]}), f3{ta_[10], ta_[11], ta_[12]} - f3{tb_[0], tb_[1], tb_[2]});
+              const float* cl = S.tri_clear + (size_t)(4 * slot) * N + e;
+              const f3 dd = cq - f3{cl[0], cl[(size_t)N], cl[2 * (size_t)N]};
+              const float slack = cl[3 * (size_t)N];
+              clear_ = slack > 0.f && dot(dd, dd) < slack * slack;  // (an unset entry is a NaN: false)
+            }
+          }
+          clear_mask |= (unsigned long long)b16(clear_) << base;
+        }
         int nc_node[2] = {-1, -1}, nc_ref[2] = {0, 0}, nc_victim = 0;  // (node cache of the traversal, see below)
         float nc_box[2][6];
 #pragma unroll
@@ -1210,6 +1233,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int pk = hitw[idx];
           const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
           if ((int)(__float_as_uint(tb_[14]) & 7u) != SH_TRIMESH) continue;
+          if ((clear_mask >> idx) & 1ull) continue;
           const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
           const m3 RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});
           const f3 cq = mtmulv(RB, f3{ta_[10], ta_[11], ta_[12]} - f3{tb_[0], tb_[1], tb_[2]});
@@ -1221,6 +1245,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const f3 ext = f3{fabsf(ax0.x) + fabsf(ax1.x) + fabsf(ax2.x), fabsf(ax0.y) + fabsf(ax1.y) + fabsf(ax2.y), fabsf(ax0.z) + fabsf(ax1.z) + fabsf(ax2.z)};
           const float off_ = range;
           int sp = 1, ncand = 0;
+          float near2 = 3e38f;  // squared distance from cq to the nearest box that was examined and not descended into (this lane's share)
           if (c == 0) stack[0] = (int)(__float_as_uint(tb_[14]) >> 15);
           WSYNC();
           while (sp > 0) {
@@ -1277,10 +1302,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               }
             }
             const unsigned mn = b16(in && ref >= 0), ml2 = b16(in && ref < 0), lt = (1u << c) - 1u;
+            bool descend = false;
             if (in && ref >= 0) {
               const int at = sp + __popc(mn & lt);
-              if (at < 20) stack[at] = ref; else tri_over = true;
+              if (at < 20) { stack[at] = ref; descend = true; } else tri_over = true;
             }
+            if (lx <= hx && !descend) near2 = fminf(near2, dx * dx + dy * dy + dz * dz);  // (its triangles are all inside this box)
             if (in && ref < 0) {
               const int at = ncand + __popc(ml2 & lt);
               if (at < MSSIM_MAX_TRI_HITS) cand[at] = ~ref; else tri_over = true;
@@ -1288,6 +1315,14 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             sp = min(sp + __popc(mn), 20);
             ncand = min(ncand + __popc(ml2), MSSIM_MAX_TRI_HITS);
             WSYNC();
+          }
+          if (step == 0) {  // (full range: what this traversal says about the pair's clearance)
+            const int slot = M.pair_mesh_slot[pk & 0xFFFF];
+            const float slack = fminf(sqrt_f(-gmax16(-near2)) - rq, 1e6f);
+            if (c == 0 && live && slot >= 0) {
+              float* cl = S.tri_clear + (size_t)(4 * slot) * N + e;
+              cl[0] = cq.x; cl[(size_t)N] = cq.y; cl[2 * (size_t)N] = cq.z; cl[3 * (size_t)N] = slack;
+            }
           }
           // rank by triangle index; room in the hit list and the task list permitting
 #pragma unroll
