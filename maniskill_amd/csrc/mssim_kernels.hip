@@ -857,6 +857,11 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   }
   for (int j = 0; j < d->n_dof; j++)
     if (d->dof_parent[j] >= j) { g_create_error = "dof_parent must be topologically sorted"; return 4; }
+  for (int p = 0; p < d->n_pair; p++)
+    if (d->pair_shape[2 * p] < 0 || d->pair_shape[2 * p] >= d->n_shape || d->pair_shape[2 * p + 1] < 0 || d->pair_shape[2 * p + 1] >= d->n_shape) {
+      g_create_error = "pair_shape names a shape that does not exist";
+      return 4;
+    }
   for (int s = 0; s < d->n_shape; s++)
     if (d->shape_type[s] == MSSIM_SHAPE_CONVEX && (d->shape_hull[2 * s + 1] < 4 || d->shape_hull[2 * s + 1] > MSSIM_MAX_HULL_VERTS)) {
       g_create_error = "convex hull vertex count out of range";

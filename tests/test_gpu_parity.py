@@ -654,6 +654,12 @@ def test_create_rejects_what_the_kernel_cannot_hold():
     with pytest.raises(RuntimeError, match="plane"):
         MssimSystem(device="cuda:0").gpu_init(model, N)
     par[:] = keep
+    pairs = model.arrays["pair_shape"]
+    keep_pairs = pairs.copy()
+    pairs.reshape(-1)[1] = 99  # a pair that names shape 99
+    with pytest.raises(RuntimeError, match="pair_shape"):
+        MssimSystem(device="cuda:0").gpu_init(model, N)
+    pairs[:] = keep_pairs
     MssimSystem(device="cuda:0").gpu_init(model, N)  # (the untouched model is fine)
 
 
