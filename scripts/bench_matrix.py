@@ -30,7 +30,7 @@ def run(env_id, N, steps=1000, control_mode="pd_joint_delta_pos", **kw):
         if (i + 1) % 200 == 0:
             env.reset()
     torch.cuda.synchronize(); dt_reset = time.perf_counter() - t
-    out = dict(env_id=env_id, num_envs=N, control_mode=control_mode, substeps=base._sim_steps_per_control, steps=steps, step_only=round(N * steps / dt_step),
+    out = dict(env_id=env_id + (":fetch" if kw.get("robot_uids") == "fetch" or env_id.startswith("SceneManipulation") else ""), num_envs=N, control_mode=control_mode, substeps=base._sim_steps_per_control, steps=steps, step_only=round(N * steps / dt_step),
                step_only_first_200=round(N * 200 / dt_200) if dt_200 else None, step_reset_every_200=round(N * steps / dt_reset),
                ms_per_step=round(dt_step / steps * 1e3, 3), overflow_envs=overflow + base.scene.px.overflow_count())
     print(json.dumps(out), flush=True)
@@ -40,6 +40,8 @@ only = sys.argv[1:]
 for args, kw in ((("PickCube-v1", 4096), {}), (("PushCube-v1", 4096), {}), (("PegInsertionSide-v1", 2048), {}),
                  (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pos")), (("PickCube-v1", 4096), dict(control_mode="pd_ee_delta_pose")),
                  (("PickCube-v1", 16384), {}),
-                 (("PickCube-v1", 4096), dict(sim_config=dict(control_freq=25)))):  # 4 substeps (SURVEY 8d reports 5 and 4)
+                 (("PickCube-v1", 4096), dict(sim_config=dict(control_freq=25))),  # 4 substeps (SURVEY 8d reports 5 and 4)
+                 # BASELINE config 5's robot and env count: the Fetch on an empty ground, and in synthetic triangle-mesh rooms
+                 (("Empty-v1", 1024), dict(robot_uids="fetch")), (("SceneManipulation-v1", 1024), dict(build_config_idxs=[i % 3 for i in range(1024)]))):
     if not only or args[0] in only or kw.get("control_mode") in only or ("substeps4" in only and "sim_config" in kw):
         run(*args, **kw)
