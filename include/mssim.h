@@ -98,7 +98,8 @@ extern "C" {
 #define MSSIM_TRI_SLACK 4e-3f    /* m: a convex shape's points this much higher above a triangle's plane than its lowest one give no contact */
 #define MSSIM_TRI_TIE 1e-5f      /* m: candidates of a triangle whose gaps differ by less are equally deep (the first in order is kept) */
 #define MSSIM_MAX_TRI_HITS 32   /* triangles of one mesh in range of one convex shape at a time (more: reported overflow) */
-#define MSSIM_MAX_TRI_TASKS 56  /* triangles in range over all (convex shape, mesh) pairs of an env (they also share MSSIM_MAX_HITS) */
+#define MSSIM_MAX_TRI_TASKS 56  /* triangles in range over all (convex shape, mesh) pairs of an env (they also share MSSIM_MAX_HITS with the
+                                   surviving pairs of other kinds; a (convex shape, mesh) pair itself takes no entry there) */
 /* The range in which triangles are looked for is the contact offset. When that finds more triangles than there is room
  * for (either capacity above, or the hit list), the env's search is repeated with the range halved, quartered and finally
  * zero (triangles the convex shape's oriented box touches): the speculative contacts furthest out are given up first and

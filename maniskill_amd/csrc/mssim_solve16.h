@@ -706,6 +706,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       PH(22);
       // ---- cull: 16 pairs of this env per round, survivors appended in pair order
       int nh = 0;
+      int nmesh = 0;  // (TRI) surviving (convex shape, mesh) pairs of this env: a list of its own in the record area, idle until the narrowphase ends
       bool hit_over = false;
       // stage 1: bounding spheres / plane distance, all pairs (16 per round); survivors appended in pair order
       auto cull_round = [&](int p, int sab) __attribute__((always_inline)) {
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll 1
         for (int base = 0; base < nh; base += 16) {
           const int idx = base + c;
-          bool keep = false;
+          bool keep = false, mesh = false;
           int pk = 0;
           if (idx < nh) {
             pk = reinterpret_cast<const int*>(L)[S16_NP_SCR + idx];
@@ -769,6 +770,18 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               const f3 d = f3{tb_[10], tb_[11], tb_[12]} - f3{ta_[10], ta_[11], ta_[12]};
               keep = !obb_separated(RA, f3{ta_[16], ta_[17], ta_[18]}, RB, f3{tb_[16], tb_[17], tb_[18]}, d, M.contact_offset);
             }
+            // (a surviving (convex shape, mesh) pair goes to the mesh list of stage T: only its triangles in range take hit entries)
+            mesh = TRI && keep && (int)(__float_as_uint(tb_[14]) & 7u) == SH_TRIMESH;
+            keep = keep && !mesh;
+          }
+          if (TRI) {
+            const unsigned mm = (unsigned)(__ballot(mesh) >> (16 * g)) & 0xFFFFu;
+            const int rankm = nmesh + __popc(mm & ((1u << c) - 1u));
+            if (mesh) {
+              if (rankm < S16_MAX_HIT) reinterpret_cast<int*>(L)[S16_REC + rankm] = pk;
+              else hit_over = true;
+            }
+            nmesh = min(nmesh + __popc(mm), S16_MAX_HIT);
           }
           const unsigned m16 = (unsigned)(__ballot(keep) >> (16 * g)) & 0xFFFFu;
           const int rank = nh2 + __popc(m16 & ((1u << c) - 1u));
@@ -779,7 +792,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           nh2 += __popc(m16);
         }
         nh = nh2 < S16_MAX_HIT ? nh2 : S16_MAX_HIT;
-        if (!live) nh = 0;  // (a shadow group of the last env produces nothing: its pairs would touch that env's manifold cache twice)
+        if (!live) { nh = 0; nmesh = 0; }  // (a shadow group of the last env produces nothing: its pairs would touch that env's manifold cache twice)
       }
       WSYNC();
       if (__any(hit_over) && hit_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_HITS);
@@ -1199,14 +1212,15 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         // (mesh frame) and the distance that centre may move before any triangle's box can come into range. While it has not,
         // the pair is not traversed at all -- an arm in the middle of a room has 40 such pairs and is near nothing. The
         // result is that of a traversal (every triangle lies in a box the traversal rejected by the same sphere test).
-        unsigned long long clear_mask = 0ull;  // bit idx: hit idx is a mesh pair known to be out of range
-        for (int base = 0; base < nh; base += 16) {
+        const int* const meshl = reinterpret_cast<const int*>(L) + S16_REC;  // the env's mesh pairs (from the cull)
+        unsigned long long clear_mask = 0ull;  // bit i: mesh pair i is known to be out of range
+        for (int base = 0; base < nmesh; base += 16) {
           const int idx = base + c;
           bool clear_ = false;
-          if (idx < nh) {
-            const int pk = hitw[idx];
+          if (idx < nmesh) {
+            const int pk = meshl[idx];
             const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
-            const int slot = (int)(__float_as_uint(tb_[14]) & 7u) == SH_TRIMESH ? M.pair_mesh_slot[pk & 0xFFFF] : -1;
+            const int slot = M.pair_mesh_slot[pk & 0xFFFF];
             if (slot >= 0) {
               const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
               const f3 cq = mtmulv(qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]}), f3{ta_[10], ta_[11], ta_[12]} - f3{tb_[0], tb_[1], tb_[2]});
@@ -1229,10 +1243,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll 1
         for (int step = 0; step < MSSIM_TRI_RANGE_STEPS; step++) {
         nh = nh0; ntask = 0; tri_over = false;
-        for (int idx = 0; idx < nh0; idx++) {  // (group-uniform)
-          const int pk = hitw[idx];
+        for (int idx = 0; idx < nmesh; idx++) {  // (group-uniform)
+          const int pk = meshl[idx];
           const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
-          if ((int)(__float_as_uint(tb_[14]) & 7u) != SH_TRIMESH) continue;
           if ((clear_mask >> idx) & 1ull) continue;
           const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
           const m3 RB = qmat(q4{tb_[3], tb_[4], tb_[5], tb_[6]});

@@ -837,8 +837,9 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
       Vec ca, cb;
       Real ra;
       if (!survives(p, ca, cb, ra)) continue;
-      nh0++;
+      // (a mesh pair takes no entry of the kernels' hit list itself: its triangles in range do)
       if (sh[M.pair_shape[2 * p + 1]].type == SH_TRIMESH) { mesh_pairs.push_back(p); mesh_ca.push_back(ca); mesh_ra.push_back(ra); }
+      else nh0++;
     }
     nh0 = std::min(nh0, (int)MSSIM_MAX_HITS);
     Real range = M.contact_offset;
