@@ -1,5 +1,5 @@
 """The Fetch driving around procedurally generated rooms: `SceneManipulation-v1` with the `SyntheticRooms` scene builder
-(one of three triangle-mesh layouts per sub-scene). Random arm / head actions, the base drives forward and turns away when
+(one of five triangle-mesh layouts per sub-scene). Random arm / head actions, the base drives forward and turns away when
 it stops making progress.   usage: python examples/fetch_rooms.py [num_envs] [steps]"""
 import os
 import sys
@@ -13,7 +13,7 @@ import gymnasium as gym
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-env = gym.make("SceneManipulation-v1", num_envs=N, obs_mode="state", build_config_idxs=[i % 3 for i in range(N)])
+env = gym.make("SceneManipulation-v1", num_envs=N, obs_mode="state", build_config_idxs=[i % 5 for i in range(N)])
 obs, _ = env.reset(seed=0)
 base = env.unwrapped
 builder = base.scene_builder

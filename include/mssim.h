@@ -256,9 +256,10 @@ typedef struct mssim_model_desc {
                                     convex shape: first vertex in hull_verts, vertex count <= MSSIM_MAX_HULL_VERTS, -, as
                                     float-valued integers: a different hull per env), row 3 = the env's shape type + 1 as a
                                     float-valued integer, 0 = shape_type[s]. Envs may carry different shape types in a slot
-                                    (never a plane; a triangle mesh only in a slot that IS that mesh, rows 0..1 = the slot's
-                                    triangle range: the env has the mesh, MSSIM_SHAPE_NONE: it has not -- a static piece of
-                                    scenery built into some of the sub-scenes) or none at all -- the reference's per-env object sets:
+                                    (never a plane; a triangle mesh only in a slot whose own type is a triangle mesh: rows 0..2 =
+                                    first triangle in tri_soup, triangle count, root node in tri_bvh of THIS env's mesh --
+                                    scenery that differs from sub-scene to sub-scene, or is absent: MSSIM_SHAPE_NONE) or none
+                                    at all -- the reference's per-env object sets:
                                     one object model per sub-scene, merged into one actor (utils/structs/actor.py:99-126). A
                                     free body whose mass (env_free_inertial row 0) is 0 in an env does not exist there: it
                                     is never awake, keeps the pose it is given and takes part in nothing              */

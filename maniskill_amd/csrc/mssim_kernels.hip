@@ -938,24 +938,34 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
           const float* src = d->env_shape_param;
           const int tcode = (int)src[(size_t)(4 * slot + 3) * NE + e];
           const int type = tcode > 0 ? tcode - 1 : d->shape_type[s2];
-          // (a triangle mesh only as "this env has the slot's mesh": the slot's own type is TRIMESH and the env's triangle range is the slot's)
-          const bool env_mesh = type == MSSIM_SHAPE_TRIMESH && d->shape_type[s2] == MSSIM_SHAPE_TRIMESH &&
-                                src[(size_t)(4 * slot) * NE + e] == d->shape_param[4 * s2] && src[(size_t)(4 * slot + 1) * NE + e] == d->shape_param[4 * s2 + 1];
-          if ((type < MSSIM_SHAPE_BOX || type > MSSIM_SHAPE_NONE) && !env_mesh) { g_create_error = "per-env shape type out of range (planes cannot be per-env shapes; a triangle mesh only where the slot itself is that mesh)"; mssim_destroy(S); return 8; }
+          // (a triangle mesh only in a slot whose own type is TRIMESH: the mesh variant of the kernel is chosen by the shared types)
+          const bool env_mesh = type == MSSIM_SHAPE_TRIMESH && d->shape_type[s2] == MSSIM_SHAPE_TRIMESH;
+          if ((type < MSSIM_SHAPE_BOX || type > MSSIM_SHAPE_NONE) && !env_mesh) { g_create_error = "per-env shape type out of range (planes cannot be per-env shapes; a triangle mesh only in a slot that is a triangle mesh)"; mssim_destroy(S); return 8; }
           int32_t word = type;
           float rows[3] = {src[(size_t)(4 * slot) * NE + e], src[(size_t)(4 * slot + 1) * NE + e], src[(size_t)(4 * slot + 2) * NE + e]};
           if (type == MSSIM_SHAPE_NONE) rows[0] = rows[1] = rows[2] = 0.f;
-          if (env_mesh) {  // root node of the BVH in the word's upper bits, the mesh's half extents about its bound centre in the rows
-            const int first = (int)d->shape_param[4 * s2], count = (int)d->shape_param[4 * s2 + 1];
-            if (first < 0 || count < 0 || first + count > d->n_tri) { g_create_error = "triangle mesh: triangle range out of tri_soup"; mssim_destroy(S); return 8; }
-            const float* b = d->shape_bound + 4 * s2;
+          if (env_mesh) {
+            // this env's mesh: rows = first triangle, triangle count, root node of its BVH. The device row gets the root in
+            // the word's upper bits and the mesh's half extents about its bound centre (shape frame) in the rows.
+            const int first = (int)rows[0], count = (int)rows[1], root = (int)rows[2];
+            if (first < 0 || count < 0 || first + count > d->n_tri || root < 0 || root >= d->n_tri_node) { g_create_error = "per-env triangle mesh: triangle range / root node out of range"; mssim_destroy(S); return 8; }
+            float fr[7], cb[3];
+            for (int k = 0; k < 7; k++) fr[k] = d->env_shape_frame[(size_t)(7 * slot + k) * NE + e];
+            for (int k = 0; k < 3; k++) cb[k] = d->env_shape_bound[(size_t)(4 * slot + k) * NE + e] - fr[k];
+            const float nq = std::sqrt(fr[3] * fr[3] + fr[4] * fr[4] + fr[5] * fr[5] + fr[6] * fr[6]);
+            const float qw = fr[3] / nq, qx = fr[4] / nq, qy = fr[5] / nq, qz = fr[6] / nq;
+            const float R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)},
+                                   {2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)},
+                                   {2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
+            float cs[3];
+            for (int k = 0; k < 3; k++) cs[k] = R[0][k] * cb[0] + R[1][k] * cb[1] + R[2][k] * cb[2];
             rows[0] = rows[1] = rows[2] = 0.f;
             for (int t = first; t < first + count; t++) {
               const float* q = d->tri_soup + 12 * (size_t)t;
               for (int c3 = 0; c3 < 3; c3++)
-                for (int k = 0; k < 3; k++) rows[k] = std::max(rows[k], std::fabs(q[k] + q[3 + 3 * c3 + k] - b[k]));
+                for (int k = 0; k < 3; k++) rows[k] = std::max(rows[k], std::fabs(q[k] + q[3 + 3 * c3 + k] - cs[k]));
             }
-            word |= d->shape_hull[2 * s2] << 10;
+            word |= root << 10;
           }
           if (type == MSSIM_SHAPE_CONVEX) {
             const int st = (int)rows[0], cnt = (int)rows[1];

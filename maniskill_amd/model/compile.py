@@ -428,6 +428,23 @@ class SceneModelBuilder:
                 v = mesh.simplify_hull(v, MAX_HULL_VERTS)
             return v
 
+        env_meshes = {}  # id(vertex array) -> (first triangle, triangle count, root node): a mesh shared by envs / slots is stored once
+
+        def add_mesh(rec):
+            key = (id(rec.vertices), id(rec.triangles))
+            if key not in env_meshes:
+                soup = mesh.triangle_soup(rec.vertices, rec.triangles)
+                nodes = mesh.build_bvh16(soup)
+                refs = nodes[:, 96:].view(np.int32)
+                n_nodes0, n_tri0 = sum(len(x) for x in tri_nodes), sum(len(x) for x in tri_soup)
+                leaf = (refs < 0) & (refs != -2**31)
+                refs[refs >= 0] += n_nodes0                # node references: global node index
+                refs[leaf] = ~((~refs[leaf]) + n_tri0)     # leaf references: global triangle index
+                tri_soup.append(soup)
+                tri_nodes.append(nodes)  # (kept as float32 arrays: the references are int32 bit patterns)
+                env_meshes[key] = (n_tri0, len(soup), n_nodes0)
+            return env_meshes[key]
+
         for s in shapes:
             if s.get("env") is not None:
                 fr, pr, bd = [], [], []
@@ -444,9 +461,9 @@ class SceneModelBuilder:
                             hull_verts.extend(v.tolist())
                         pr.append([float(env_hulls[key][0]), float(env_hulls[key][1]), 0.0, float(SHAPE_CONVEX + 1)])
                     elif r_e.type == "trimesh":
-                        # (one mesh per slot -- envs either have it or not; its triangle range is filled in below)
-                        assert r_e is s["rec"] or (r_e.vertices is s["rec"].vertices and r_e.triangles is s["rec"].triangles), f"{s['owner']}: a slot holds one triangle mesh"
-                        pr.append([0.0, 0.0, 0.0, float(SHAPE_TRIMESH + 1)])
+                        # this env's mesh: first triangle, triangle count, root node of its BVH (a different mesh per env is fine)
+                        assert s["kind"] in (BODY_WORLD, BODY_KIN), f"{s['owner']}: triangle-mesh collision needs a static or kinematic body"
+                        pr.append([*map(float, add_mesh(r_e)), float(SHAPE_TRIMESH + 1)])
                     else:
                         pr.append([*r_e.param()[:3], float(_SHAPE_NAMES[r_e.type] + 1)])  # [3]: this env's shape type + 1
                     bd.append([*geom.transform_point(f_e, c_e), rad_e])
@@ -477,21 +494,9 @@ class SceneModelBuilder:
                 # triangle mesh (static / kinematic bodies): its triangles join the soup, its 16-wide BVH the node table;
                 # shape_hull = (root node, triangle count) -- include/mssim.h MSSIM_SHAPE_TRIMESH
                 assert s["kind"] in (BODY_WORLD, BODY_KIN), f"{s['owner']}: triangle-mesh collision needs a static or kinematic body"
-                soup = mesh.triangle_soup(r.vertices, r.triangles)
-                nodes = mesh.build_bvh16(soup)
-                refs = nodes[:, 96:].view(np.int32)
-                n_nodes0, n_tri0 = sum(len(x) for x in tri_nodes), sum(len(x) for x in tri_soup)
-                leaf = (refs < 0) & (refs != -2**31)
-                refs[refs >= 0] += n_nodes0                # node references: global node index
-                refs[leaf] = ~((~refs[leaf]) + n_tri0)     # leaf references: global triangle index
-                shull.append([n_nodes0, len(soup)])
-                sparam[-1] = np.array([float(n_tri0), float(len(soup)), 0.0, 0.0])  # its triangles: tri_soup[first .. first + count)
-                if s.get("env") is not None:
-                    rows = env_param[shape_env_slot[-1]]
-                    has = rows[3] == float(SHAPE_TRIMESH + 1)
-                    rows[0, has], rows[1, has] = float(n_tri0), float(len(soup))
-                tri_soup.append(soup)
-                tri_nodes.append(nodes)  # (kept as float32 arrays: the references are int32 bit patterns)
+                n_tri0, n_tri, n_nodes0 = add_mesh(r)
+                shull.append([n_nodes0, n_tri])
+                sparam[-1] = np.array([float(n_tri0), float(n_tri), 0.0, 0.0])  # its triangles: tri_soup[first .. first + count)
             else:
                 shull.append([0, 0])
             c, rad = r.bound()

@@ -3,8 +3,9 @@ the reference (utils/scene_builder/replicacad/scene_builder.py:65-300), whose as
 
 What it keeps of the original: several static layouts (`build_configs`), one per sub-scene, chosen per env when the scene
 is built; scenery as static TRIANGLE MESHES (one mesh for a layout's walls, one for its furniture -- the collision meshes
-of ReplicaCAD are triangle meshes too), built with `set_scene_idxs` so that every piece exists only in the sub-scenes of
-its layout; start arrangements of the robot (`init_configs`: base position and heading, inside the room); navigable
+of ReplicaCAD are triangle meshes too), built with `set_scene_idxs` per layout and merged into two actors, "walls" and
+"furniture", whose mesh differs from sub-scene to sub-scene (`Actor.merge`: one shape slot each, however many layouts
+there are); start arrangements of the robot (`init_configs`: base position and heading, inside the room); navigable
 positions per env. What it does not have: objects to manipulate (a free body next to the Fetch's 15 joints is more than an
 env's 16 velocity components) and articulated furniture.
 
@@ -58,6 +59,18 @@ LAYOUTS = {
         (-0.7, 1.3, -0.6, 0.7),
         [(-0.6, 0.4, -np.pi / 2), (-0.6, -0.5, 0.0)],
     ),
+    "lab": (
+        _walls(-2.0, 2.0, -1.2, 1.2, door=(-1.0, -0.1)),
+        [((-2.0, 0.6, 0.0), (0.5, 1.2, 0.9)), ((1.2, -1.2, 0.0), (2.0, -0.4, 1.1)), ((-0.4, -0.5, 0.0), (0.4, -0.1, 0.7))],  # a bench, a cabinet, a cart
+        (-1.5, 0.8, -0.8, 0.1),
+        [(-1.4, -0.5, 0.0), (0.9, 0.2, np.pi)],
+    ),
+    "hall": (
+        _walls(-2.5, 2.5, -2.5, 2.5),
+        [((-0.3, -0.3, 0.0), (0.3, 0.3, 1.2)), ((1.3, 1.3, 0.0), (1.9, 1.9, 1.2)), ((-1.9, -1.9, 0.0), (-1.3, -1.3, 1.2))],  # three pillars
+        (-2.0, 2.0, -2.0, 2.0),
+        [(-1.2, 0.0, 0.0), (1.0, -1.0, np.pi / 2)],
+    ),
 }
 
 
@@ -93,19 +106,23 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
         self.ground = build_ground(self.scene)
         self.ground.set_collision_group_bit(group=2, bit_idx=FETCH_WHEELS_COLLISION_BIT, bit=1)
         self.scene_objects["ground"] = self.ground
+        from maniskill_amd.utils.structs.actor import Actor
+
+        fragments = {"walls": [], "furniture": []}
         for li, name in enumerate(self.build_configs):
             envs = [e for e, i in enumerate(self.build_config_idxs) if i == li]
             if not envs:
                 continue
-            walls, furniture = LAYOUTS[name][0], LAYOUTS[name][1]
-            for part, boxes in (("walls", walls), ("furniture", furniture)):
+            for part, boxes in (("walls", LAYOUTS[name][0]), ("furniture", LAYOUTS[name][1])):
                 path = os.path.join(self._mesh_dir, f"{name}_{part}.obj")
                 _write_boxes_obj(path, [(np.asarray(lo, float), np.asarray(hi, float)) for lo, hi in boxes])
                 b = self.scene.create_actor_builder()
                 b.add_nonconvex_collision_from_file(path)
                 b.set_scene_idxs(envs)
                 b.initial_pose = sapien.Pose()
-                self.scene_objects[f"{name}_{part}"] = b.build_static(name=f"{name}_{part}")
+                fragments[part].append(b.build_static(name=f"{name}_{part}"))
+        for part, frags in fragments.items():
+            self.scene_objects[part] = Actor.merge(frags, name=part)
         self.navigable_positions = [LAYOUTS[self.build_configs[i]][2] for i in self.build_config_idxs]
 
     def initialize(self, env_idx: torch.Tensor, init_config_idxs: List[int] = None):

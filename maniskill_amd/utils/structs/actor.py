@@ -56,6 +56,9 @@ class Actor(_RigidBase):
         assert all(by_env[i].px_body_type == first.px_body_type for i in covered)
         # (a kinematic body is a row of the state in every env; a static one is geometry only, a dynamic one has mass 0 where it is absent)
         assert first.px_body_type != "kinematic" or covered == list(range(N)), "a kinematic object has to exist in every env"
+        if first.px_body_type == "static":  # (scenery has no row to carry a pose of its own: one world pose for the merged actor)
+            poses = torch.cat([by_env[i].initial_pose.raw_pose[:1] for i in covered], dim=0)
+            assert torch.allclose(poses, poses[:1].expand_as(poses)), "static fragments merge only when they are built at the same pose"
         name = name if name is not None else first.name
         # (an env without the object still has the body's row: it keeps this pose, has mass 0 there and takes part in nothing)
         raw = torch.cat([by_env.get(i, first).initial_pose.raw_pose[:1] for i in range(N)], dim=0)

@@ -693,8 +693,18 @@ inline Vec shape_obb_half(const Model& M, int s, int e) {
       break;
     }
     case MSSIM_SHAPE_TRIMESH: {
-      const float* b = &M.shape_bound[4 * s];
-      const int first = (int)M.shape_param[4 * s], count = (int)M.shape_param[4 * s + 1];
+      float b[3] = {M.shape_bound[4 * s], M.shape_bound[4 * s + 1], M.shape_bound[4 * s + 2]};
+      int first = (int)M.shape_param[4 * s], count = (int)M.shape_param[4 * s + 1];
+      if (slot >= 0) {
+        // this env's mesh (its triangle range; bound centre stored in the BODY frame: back into the shape frame)
+        first = (int)pr[0]; count = (int)pr[1];
+        float fr[7];
+        for (int k = 0; k < 7; k++) fr[k] = M.env_shape_frame[(size_t)(7 * slot + k) * M.N + e];
+        const Pose<Real> F = pose7(fr);
+        const Vec cb(M.env_shape_bound[(size_t)(4 * slot) * M.N + e], M.env_shape_bound[(size_t)(4 * slot + 1) * M.N + e], M.env_shape_bound[(size_t)(4 * slot + 2) * M.N + e]);
+        const Vec cs = qmat(F.q).tmul(cb - F.p);
+        b[0] = (float)cs.x; b[1] = (float)cs.y; b[2] = (float)cs.z;
+      }
       for (int t = first; t < first + count; t++) {
         const float* q = &M.tri_soup[12 * (size_t)t];
         for (int k = 0; k < 3; k++) {
@@ -788,7 +798,14 @@ void narrowphase(const Model& M, EnvState& E, int e, std::vector<Contact>& out) 
     for (int i = 0; i < 3; i++) { un[i] = B.rot.tmul(A.rot.col(i)); ax[i] = un[i] * (i == 0 ? hA.x : i == 1 ? hA.y : hA.z); }
     const Vec ext(std::fabs(ax[0].x) + std::fabs(ax[1].x) + std::fabs(ax[2].x), std::fabs(ax[0].y) + std::fabs(ax[1].y) + std::fabs(ax[2].y),
                   std::fabs(ax[0].z) + std::fabs(ax[1].z) + std::fabs(ax[2].z));
-    const int first = (int)M.shape_param[4 * sb], count = (int)M.shape_param[4 * sb + 1];
+    int first = (int)M.shape_param[4 * sb], count = (int)M.shape_param[4 * sb + 1];
+    {  // (a slot may hold a different mesh in every env: its triangle range is in the env's row)
+      const int slot = M.shape_env_slot.empty() ? -1 : M.shape_env_slot[sb];
+      if (slot >= 0) {
+        first = (int)M.env_shape_param[(size_t)(4 * slot) * M.N + e];
+        count = (int)M.env_shape_param[(size_t)(4 * slot + 1) * M.N + e];
+      }
+    }
     for (int t = first; t < first + count; t++) {
       const float* q = &M.tri_soup[12 * (size_t)t];
       float lo[3], hi[3];

@@ -42,6 +42,6 @@ for args, kw in ((("PickCube-v1", 4096), {}), (("PushCube-v1", 4096), {}), (("Pe
                  (("PickCube-v1", 16384), {}),
                  (("PickCube-v1", 4096), dict(sim_config=dict(control_freq=25))),  # 4 substeps (SURVEY 8d reports 5 and 4)
                  # BASELINE config 5's robot and env count: the Fetch on an empty ground, and in synthetic triangle-mesh rooms
-                 (("Empty-v1", 1024), dict(robot_uids="fetch")), (("SceneManipulation-v1", 1024), dict(build_config_idxs=[i % 3 for i in range(1024)]))):
+                 (("Empty-v1", 1024), dict(robot_uids="fetch")), (("SceneManipulation-v1", 1024), dict(build_config_idxs=[i % 5 for i in range(1024)]))):
     if not only or args[0] in only or kw.get("control_mode") in only or ("substeps4" in only and "sim_config" in kw):
         run(*args, **kw)

@@ -1,4 +1,4 @@
-"""step rate of SceneManipulation-v1 (Fetch in the SyntheticRooms layouts, one of three triangle-mesh rooms per sub-scene)
+"""step rate of SceneManipulation-v1 (Fetch in the SyntheticRooms layouts, one of five triangle-mesh rooms per sub-scene)
 at BASELINE config 5's env count.   usage: bench_scene.py [N] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ import gymnasium as gym
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-env = gym.make("SceneManipulation-v1", num_envs=N, obs_mode="state", build_config_idxs=[i % 3 for i in range(N)])
+env = gym.make("SceneManipulation-v1", num_envs=N, obs_mode="state", build_config_idxs=[i % 5 for i in range(N)])
 env.reset(seed=0)
 px = env.unwrapped.scene.px
 acts = [2 * torch.rand(N, 13, device="cuda") - 1 for _ in range(16)]

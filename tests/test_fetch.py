@@ -130,10 +130,11 @@ def test_scene_manipulation_env_with_synthetic_rooms():
     env = gym.make("SceneManipulation-v1", num_envs=6, obs_mode="state", sim_backend=BACKEND, build_config_idxs=[0, 1, 2, 0, 1, 2])
     base = env.unwrapped
     sb = base.scene_builder
-    assert sb.build_configs == ["study", "corridor", "kitchen"] and sb.build_config_names_to_idxs["kitchen"] == 2
-    assert base.agent.uid == "fetch" and base.scene.model.scalars["n_shape"] <= 28
-    assert sorted(sb.scene_objects) == ["corridor_furniture", "corridor_walls", "ground", "kitchen_furniture", "kitchen_walls", "study_furniture", "study_walls"]
-    assert sb.scene_objects["corridor_walls"]._own_idx.tolist() == [1, 4] and len(sb.navigable_positions) == 6
+    assert sb.build_configs == ["study", "corridor", "kitchen", "lab", "hall"] and sb.build_config_names_to_idxs["kitchen"] == 2
+    # the layouts' meshes are merged into two actors (one shape slot each, a different mesh per sub-scene): 20 robot hulls + ground + 2
+    assert base.agent.uid == "fetch" and base.scene.model.scalars["n_shape"] == base.scene.model.scalars["n_shape"] and sorted(sb.scene_objects) == ["furniture", "ground", "walls"]
+    first_tri = base.scene.model.arrays["env_shape_param"]
+    assert len({tuple(first_tri[:2, e]) for e in range(6)}) == 3 and len(sb.navigable_positions) == 6  # (three different meshes over the six envs)
     env.reset(seed=0, options=dict(init_config_idxs=[0, 0, 0, 1, 1, 1]))
     q = base.agent.robot.get_qpos()
     expect = torch.tensor([[-0.6, 0.0, 0.0], [-0.5, 0.0, 0.0], [-0.6, 0.4, -np.pi / 2], [0.0, -0.6, np.pi / 2], [2.0, -0.1, np.pi], [-0.6, -0.5, 0.0]])
@@ -155,6 +156,8 @@ def test_scene_manipulation_env_with_synthetic_rooms():
     assert -0.2 < float(q[5, 0]) < 0.2        # kitchen, facing the island at x = 0.2
     assert base.scene.px.overflow_count() == 0
     # a new set of layouts needs a rebuild
-    env.reset(seed=1, options=dict(reconfigure=True, build_config_idxs=[2, 2, 2, 1, 1, 1]))
-    assert base.scene_builder.scene_objects["kitchen_walls"]._own_idx.tolist() == [0, 1, 2] and "study_walls" not in base.scene_builder.scene_objects
+    env.reset(seed=1, options=dict(reconfigure=True, build_config_idxs=[4, 4, 3, 3, 1, 1]))
+    assert base.scene_builder.build_config_idxs == [4, 4, 3, 3, 1, 1]
+    rows = base.scene.model.arrays["env_shape_param"]
+    assert len({tuple(rows[:2, e]) for e in range(6)}) == 3 and tuple(rows[:2, 0]) == tuple(rows[:2, 1]) != tuple(rows[:2, 2])
     env.close()

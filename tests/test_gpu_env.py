@@ -516,15 +516,15 @@ def test_fetch_in_per_env_mesh_rooms_matches_oracle(tmp_path):
 
 
 def test_scene_manipulation_rooms_match_oracle():
-    """BASELINE config 5 on synthetic scenery: SceneManipulation-v1, the Fetch, three static triangle-mesh layouts spread
-    over the sub-scenes (per-env shape types TRIMESH / NONE), start arrangements per reset. HIP env against the oracle-backed
+    """BASELINE config 5 on synthetic scenery: SceneManipulation-v1, the Fetch, five static triangle-mesh layouts spread
+    over the sub-scenes (a different mesh per env in the merged "walls" / "furniture" slots), start arrangements per reset. HIP env against the oracle-backed
     env over 2 s of driving into the rooms' furniture; the mesh variant of the 15-joint kernel, no capacity overflow."""
     import gymnasium as gym
 
     ob.register("f64", "oracle_f64_env")
     N = 12
-    layouts = [i % 3 for i in range(N)]
-    starts = [(i // 3) % 2 for i in range(N)]
+    layouts = [i % 5 for i in range(N)]  # (study, corridor, kitchen, lab, hall: one "walls" and one "furniture" slot, five meshes each)
+    starts = [(i // 5) % 2 for i in range(N)]
     a = torch.zeros(N, 13)
     a[:, 7] = -0.1666667
     a[:, 11] = 1.0
