@@ -796,6 +796,43 @@ def test_triangle_mesh_next_to_the_panda_matches_oracle():
     assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
 
 
+def test_a_different_triangle_mesh_per_env_in_one_slot_matches_oracle():
+    """one static "terrain" slot whose mesh differs from env to env (include/mssim.h env_shape_param: the env's triangle
+    range and BVH root) -- a flat grid, the same grid 3 cm higher, a 10-degree slope, nothing at all (the cube falls to the
+    ground plane below): the kernel stays with the oracle, every cube ends where its own env's terrain puts it"""
+    from maniskill_amd.model import geom
+    from maniskill_amd.model.compile import ActorRecord, ShapeRecord
+    from tests.test_oracle_contacts import _grid_mesh
+
+    Vf, Ff = _grid_mesh(n=6, size=0.6)
+    Vh = Vf + np.array([0.0, 0.0, 0.03])
+    Vs, Fs = _grid_mesh(n=6, size=0.6, tilt_deg=10.0)
+    flat = ShapeRecord("trimesh", geom.pose(), vertices=Vf, triangles=Ff)
+    high = ShapeRecord("trimesh", geom.pose(), vertices=Vh, triangles=Ff)
+    slope = ShapeRecord("trimesh", geom.pose(), vertices=Vs, triangles=Fs)
+    per_env = [[flat], [high], [slope], [], [flat], [slope]]
+    N = len(per_env)
+    b = SceneModelBuilder()
+    b.add_actor(ground_record(altitude=-0.2))
+    b.add_actor(ActorRecord("terrain", "static", [flat], initial_pose=geom.pose(), env_shapes=per_env))
+    b.add_actor(cube_record(p=(0.0, 0.0, 0.08)))
+    model = b.compile(num_envs=N, sleep_threshold=0.0)
+    assert model.scalars["n_shape"] == 3  # ground, ONE terrain slot, cube
+    gpu, cpu = make_pair(model, N)
+    row = model.row_of("cube")
+    for px in (gpu, cpu):
+        px.step(60)
+    a, c = get_state(gpu, model, N), get_state(cpu, model, N)
+    za, zc = a["rb"][row, :, 2], c["rb"][row, :, 2]
+    assert torch.allclose(a["rb"][row, :, :3], c["rb"][row, :, :3], atol=2e-3), (a["rb"][row, :, :3] - c["rb"][row, :, :3]).abs().max(dim=1).values
+    for z in (za, zc):
+        assert abs(float(z[0]) - 0.02) < 1e-3 and abs(float(z[4]) - 0.02) < 1e-3      # flat grid
+        assert abs(float(z[1]) - 0.05) < 1e-3                                        # the grid 3 cm higher
+        assert abs(float(z[3]) + 0.18) < 1e-3                                        # no terrain: on the ground plane at -0.2
+        assert float(z[2]) < 0.06 and float(z[2]) > -0.15 and float(z[5]) < 0.06     # on the slope (tan 10 deg < mu: it stays near where it landed)
+    assert gpu.overflow_count() == 0 and cpu.overflow_count() == 0
+
+
 def test_kinematic_triangle_mesh_that_moves_matches_oracle():
     """a triangle mesh on a KINEMATIC body (include/mssim.h: fixed or kinematic bodies carry meshes): a tray that is moved
     up 2 mm per control step (and sideways in every other env) carries a cube up; kernel and oracle agree"""
