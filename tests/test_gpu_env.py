@@ -549,3 +549,28 @@ def test_scene_manipulation_rooms_match_oracle():
     # the bases moved, and not all the same way
     moved = torch.linalg.norm(out[1][-1][:, :2] - out[1][0][:, :2], dim=1)
     assert torch.all(moved > 0.2) and float(moved.std()) > 0.05, moved
+
+
+def test_thousand_heterogeneous_sub_scenes_step_like_the_oracle():
+    """BASELINE config 5's env count: 1024 sub-scenes of SceneManipulation-v1 (the Fetch; five room layouts, a different
+    triangle mesh per env in the walls / furniture slots; two start arrangements), two control steps of random actions on
+    the HIP back end and on the oracle: joint state equal to 1e-4, no capacity overflow"""
+    import gymnasium as gym
+
+    ob.register("f32", "oracle_f32_env")
+    N = 1024
+    layouts = [i % 5 for i in range(N)]
+    starts = [(i // 5) % 2 for i in range(N)]
+    g = torch.Generator().manual_seed(7)
+    acts = [2 * torch.rand(N, 13, generator=g) - 1 for _ in range(2)]
+    out = []
+    for backend in ("oracle_f32_env", BACKEND):
+        env = gym.make("SceneManipulation-v1", num_envs=N, obs_mode="state", sim_backend=backend, build_config_idxs=layouts)
+        env.reset(seed=0, options=dict(init_config_idxs=starts))
+        for a in acts:
+            obs, *_ = env.step(a.to(env.unwrapped.device))
+        assert env.unwrapped.scene.px.overflow_count() == 0
+        out.append(obs.cpu().clone())
+        env.close()
+    err = (out[0] - out[1]).abs()
+    assert float(err[:, :15].max()) < 1e-4 and float(err[:, 15:].max()) < 1e-2, (float(err[:, :15].max()), float(err[:, 15:].max()))
