@@ -773,6 +773,7 @@ struct mssim_sim {
   float* d_drive = nullptr;
   bool panda = false;
   bool has_tri = false;  // the model has triangle-mesh shapes: control steps run the kernel variant with the mesh stage
+  int rows_per_env = 1;  // 16-lane rows an env takes in the control-step kernel (its template parameter NR): 2 when the model has more than 16 velocity components
   bool dirty = true;
   int n_cu = 256;  // compute units of the device
   unsigned deferred_fetch = 0u;  // mssim_defer_fetch: copy-out owed to the next call on the handle
@@ -847,11 +848,12 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   if (!d || !out || num_envs <= 0) { g_create_error = "bad arguments"; return 1; }
   if (d->abi_version != MSSIM_ABI_VERSION) { g_create_error = "ABI version mismatch"; return 2; }
   if (d->n_dof > MSSIM_MAX_DOF || d->n_free > MSSIM_MAX_FREE) { g_create_error = "model exceeds MSSIM_MAX_DOF / MSSIM_MAX_FREE"; return 3; }
-  // the control-step kernel keeps an env on 16 lanes (one velocity component each) and its scene in fixed LDS tables
-  if (d->n_dof + 6 * d->n_free > S16_LANES || d->n_free > S16_MAX_FREE || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE || d->n_pair > 56 * 16) {
+  // the control-step kernel keeps an env on one or two 16-lane rows (one velocity component per lane: the joints in row 0, the free
+  // bodies behind them or, when that is more than 16 components, in a row of their own) and its scene in fixed LDS tables
+  if (d->n_dof > S16_LANES || d->n_free > S16_MAX_FREE || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE || d->n_pair > 56 * 16) {
     char msg[256];
-    snprintf(msg, sizeof msg, "model exceeds the control-step kernel's tables: %d velocity components (max %d), %d free bodies (max %d), %d kinematic bodies (max %d), "
-             "%d shapes (max %d), %d candidate pairs (max %d)", d->n_dof + 6 * d->n_free, S16_LANES, d->n_free, S16_MAX_FREE, d->n_kin, S16_MAX_KIN, d->n_shape, S16_MAX_SHAPE, d->n_pair, 56 * 16);
+    snprintf(msg, sizeof msg, "model exceeds the control-step kernel's tables: %d joints (max %d), %d free bodies (max %d), %d kinematic bodies (max %d), "
+             "%d shapes (max %d), %d candidate pairs (max %d)", d->n_dof, S16_LANES, d->n_free, S16_MAX_FREE, d->n_kin, S16_MAX_KIN, d->n_shape, S16_MAX_SHAPE, d->n_pair, 56 * 16);
     g_create_error = msg;
     return 9;
   }
@@ -870,6 +872,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   mssim_sim* S = new mssim_sim();
   S->device = device;
   S->N = num_envs;
+  S->rows_per_env = d->n_dof + 6 * d->n_free > S16_LANES ? 2 : 1;
   hipError_t e0 = hipSetDevice(device);
   if (e0 != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e0); delete S; return 6; }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) S->n_cu = ncu; }
@@ -1112,7 +1115,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin) AL(free_wake, d->n_free)
   AL(bodypose, 7 * n) AL(bodyvel, 6 * n) AL(bodyaux, 6 * n)
   AL(pair_cnt, d->n_pair) AL(pair_imp, 3 * d->n_pair)
-  if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN, &D.rows))) { mssim_destroy(S); return rc; }
+  if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN_(S->rows_per_env), &D.rows))) { mssim_destroy(S); return rc; }
   AL(overflow, 1)
   AL(hit_list, 1 + MAXC)
   AL(pcm_tick, 1)
@@ -1256,7 +1259,20 @@ extern "C++" {
 template <int TASK>
 static void launch_control_step(mssim_handle h, const DevState& S, int n_substeps, hipStream_t st) {
   prof_mark(h, 0, st);
-  const dim3 grid = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), block(64 * S16_WAVES);
+  const dim3 block(64 * S16_WAVES);
+  if (h->rows_per_env == 2) {  // more than 16 velocity components: two 16-lane rows per env, 8 envs per block
+    const dim3 grid2 = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK / 2);
+    if (h->has_tri) {
+      if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, 0, true, 2>), grid2, block, 0, st, h->M, S, n_substeps);
+      else if (h->M.n_dof == 15) hipLaunchKernelGGL((k_solve16<15, 0, true, 2>), grid2, block, 0, st, h->M, S, n_substeps);
+      else hipLaunchKernelGGL((k_solve16<0, 0, true, 2>), grid2, block, 0, st, h->M, S, n_substeps);
+    } else if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, 0, false, 2>), grid2, block, 0, st, h->M, S, n_substeps);
+    else if (h->M.n_dof == 15) hipLaunchKernelGGL((k_solve16<15, 0, false, 2>), grid2, block, 0, st, h->M, S, n_substeps);
+    else hipLaunchKernelGGL((k_solve16<0, 0, false, 2>), grid2, block, 0, st, h->M, S, n_substeps);
+    prof_mark(h, 0, st);
+    return;
+  }
+  const dim3 grid = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK);
   if (h->has_tri) {  // models with triangle meshes: the variant that carries the mesh stage (never with a task tail)
     if (h->M.n_dof == 9) hipLaunchKernelGGL((k_solve16<9, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
     else if (h->M.n_dof == 15) hipLaunchKernelGGL((k_solve16<15, 0, true>), grid, block, 0, st, h->M, S, n_substeps);
@@ -1421,7 +1437,7 @@ static int finger_pair_list(mssim_handle h, int obj_row, int f1_row, int f2_row)
 extern "C++" {
 template <int TASK>
 static bool control_step_with_task(mssim_handle h, DevState& S, hipStream_t st) {
-  if (!(h->deferred_action && h->deferred_fetch && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0) || h->has_tri) return false;
+  if (!(h->deferred_action && h->deferred_fetch && h->M.n_dof == 9 && h->deferred_nsub > 0 && st == h->deferred_stream && h->ee.link < 0) || h->has_tri || h->rows_per_env != 1) return false;
   // The tail runs at the kernel's one wave per SIMD: worth it while all blocks are resident at once (4 per CU) and
   // the launch is latency-bound anyway; with more blocks the separate, fully occupied copy-out + epilogue launch
   // is cheaper than a tail per block.

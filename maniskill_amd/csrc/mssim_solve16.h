@@ -1,25 +1,30 @@
-// mssim_solve16.h -- the cooperative step kernel: 16 lanes per env, 4 envs per wave.
+// mssim_solve16.h -- the control-step kernel: an env on one or two 16-lane DPP rows, a whole control step per launch.
 //
 // Why: with one env per lane N = 4096 envs are 64 wavefronts on a chip with 1024 SIMDs and the
 // kernel is instruction-issue bound at one wave per SIMD. Here every env is
-// spread over a 16-lane DPP row: lane c owns velocity component c (joint c, or one linear /
-// angular component of a free body), so N = 4096 is 1024 waves and the long serial chains become
+// spread over 16-lane DPP rows: a lane owns one velocity component (a joint, or one linear / angular
+// component of a free body), so N = 4096 is 1024 waves and the long serial chains become
 //   * tree recursions  -> sums over ancestor / descendant bit sets of per-body quantities staged
 //                         in LDS; FK by pointer jumping,
 //   * dense 9x9 algebra-> Gauss-Jordan with one matrix row per lane, pivot row broadcast via LDS,
-//   * Gauss-Seidel row -> one multiply, a 4-step DPP row-rotate all-reduce, a clamp, one FMA.
+//   * Gauss-Seidel row -> one multiply, a DPP row-rotate all-reduce, a clamp, one FMA.
 //
-// k_solve16<true>  (FUSED): one launch runs a whole control step. The wave keeps its 4 envs' state in
-//   registers / LDS across the substeps and does the narrowphase itself between them (per-env
-//   world shape table in LDS, 16 pairs per env culled per round, surviving pairs spread over all
-//   64 lanes for the manifold computation, contact records in LDS). State crosses HBM once per
-//   control step; there is no global contact buffer.
-// k_solve16<false> (split): one substep; contacts come from k_narrow through the global pair
-//   buffers (kept as the A/B reference of the fused path and for per-substep stepping).
+// k_solve16<NDOF, TASK, TRI, NR>: one launch runs a whole control step. A wave keeps its envs' state in registers /
+//   LDS across the substeps and does the narrowphase itself between them (per-env world shape table in LDS, 16 pairs
+//   per env culled per round, generic-convex / box-box / mesh-triangle pairs of the whole block taken round-robin by
+//   its sixteen 16-lane groups, persistent manifolds, contact patches, contact records in LDS). State crosses HBM once
+//   per control step; there is no global contact buffer. Optional head: the action map (mssim_step_action); optional
+//   tail (TASK > 0): copy-out + a task's evaluate / obs / reward.
+//   NR = 16-lane rows per env. NR = 1: 4 envs per wave, the articulation's joints and up to two free bodies share the
+//   row (n_dof + 6 n_free <= 16: the Panda with one object, the Fetch alone). NR = 2: 2 envs per wave; row 0 holds
+//   the articulation (<= 16 joints) and does the env's own narrowphase bookkeeping, row 1 holds two free bodies (6
+//   lanes each). A^-1 is block diagonal over (articulation | free body | free body), so W = A^-1 J^T never crosses a
+//   row; only the J.v reductions of the solver and the Delassus terms of the row build add one cross-row step
+//   (v_permlane16_swap). The shared narrowphase stages see sixteen groups per block either way.
 //
-// Same math and the same row order as k_solve / the oracle (limits, then contacts in pair order,
-// normal + 2 friction rows each), so the parity tests cover both unchanged.
-// Requires n_dof + 6 * n_free <= 16 (and n_free <= 2, n_kin <= 6, n_shape <= 32 for FUSED).
+// Same math and the same row order as the oracle (contacts patch by patch in pair order, normal + 2 friction rows
+// each, then the joint limits), so the parity tests cover every variant unchanged.
+// Requires n_dof <= 16, n_free <= 2, n_kin <= 6, n_shape <= 28 (mssim_create picks NR and says what a model exceeds).
 #pragma once
 
 #define S16_LANES 16
@@ -62,13 +67,21 @@
 #define S16_CS (S16_U + 256)   // [MAXC][16] block scalars of every contact: 1/d0 bias+ bias- mu | 1/d1 k10 1/d2 k20 | k21 lam0 lam1 lam2 | pair
 #define S16_REGC 12            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
 #define S16_LDSC 7             // next contacts: J | W rows in LDS; the rest stream from the per-env global scratch
-#define S16_JWLEN 96           // 3 x (J[16] W[16]) of one contact
-#define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][96]
-#define S16_REC (S16_JW + S16_JWLEN * S16_LDSC)         // contact records [MAXC][10]
-#define S16_REC_LEN 10         // n(3) x(3) sep pair lane-masks(A | B << 16) mu
-#define S16_ENV_FLOATS (S16_REC + S16_REC_LEN * MAXC)   // 2448 floats = 9792 B per env (== 16 mod 32 banks)
-#define S16_ROWLEN 32
+// (sizes that depend on NR, the number of 16-lane rows per env: `_(nr)` forms for the host; inside the kernel the plain
+// names read its template parameter NR)
+#define S16_JWLEN_(nr) (96 * (nr))  // 3 x (J[16 nr] W[16 nr]) of one contact
+#define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][S16_JWLEN]
+#define S16_REC_(nr) (S16_JW + S16_JWLEN_(nr) * S16_LDSC)  // contact records [MAXC][S16_REC_LEN]
+#define S16_REC_LEN_(nr) ((nr) > 1 ? 12 : 10)  // n(3) x(3) sep pair lane-masks of row 0 (A | B << 16) mu [lane-masks of row 1, -]
+// per env: NR = 1: 2552 floats (== 24 mod 32 banks); NR = 2: 3344 floats (== 16 mod 32: the wave's two envs on different banks)
+#define S16_ENV_FLOATS_(nr) (S16_REC_(nr) + S16_REC_LEN_(nr) * MAXC + ((nr) > 1 ? 16 : 0))
+#define S16_ROWLEN_(nr) (32 * (nr))
 #define S16_ROWS_GLB (3 * (MAXC - S16_REGC - S16_LDSC))  // global scratch rows per env (x S16_ROWLEN floats)
+#define S16_JWLEN S16_JWLEN_(NR)
+#define S16_REC S16_REC_(NR)
+#define S16_REC_LEN S16_REC_LEN_(NR)
+#define S16_ENV_FLOATS S16_ENV_FLOATS_(NR)
+#define S16_ROWLEN S16_ROWLEN_(NR)
 // narrowphase scratch, overlays the union below the contact records
 #define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 torsional-radius
 #define S16_NP_SHP (S16_U)        // [28][20] world shape table
@@ -92,7 +105,7 @@
 #define S16_MAX_BBC 16            // box-box pairs per wave up to which they are worked on by 16-lane groups
 #define S16_MAX_MPR 64            // (= every hit: an arm folded onto itself and jammed into the table has 20+ hull pairs in range)
 static_assert(S16_NP_BOUT + 20 <= S16_NP_SCR + 896, "narrowphase staging exceeds the scratch area");
-static_assert(S16_NP_SLOT + 16 <= S16_REC, "narrowphase lists run into the contact records");
+static_assert(S16_NP_SLOT + 16 <= S16_REC_(1), "narrowphase lists run into the contact records");
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
 static_assert(MSSIM_MAX_TRI_TASKS + MSSIM_MAX_TRI_HITS <= S16_NP_KEY - S16_NP_BSCR, "triangle task list + candidates exceed the scratch they borrow (BSCR + KEEP)");
 
@@ -196,6 +209,24 @@ MS_DEV void gsum16x3(float& a, float& b, float& c) {
       "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n"
       "s_nop 1\n"
       : "+v"(a), "+v"(b), "+v"(c));
+}
+// NR rows per env: the sums over an env's lanes. One more step after the row all-reduce: v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, so with both operands = x the two results are (row 0's
+// value in rows 0 and 1 | row 2's in rows 2 and 3) and (row 1's | row 3's): their sum is the total of each row pair.
+template <int NR>
+MS_DEV float xrow_sum(float x) {
+  if constexpr (NR == 1) {
+    return x;
+  } else {
+    static_assert(NR == 2, "rows per env");
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
+template <int NR>
+MS_DEV void gsumx3(float& a, float& b, float& c) {
+  gsum16x3(a, b, c);
+  if constexpr (NR > 1) { a = xrow_sum<NR>(a); b = xrow_sum<NR>(b); c = xrow_sum<NR>(c); }
 }
 // W = A^-1 row (pre-rotated, see the row build) * J of the lane a row rotation by k reads from, for the
 // three rows of a contact at once: one v_fmac_f32 with a DPP operand per term, no LDS round trip.
@@ -392,9 +423,15 @@ MS_DEV int pose_slot(int kind, int index) {
 }
 // lanes (velocity components) that move with the body in pose-table slot `sl`: the dofs on the path
 // to a link, the 6 components of a free body, nothing for fixed / kinematic bodies
-MS_DEV unsigned slot_lane_mask(const float* L, int sl, int n) {
-  if (sl >= S16_PT_LINK && sl < S16_PT_FREE) return reinterpret_cast<const unsigned*>(L)[S16_ANC + sl - S16_PT_LINK];
-  if (sl >= S16_PT_FREE && sl < S16_PT_KIN) return 0x3Fu << (n + 6 * (sl - S16_PT_FREE));
+// (`row`: which 16-lane row of the env the mask is for. NR = 1: joints, then the free bodies, all in row 0; NR = 2: the joints
+// in row 0, the free bodies from lane 0 of row 1)
+template <int NR>
+MS_DEV unsigned slot_lane_mask(const float* L, int sl, int n, int row) {
+  if (sl >= S16_PT_LINK && sl < S16_PT_FREE) return row == 0 ? reinterpret_cast<const unsigned*>(L)[S16_ANC + sl - S16_PT_LINK] : 0u;
+  if (sl >= S16_PT_FREE && sl < S16_PT_KIN) {
+    if constexpr (NR == 1) return 0x3Fu << (n + 6 * (sl - S16_PT_FREE));
+    else return row == 1 ? 0x3Fu << (6 * (sl - S16_PT_FREE)) : 0u;
+  }
   return 0u;
 }
 // separating-axis test of two oriented boxes (rotations RA / RB, half extents ha / hb, d = centre B -
@@ -495,36 +532,57 @@ struct SupCoop16 {
 // (action map, substeps, copy-out, epilogue) is one launch.
 // TRI: the model has triangle-mesh shapes (MSSIM_SHAPE_TRIMESH): the narrowphase carries the mesh stage (BVH traversal, one
 // multi-point manifold per triangle in range); instantiated without a task tail only.
-template <int NDOF = 0, int TASK = 0, bool TRI = false>
+template <int NDOF = 0, int TASK = 0, bool TRI = false, int NR = 1>
 __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState S, int n_sub) {
   constexpr bool FUSED = true;  // (the per-substep variant fed by a separate narrowphase kernel is gone)
-  __shared__ __attribute__((aligned(16))) float sm[S16_WAVES * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS];
-  __shared__ int blk_nml[S16_WAVES * S16_ENVS_PER_BLOCK];  // generic-convex pairs of every env of the block (stage B task list)
-  __shared__ int blk_nbl[S16_WAVES * S16_ENVS_PER_BLOCK];  // its box-box pairs that go to 16-lane groups (stage C task list)
-  __shared__ int blk_ntl[S16_WAVES * S16_ENVS_PER_BLOCK];  // its mesh-triangle tasks (stage T task list; TRI variants only)
+  static_assert(NR == 1 || (NR == 2 && TASK == 0), "rows per env: 1 or 2; the task tails are compiled for one row only");
+  constexpr int EPW = 4 / NR;                 // envs per wave
+  constexpr int BLK_ENVS = S16_WAVES * EPW;   // envs per block
+  constexpr int BLK_GRPS = S16_WAVES * 4;     // 16-lane groups per block: who takes the tasks of the shared narrowphase stages
+  constexpr int GW = 16 * NR;                 // lanes per env
+  __shared__ __attribute__((aligned(16))) float sm[BLK_ENVS * S16_ENV_FLOATS];
+  __shared__ int blk_nml[BLK_ENVS];  // generic-convex pairs of every env of the block (stage B task list)
+  __shared__ int blk_nbl[BLK_ENVS];  // its box-box pairs that go to 16-lane groups (stage C task list)
+  __shared__ int blk_ntl[BLK_ENVS];  // its mesh-triangle tasks (stage T task list; TRI variants only)
   const int N = S.N;
-  constexpr int BLK_ENVS = S16_WAVES * S16_ENVS_PER_BLOCK;
   const int wv = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
-  const int g = lane64 >> 4, c = threadIdx.x & 15;  // group within the wave, lane within the group
-  const int gb = wv * S16_ENVS_PER_BLOCK + g;       // group (= env slot) within the block
+  const int g = lane64 >> 4, c = threadIdx.x & 15;  // 16-lane group within the wave (ballot slices), lane within the group
+  const int r = NR > 1 ? (g & (NR - 1)) : 0;        // row of this lane within its env
+  const int ew = g / NR;                            // env within the wave
+  const bool lead = r == 0;                         // row 0: the articulation's lanes; does the env's own narrowphase bookkeeping
+  const int cl = 16 * r + c;                        // lane within the env
+  const int gb = wv * EPW + ew;                     // env slot within the block
+  const int grp = wv * 4 + g;                       // group within the block
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   if (chunk * BLK_ENVS >= N) return;  // grid padding
   const int e_raw = chunk * BLK_ENVS + gb;
   const bool live = e_raw < N;
   const int e = live ? e_raw : N - 1;  // dead groups shadow the last env and never store
   float* L = sm + gb * S16_ENV_FLOATS;
-  float* const smw = sm + wv * S16_ENVS_PER_BLOCK * S16_ENV_FLOATS;  // the envs of this wave
+  float* const smw = sm + wv * EPW * S16_ENV_FLOATS;  // the envs of this wave
   const int n = NDOF > 0 ? NDOF : M.n_dof, nf = M.n_free;
   const float dt = M.dt;
   const float inv_dt = rcp_f(dt);
   const f3 g3 = f3{M.gx, M.gy, M.gz};
-  const bool art = c < n;
-  // lane role among the free-body components
-  const int fc = c - n;
+  const bool art = lead && c < n;
+  // lane role among the free-body components (NR = 1: behind the joints in the same row; NR = 2: row 1 from lane 0)
+  const int fc = NR == 1 ? c - n : (r == 1 ? c : -1);
   const bool freel = fc >= 0 && fc < 6 * nf;
   const int fb_id = freel ? fc / 6 : 0;
   const int fk = freel ? fc % 6 : 0;  // 0..2 linear xyz, 3..5 angular xyz
-  const int fbase = n + 6 * fb_id;
+  const int fcol0 = NR == 1 ? n : 0;  // this row's first free-body column
+  const int fbase = fcol0 + 6 * fb_id;
+  const bool frow = NR == 1 || r == 1;  // the row that holds the free bodies' lanes
+  // ballot over the lanes of this env / broadcast from its lane `j` (j < 16: a lane of row 0)
+  auto benv = [&](bool v) __attribute__((always_inline)) -> unsigned {
+    if constexpr (NR == 1) return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu;
+    else return (unsigned)(__ballot(v) >> (32 * ew));
+  };
+  auto env_bci = [&](int x, int j) __attribute__((always_inline)) -> int {
+    if constexpr (NR == 1) return __shfl(x, j, 16);
+    else return __shfl(x, j, 32);
+  };
+  (void)cl; (void)grp; (void)benv; (void)env_bci; (void)frow;
 
   PH_INIT
   // ---------------------------------------------------------------- carried state (loaded once)
@@ -599,7 +657,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     }
   }
   // pose table: root, links, free bodies, kinematic bodies
-  {
+  if (lead) {
     reinterpret_cast<unsigned*>(L)[S16_ANC + c] = (art ? M.dof_anc[c] : 0u) | self_c;
     if (c == 0) lds_pose_store(L + S16_PT, root0);
     if (art) lds_pose_store(L + S16_BP + 7 * c, pose_soa(S.bodypose, 7 * c, N, e));
@@ -639,7 +697,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int s = c + 16 * k;
           shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
           shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shTr[k] = 0.f; shBc[k] = f3{0, 0, 0}; shH[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
-          if (s < M.n_shape) {
+          if (lead && s < M.n_shape) {
             float r[24];  // the shape's 96-byte constant record
             const float4* rp = reinterpret_cast<const float4*>(M.shape_pack + 24 * s);
 #pragma unroll
@@ -680,7 +738,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       }
       // the pair table (sa | sb << 8 per pair) is staged in this env's clip-scratch area for the cull
       // rounds (the area is only needed again by the box-box manifolds afterwards)
-      {
+      if (lead) {
         int* const lp = reinterpret_cast<int*>(L + S16_NP_SCR);
         for (int p = c; p < M.n_pair; p += 16) lp[p] = M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8);
       }
@@ -688,7 +746,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const int s = c + 16 * k;
-        if (s < M.n_shape) {
+        if (lead && s < M.n_shape) {
           pose_t P = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
           if (shSlot[k] >= 0) P = lds_pose(L + S16_PT + 7 * shSlot[k]);
           const pose_t W = pmul(P, shF[k]);
@@ -747,7 +805,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll 1
       for (int base = 0; base < M.n_pair; base += 16) {
         const int p = base + c;
-        cull_round(p, p < M.n_pair ? reinterpret_cast<const int*>(L + S16_NP_SCR)[p] : -1);
+        cull_round(p, (lead && p < M.n_pair) ? reinterpret_cast<const int*>(L + S16_NP_SCR)[p] : -1);  // (the lanes of an env's other rows idle through its own bookkeeping)
       }
       // stage 2, on the survivors only (usually one or two rounds): 15-axis separating-axis test of the two
       // shapes' oriented boxes, contact offset added to the radii. It discards the pairs whose bounding
@@ -830,23 +888,23 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         nml = nml < S16_MAX_MPR ? nml : S16_MAX_MPR;
       }
       // wave totals: all hits, MPR tasks, box-box tasks
-      int cum[S16_ENVS_PER_BLOCK + 1], mcum[S16_ENVS_PER_BLOCK + 1], bcum[S16_ENVS_PER_BLOCK + 1];
+      int cum[EPW + 1], mcum[EPW + 1], bcum[EPW + 1];
       cum[0] = mcum[0] = bcum[0] = 0;
 #pragma unroll
-      for (int j = 0; j < S16_ENVS_PER_BLOCK; j++) {
-        cum[j + 1] = cum[j] + __shfl(nh, 16 * j);
-        mcum[j + 1] = mcum[j] + __shfl(nml, 16 * j);
-        bcum[j + 1] = bcum[j] + __shfl(nbl, 16 * j);
+      for (int j = 0; j < EPW; j++) {
+        cum[j + 1] = cum[j] + __shfl(nh, GW * j);
+        mcum[j + 1] = mcum[j] + __shfl(nml, GW * j);
+        bcum[j + 1] = bcum[j] + __shfl(nbl, GW * j);
       }
-      const int T = cum[S16_ENVS_PER_BLOCK], TM = mcum[S16_ENVS_PER_BLOCK], TB = bcum[S16_ENVS_PER_BLOCK];
+      const int T = cum[EPW], TM = mcum[EPW], TB = bcum[EPW];
       // Box-box pairs: with few of them in the wave (the usual case: cube on table, peg on table) one lane per pair
       // leaves the wave almost empty for ~3400 instructions, so the 4 groups take them round-robin, 16 lanes per
       // pair (stage C). Many of them (fingers on the table: 8 per env): one lane per pair (stage A), whose clip
       // scratch is this area -- only possible while all tasks of the wave fit one round.
-      const bool bb_lane = TB > S16_MAX_BBC && T <= 64;  // wave-uniform
+      const bool bb_lane = NR == 1 && TB > S16_MAX_BBC && T <= 64;  // wave-uniform (the clip scratch holds one column per lane of a 16-lane env)
       bool pool_over = false;
       WSYNC();
-      PH_ADD(14, (TM + S16_ENVS_PER_BLOCK - 1) / S16_ENVS_PER_BLOCK);
+      PH_ADD(14, (TM + EPW - 1) / EPW);
       (void)mcum;
       PH_ADD(26, T);
       // a manifold goes to the staging tables of its env: normal, size, `cnt` points from the pool
@@ -862,7 +920,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         const bool has = t < T;
         int ge = 0;
 #pragma unroll
-        for (int j = 1; j < S16_ENVS_PER_BLOCK; j++) ge += (has && t >= cum[j]) ? 1 : 0;
+        for (int j = 1; j < EPW; j++) ge += (has && t >= cum[j]) ? 1 : 0;
         const int idx = has ? t - cum[ge] : 0;
         float* Lg = smw + ge * S16_ENV_FLOATS;
         manifold_t m;
@@ -884,7 +942,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         }
         WSYNC();  // the clip scratch is dead: the staging tables take its place
         if (t0 == 0) {
-          if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
+          if (c == 0 && lead) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
           WSYNC();
         }
         if (mine && m.count > 0) {
@@ -901,9 +959,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         }
       }
       if (T == 0) {  // (wave-uniform) no round ran: the pool counter is still to be cleared
-        if (c == 0) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
+        if (c == 0 && lead) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
       }
-      if (c == 0) { blk_nml[gb] = nml; blk_nbl[gb] = bb_lane ? 0 : nbl; }
+      if (c == 0 && lead) { blk_nml[gb] = nml; blk_nbl[gb] = bb_lane ? 0 : nbl; }
       BSYNC();  // every wave is done with its clip scratch: stage B may write manifolds into any env's staging tables
       PH(13);
       // ---- stage B: generic convex pairs through the persistent manifold cache (include/mssim.h MSSIM_PCM_*).
@@ -954,9 +1012,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       int TMb = 0;
 #pragma unroll
       for (int j = 0; j < BLK_ENVS; j++) TMb += blk_nml[j];
-      for (int t0 = 0; t0 < TMb; t0 += BLK_ENVS) {
-        const bool has = t0 + gb < TMb;
-        const int t = has ? t0 + gb : t0;  // (idle groups shadow the round's first pair: valid shapes, no output)
+      for (int t0 = 0; t0 < TMb; t0 += BLK_GRPS) {
+        const bool has = t0 + grp < TMb;
+        const int t = has ? t0 + grp : t0;  // (idle groups shadow the round's first pair: valid shapes, no output)
         int ge = 0, k = t;
 #pragma unroll
         for (int j = 0; j < BLK_ENVS - 1; j++) {
@@ -1366,14 +1424,14 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         if (tri_over && live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_TRI);
         // T1: the triangle tasks of all the block's envs form one list that its 16 groups take round-robin, like the
         // generic-convex pairs of stage B (an env with the whole arm on a mesh has 40-56 of them, its neighbours none)
-        if (c == 0) blk_ntl[gb] = ntask;
+        if (c == 0 && lead) blk_ntl[gb] = ntask;
         BSYNC();  // every env's task list is complete
         int TT = 0;
 #pragma unroll
         for (int j = 0; j < BLK_ENVS; j++) TT += blk_ntl[j];
-        for (int t0 = 0; t0 < TT; t0 += BLK_ENVS) {
-          const bool has = t0 + gb < TT;
-          const int t = has ? t0 + gb : t0;
+        for (int t0 = 0; t0 < TT; t0 += BLK_GRPS) {
+          const bool has = t0 + grp < TT;
+          const int t = has ? t0 + grp : t0;
           int ge = 0, kt = t;
 #pragma unroll
           for (int j = 0; j < BLK_ENVS - 1; j++) {
@@ -1628,7 +1686,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         int TBb = 0;
 #pragma unroll
         for (int j = 0; j < BLK_ENVS; j++) TBb += blk_nbl[j];
-        for (int t = gb; t < TBb; t += BLK_ENVS) {
+        for (int t = grp; t < TBb; t += BLK_GRPS) {
           int ge = 0, k = t;
 #pragma unroll
           for (int j = 0; j < BLK_ENVS - 1; j++) {
@@ -1642,8 +1700,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
           const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
-          float* out = L + S16_NP_BOUT;
-          collide_box_box_coop(A, B, M.contact_offset, L + S16_NP_BSCR, out, c, g);
+          // (scratch of this GROUP: the env's other row borrows the body-pair keys' words, idle until the patch pass)
+          float* out = lead ? L + S16_NP_BOUT : L + S16_NP_KEY + 24;
+          collide_box_box_coop(A, B, M.contact_offset, lead ? L + S16_NP_BSCR : L + S16_NP_KEY, out, c, g);
           const int cnt = __float_as_int(out[0]);  // (one wave: the LDS writes of the group's lanes are complete)
           if (cnt > 0) {
             int off = 0;
@@ -1705,6 +1764,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             if (bb >= 0 && disturber(s1a)) dist |= 1u << bb;
           }
           dist |= __shfl_xor(dist, 8, 16); dist |= __shfl_xor(dist, 4, 16); dist |= __shfl_xor(dist, 2, 16); dist |= __shfl_xor(dist, 1, 16);
+          if constexpr (NR > 1) dist = (unsigned)env_bci((int)dist, 0);  // (every lane of the env keeps the sleep counters)
           fdist = dist;
 #pragma unroll
           for (int b = 0; b < S16_MAX_FREE; b++)
@@ -1979,8 +2039,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int pk = hit_[i];
           const int sa = (pk >> 16) & 0xFF, sb = (pk >> 24) & 0xFF;
           const float mu = 0.5f * (L[S16_NP_SHP + S16_SHP * sa + 15] + L[S16_NP_SHP + S16_SHP * sb + 15]);
-          const int bodies = (int)(slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, n) |
-                                   (slot_lane_mask(L, (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1, n) << 16));
+          const int slA = (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, slB = (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1;
+          const int bodies = (int)(slot_lane_mask<NR>(L, slA, n, 0) | (slot_lane_mask<NR>(L, slB, n, 0) << 16));
+          const int bodies1 = NR > 1 ? (int)(slot_lane_mask<NR>(L, slA, n, 1) | (slot_lane_mask<NR>(L, slB, n, 1) << 16)) : 0;
           const f3 nn = f3{L[S16_NP_HN + 3 * i], L[S16_NP_HN + 3 * i + 1], L[S16_NP_HN + 3 * i + 2]};
           const int of = off_[i];
           for (int q = 0; q < 4; q++) {
@@ -1995,6 +2056,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               r[7] = __int_as_float((pk & 0xFFFF) | (a << 16) | (q << 24) | ((TRI && (__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) & 7u) == SH_TRIMESH) ? 1 << 27 : 0));
               r[8] = __int_as_float(bodies);
               r[9] = mu;
+              if constexpr (NR > 1) r[10] = __int_as_float(bodies1);
             }
             off++;
           }
@@ -2005,14 +2067,16 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             r[7] = __int_as_float((pk & 0xFFFF) | (a << 16) | (1 << 30));  // bit 30: torsional record
             r[8] = __int_as_float(bodies);
             r[9] = mu * my_tr;
+            if constexpr (NR > 1) r[10] = __int_as_float(bodies1);
           }
         }
         if (tot > MAXC) { if (live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONTACTS); tot = MAXC; }
         nc = tot;
+        if constexpr (NR > 1) nc = env_bci(nc, 0);  // (the env's other row built none of this)
       }
       WSYNC();
     }
-    if (FUSED && last) {
+    if (FUSED && last && lead) {
       nold = S.hit_list[e];
 #pragma unroll
       for (int k = 0; k < 3; k++)
@@ -2073,7 +2137,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     }
     sv6 S_c = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
     if (art) S_c = rev_c ? sv6{aw_c, cross(an_c - O, aw_c)} : sv6{f3{0, 0, 0}, aw_c};
-    {
+    if (lead) {  // (the staging tables of the dynamics belong to the articulation's row)
       float* p = L + S16_S + 6 * c;
       p[0] = S_c.w.x; p[1] = S_c.w.y; p[2] = S_c.w.z; p[3] = S_c.v.x; p[4] = S_c.v.y; p[5] = S_c.v.z;
       L[S16_VEC + c] = qd_c;
@@ -2087,7 +2151,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       V.w += f3{p[0], p[1], p[2]} * m;
       V.v += f3{p[3], p[4], p[5]} * m;
     }
-    {
+    if (lead) {
       sv6 T = crossm(V, S_c);
       float* p = L + S16_T + 6 * c;
       p[0] = T.w.x * qd_c; p[1] = T.w.y * qd_c; p[2] = T.w.z * qd_c; p[3] = T.v.x * qd_c; p[4] = T.v.y * qd_c; p[5] = T.v.z * qd_c;
@@ -2115,7 +2179,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       Fb_c = sf6{f1.n + f2.n, f1.f + f2.f};
       if (grav_c) { Fb_c.f -= g3 * m; Fb_c.n -= cross(I_c.h, g3); }
     }
-    {
+    if (lead) {
       float* p = L + S16_F + 6 * c;
       p[0] = Fb_c.n.x; p[1] = Fb_c.n.y; p[2] = Fb_c.n.z; p[3] = Fb_c.f.x; p[4] = Fb_c.f.y; p[5] = Fb_c.f.z;
       float* qI = L + S16_IC + 10 * c;
@@ -2208,7 +2272,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       for (int k = 0; k < 16; k++) {
         if (k >= n) break;
         WSYNC();
-        if (c == k) {
+        if (c == k && lead) {
 #pragma unroll
           for (int j = 0; j < NA; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + NA + j] = Irow[j]; }
         }
@@ -2231,7 +2295,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         }
       }
       WSYNC();
-      L[S16_VEC + 16 + c] = rhs_c;
+      if (lead) L[S16_VEC + 16 + c] = rhs_c;
       WSYNC();
       float rv[16];
       ld16(L + S16_VEC + 16, rv);
@@ -2267,7 +2331,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       s3 Ii = sinverse(Iw);
       const float minv = rcp_f(in[0]);
       f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
-      const int base = n + 6 * b;
+      const int base = fcol0 + 6 * b;  // (the free bodies' row reads its own lanes; what another row makes of this loop goes nowhere)
       f3 v0 = f3{gbc(vfree_c, base), gbc(vfree_c, base + 1), gbc(vfree_c, base + 2)};
       f3 w0 = clamp_norm(f3{gbc(vfree_c, base + 3), gbc(vfree_c, base + 4), gbc(vfree_c, base + 5)}, MSSIM_MAX_ANGULAR_VELOCITY);
       f3 acc = f3{gbc(fforce_c, base), gbc(fforce_c, base + 1), gbc(fforce_c, base + 2)} * minv;
@@ -2277,7 +2341,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       const float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
       vv = vv * (ld > 0.f ? ld : 0.f);
       ww = ww * (ad > 0.f ? ad : 0.f);
-      if (c == 0) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
+      if (c == 0 && frow) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
       const bool asleep_b = fwake[b] <= 0.f;  // at rest and out of the solver (none of its manifolds was kept)
       if (freel && fb_id == b) {
         mycom = com;
@@ -2316,7 +2380,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       for (int j = 0; j < 16; j++) {
         if (j >= n) break;
         const float sj = gbc(lim_side, j);
-        L[S16_LIMW + 16 * j + c] = sj * Irow[j];
+        if (lead) L[S16_LIMW + 16 * j + c] = sj * Irow[j];
         if (c == j) dself = Irow[j];
       }
       lim_inv = (has && dself > 1e-12f) ? rcp_f(dself) : 0.f;
@@ -2328,7 +2392,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     // about its direction enters). Per-lane dynamic indexing goes through 16 private LDS words.
     float Irot[16];
     {
-      float* tmp = L + S16_JW + 16 * c;
+      float* tmp = L + S16_JW + 16 * cl;
 #pragma unroll
       for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(tmp + j) = float4{Irow[j], Irow[j + 1], Irow[j + 2], Irow[j + 3]};
       rot_gather<0>(tmp, c, Irot);
@@ -2350,7 +2414,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       const bool tors = ck && ((pw >> 30) & 1);  // torsional friction block of the patch that ends just before it
       const int p = pw & 0xFFFF;
       const bool first = i == 0 || ((__float_as_int(L[S16_REC + S16_REC_LEN * (i - 1) + 7]) ^ pw) & 0x3F0000) != 0;  // first block of its patch
-      const int bodies = __float_as_int(rec[8]);
+      const int bodies = __float_as_int((NR > 1 && !lead) ? rec[10] : rec[8]);  // (lane masks of this lane's row)
       const float mu = tors ? 0.f : rec[9];
       // (one cross product and one normalisation: the helper axis is selected, not the result)
       const bool use_x = fabsf(nrm.x) < 0.57735f;
@@ -2378,9 +2442,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       // diagonal and the Delassus cross terms with the earlier rows of this contact (block Gauss-Seidel)
       float d0 = J3[0] * W3[0], d1 = J3[1] * W3[1], d2 = J3[2] * W3[2];
       float g10 = J3[1] * W3[0], g20 = J3[2] * W3[0], g21 = J3[2] * W3[1];
-      gsum16x3(d0, d1, d2);
-      gsum16x3(g10, g20, g21);
-      if (c == 0) {
+      gsumx3<NR>(d0, d1, d2);
+      gsumx3<NR>(g10, g20, g21);
+      if (c == 0 && lead) {
         const float i0 = d0 > 1e-12f ? rcp_f(d0) : 0.f, i1 = d1 > 1e-12f ? rcp_f(d1) : 0.f, i2 = d2 > 1e-12f ? rcp_f(d2) : 0.f;
         float4* cs = reinterpret_cast<float4*>(L + S16_CS + 16 * i);
         const bool pt = ck && !tors;
@@ -2394,7 +2458,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     // Warm start (include/mssim.h): the multipliers a (shape pair, manifold slot) carried in the previous substep, one
     // 16-byte load per contact, all contacts of the env in flight at once; they land in the multiplier words of the block
     // table (zeros for new contacts, torsional blocks and padding blocks) and are applied as the blocks are built.
-    for (int i = c; i < max_nc; i += 16) {
+    for (int i = lead ? c : max_nc; i < max_nc; i += 16) {
       float4 w = float4{0.f, 0.f, 0.f, 0.f};
       bool ok = false;
       if (i < nc && live) {
@@ -2429,11 +2493,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       if (i < S16_REGC + S16_LDSC) {
         float* row = L + S16_JW + S16_JWLEN * (i - S16_REGC);
 #pragma unroll
-        for (int dk = 0; dk < 3; dk++) { row[32 * dk + c] = J3[dk]; row[32 * dk + 16 + c] = W3[dk]; }
+        for (int dk = 0; dk < 3; dk++) { row[2 * GW * dk + cl] = J3[dk]; row[2 * GW * dk + GW + cl] = W3[dk]; }
       } else if (live) {
         float* row = grow + (size_t)S16_JWLEN * (i - S16_REGC - S16_LDSC);
 #pragma unroll
-        for (int dk = 0; dk < 3; dk++) { row[32 * dk + c] = J3[dk]; row[32 * dk + 16 + c] = W3[dk]; }
+        for (int dk = 0; dk < 3; dk++) { row[2 * GW * dk + cl] = J3[dk]; row[2 * GW * dk + GW + cl] = W3[dk]; }
       }
     }
     nrow_con = nc;
@@ -2469,7 +2533,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     auto con_solve = [&](float J0, float W0, float J1, float W1, float J2, float W2, float& lam0, float& lam1, float& lam2,
                          float4 s0, float4 sk, float k21, float tmu, float accmul, bool use_bias) __attribute__((always_inline)) {
       float jv0 = J0 * v_c, jv1 = J1 * v_c, jv2 = J2 * v_c;
-      gsum16x3(jv0, jv1, jv2);
+      gsumx3<NR>(jv0, jv1, jv2);
       const float a1 = fmaf(-jv1, sk.x, lam1);
       const float a2 = fmaf(-jv2, sk.z, lam2);
       const bool tors = tmu > 0.f;
@@ -2492,16 +2556,16 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       float2 tq;          // (torsional bound factor, carry factor of the manifold's normal-multiplier sum)
     };
     auto con_load = [&](const float* row, int ci, ConRec& R) __attribute__((always_inline)) {
-      R.J0 = row[c]; R.W0 = row[16 + c];
-      R.J1 = row[32 + c]; R.W1 = row[48 + c];
-      R.J2 = row[64 + c]; R.W2 = row[80 + c];
+      R.J0 = row[cl]; R.W0 = row[GW + cl];
+      R.J1 = row[2 * GW + cl]; R.W1 = row[3 * GW + cl];
+      R.J2 = row[4 * GW + cl]; R.W2 = row[5 * GW + cl];
       const float4* cs = reinterpret_cast<const float4*>(L + S16_CS + 16 * ci);
       R.s0 = cs[0]; R.sk = cs[1]; R.kl = cs[2];
       R.tq = *reinterpret_cast<const float2*>(L + S16_CS + 16 * ci + 14);
     };
     auto con_apply = [&](ConRec& R, int ci, bool use_bias) __attribute__((always_inline)) {
       con_solve(R.J0, R.W0, R.J1, R.W1, R.J2, R.W2, R.kl.y, R.kl.z, R.kl.w, R.s0, R.sk, R.kl.x, R.tq.x, R.tq.y, use_bias);
-      if (c == 0) *reinterpret_cast<float4*>(L + S16_CS + 16 * ci + 8) = R.kl;  // (padding blocks rewrite their zeros)
+      if (c == 0 && lead) *reinterpret_cast<float4*>(L + S16_CS + 16 * ci + 8) = R.kl;  // (padding blocks rewrite their zeros)
     };
 #ifdef EXP_ITERS
     const int n_iters = EXP_ITERS;
@@ -2518,7 +2582,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         for (int b = 0; b < S16_MAX_FREE; b++) {
           if (b >= nf) break;
           const float* in = fin[b];
-          const int base = n + 6 * b;
+          const int base = fcol0 + 6 * b;
           f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
           f3 ww = clamp_norm(f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)}, MSSIM_MAX_ANGULAR_VELOCITY);
           f3 com = f3{L[S16_COM + 3 * b], L[S16_COM + 3 * b + 1], L[S16_COM + 3 * b + 2]} + vv * dt;
@@ -2532,8 +2596,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             pp = f3{pt[0], pt[1], pt[2]};
             qq = q4{pt[3], pt[4], pt[5], pt[6]};
           }
-          if (c == 0) lds_pose_store(pt, pose_t{pp, qq});
-          if (c == 0 && live && last) {
+          if (c == 0 && frow) lds_pose_store(pt, pose_t{pp, qq});
+          if (c == 0 && frow && live && last) {
             SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
             SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
           }
@@ -2592,9 +2656,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         auto gload = [&](int k, ConRec& R) __attribute__((always_inline)) {
           const int kk = min(k, max_cglb - 1);
           const float* row = grow + (size_t)S16_JWLEN * kk;
-          R.J0 = row[c]; R.W0 = row[16 + c];
-          R.J1 = row[32 + c]; R.W1 = row[48 + c];
-          R.J2 = row[64 + c]; R.W2 = row[80 + c];
+          R.J0 = row[cl]; R.W0 = row[GW + cl];
+          R.J1 = row[2 * GW + cl]; R.W1 = row[3 * GW + cl];
+          R.J2 = row[4 * GW + cl]; R.W2 = row[5 * GW + cl];
         };
         auto gapply = [&](ConRec& R, int k) __attribute__((always_inline)) {
           const int ci = S16_REGC + S16_LDSC + k;
@@ -2634,22 +2698,22 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           float dl = gbc(nl - lim_lam, j);
           dl = act ? dl : 0.f;
           if (act && c == j) lim_lam = nl;
-          v_c = fmaf(L[S16_LIMW + 16 * j + c], dl, v_c);
+          if (lead) v_c = fmaf(L[S16_LIMW + 16 * j + c], dl, v_c);  // (W of a limit row is zero outside the articulation's block)
           cursor = act ? j + 1 : 16;
         }
       }
       }  // run
-      if (use_bias) settled = settled || ((unsigned)(__ballot(fabsf(v_c - v_before) > MSSIM_PGS_EXIT_TOLERANCE) >> (16 * g)) & 0xFFFFu) == 0u;
+      if (use_bias) settled = settled || benv(fabsf(v_c - v_before) > MSSIM_PGS_EXIT_TOLERANCE) == 0u;
       PH(18);
     }
-    if (c == 0) {
+    if (c == 0 && lead) {
 #pragma unroll
       for (int k = 0; k < S16_REGC; k++)
         if (k < nc_reg) { L[S16_CS + 16 * k + 9] = lamr[k][0]; L[S16_CS + 16 * k + 10] = lamr[k][1]; L[S16_CS + 16 * k + 11] = lamr[k][2]; }
     }
     WSYNC();
     // the multipliers of this substep, keyed by (shape pair, manifold slot) and stamped: the next substep's warm start
-    for (int i = c; i < nc; i += 16) {
+    for (int i = lead ? c : nc; i < nc; i += 16) {
       const int pw = __float_as_int(L[S16_REC + S16_REC_LEN * i + 7]);
       if (((pw >> 30) & 1) || !live || (TRI && ((pw >> 27) & 1))) continue;
       *reinterpret_cast<float4*>(S.warm + (((size_t)(4 * (pw & 0xFFFF) + ((pw >> 24) & 3))) * N + e) * 4) =
@@ -2667,10 +2731,10 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       f3 acc = f3{0, 0, 0};
       auto flush = [&]() __attribute__((always_inline)) {
         if (prev_p >= 0 && live) {
-          if (c == 0) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
-          if (FUSED && c == 0) { S.pair_cnt[(size_t)prev_p * N + e] = run; S.hit_list[(size_t)(1 + nnew) * N + e] = prev_p; }
+          if (c == 0 && lead) { SOA(S.pair_imp, 3 * prev_p) = acc.x; SOA(S.pair_imp, 3 * prev_p + 1) = acc.y; SOA(S.pair_imp, 3 * prev_p + 2) = acc.z; }
+          if (FUSED && c == 0 && lead) { S.pair_cnt[(size_t)prev_p * N + e] = run; S.hit_list[(size_t)(1 + nnew) * N + e] = prev_p; }
         }
-        if (FUSED && prev_p >= 0) { if (c == 0) newl[nnew] = prev_p; nnew++; }
+        if (FUSED && prev_p >= 0) { if (c == 0 && lead) newl[nnew] = prev_p; nnew++; }
       };
       for (int i = 0; i < nc; i++) {
         const float l0 = L[S16_CS + 16 * i + 9], l1 = L[S16_CS + 16 * i + 10], l2 = L[S16_CS + 16 * i + 11];
@@ -2701,7 +2765,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           for (int j = 0; j < nnew; j++) still = still || (newl[j] == po);
           if (!still && live) S.pair_cnt[(size_t)po * N + e] = 0;
         }
-        if (c == 0 && live) S.hit_list[e] = nnew;
+        if (c == 0 && lead && live) S.hit_list[e] = nnew;
         WSYNC();
       }
     }
@@ -2729,7 +2793,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       for (int round = 0; round < 4; round++) {
         if (!__any(up >= 0)) break;
         if (art) lds_pose_store(mine, T);
-        upv[c] = up;
+        if (lead) upv[c] = up;
         WSYNC();
         if (up >= 0) {
           const pose_t Tu = lds_pose(L + S16_BP + 7 * up);
@@ -2758,10 +2822,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll
     for (int b = 0; b < S16_MAX_FREE; b++) {
       if (b >= nf) break;
-      const int base = n + 6 * b;
+      const int base = fcol0 + 6 * b;
       const f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)}, ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
       const float* pt = L + S16_PT + 7 * (S16_PT_FREE + b);
-      const bool calm = norm_energy(fin[b], vv, ww, q4{pt[3], pt[4], pt[5], pt[6]}) < M.sleep_threshold;
+      bool calm = norm_energy(fin[b], vv, ww, q4{pt[3], pt[4], pt[5], pt[6]}) < M.sleep_threshold;
+      if constexpr (NR > 1) calm = env_bci(calm ? 1 : 0, 16) != 0;  // (as the free bodies' row sees it: every lane of the env keeps the counters)
       if (fwake[b] > 0.f) {
         fwake[b] = (calm && M.sleep_threshold > 0.f && !((fdist >> b) & 1u)) ? fwake[b] - dt : MSSIM_WAKE_TIME;
         if (fwake[b] <= 0.f) {
@@ -2784,13 +2849,13 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
         if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
       }
-      if (c < nf && live) SOA(S.free_wake, c) = c == 0 ? fwake[0] : fwake[1];
-      if (c == 0 && live) S.pcm_tick[e] = pcm_tick;
+      if (c < nf && lead && live) SOA(S.free_wake, c) = c == 0 ? fwake[0] : fwake[1];
+      if (c == 0 && lead && live) S.pcm_tick[e] = pcm_tick;
       // body velocities about O with the new subspaces
       sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};
       if (art) nS = rev_c ? sv6{naw, cross(nan - O, naw)} : sv6{f3{0, 0, 0}, naw};
       WSYNC();
-      {
+      if (lead) {
         float* p = L + S16_S + 6 * c;
         p[0] = nS.w.x; p[1] = nS.w.y; p[2] = nS.w.z; p[3] = nS.v.x; p[4] = nS.v.y; p[5] = nS.v.z;
         L[S16_VEC + c] = qd_c;
