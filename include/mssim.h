@@ -120,6 +120,12 @@ extern "C" {
  * area on the other side of the edge) is only taken if its area exceeds MSSIM_PATCH_TIE_REL of the 3rd point's: a point
  * on the edge itself up to rounding adds nothing and would be there or not by the sign of a rounding error. */
 #define MSSIM_PATCH_TIE_SEP 1e-5f  /* separations within 10 micrometres of the deepest count as equal */
+/* The selection goes by extent, not by depth: in a patch that rests on three or more points, the points the contact offset
+ * admits well above them (a compound body lying on two of its parts while a third hangs 8 mm over the ground) would take
+ * the places of the ones that carry the load, and the body rocks and sinks on what is left. When at least 3 points of a
+ * patch with more than 4 lie within MSSIM_PATCH_SLACK of its deepest one, only those are candidates; with fewer (a corner
+ * or an edge touching down) all points compete as before. (A mesh triangle applies the same bound to its own points: MSSIM_TRI_SLACK.) */
+#define MSSIM_PATCH_SLACK 4e-3f
 #define MSSIM_PATCH_TIE_REL 1e-3f  /* squared distances / areas within 0.1 % of the largest count as equal */
 #define MSSIM_MAX_CONTACTS 52      /* contact points per env fed to the solver, after the patch reduction */
 #define MSSIM_MAX_HITS 64          /* shape pairs per env that survive the cull               */

@@ -850,10 +850,12 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   if (d->n_dof > MSSIM_MAX_DOF || d->n_free > MSSIM_MAX_FREE) { g_create_error = "model exceeds MSSIM_MAX_DOF / MSSIM_MAX_FREE"; return 3; }
   // the control-step kernel keeps an env on one or two 16-lane rows (one velocity component per lane: the joints in row 0, the free
   // bodies behind them or, when that is more than 16 components, in a row of their own) and its scene in fixed LDS tables
-  if (d->n_dof > S16_LANES || d->n_free > S16_MAX_FREE || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE || d->n_pair > 56 * 16) {
-    char msg[256];
+  const int rows_per_env = d->n_dof + 6 * d->n_free > S16_LANES ? 2 : 1;
+  if (d->n_dof > S16_LANES || d->n_free > S16_MAX_FREE || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE_(rows_per_env) || d->n_pair > 56 * 16) {
+    char msg[320];
     snprintf(msg, sizeof msg, "model exceeds the control-step kernel's tables: %d joints (max %d), %d free bodies (max %d), %d kinematic bodies (max %d), "
-             "%d shapes (max %d), %d candidate pairs (max %d)", d->n_dof, S16_LANES, d->n_free, S16_MAX_FREE, d->n_kin, S16_MAX_KIN, d->n_shape, S16_MAX_SHAPE, d->n_pair, 56 * 16);
+             "%d shapes (max %d with %d velocity components), %d candidate pairs (max %d)", d->n_dof, S16_LANES, d->n_free, S16_MAX_FREE, d->n_kin, S16_MAX_KIN, d->n_shape,
+             S16_MAX_SHAPE_(rows_per_env), d->n_dof + 6 * d->n_free, d->n_pair, 56 * 16);
     g_create_error = msg;
     return 9;
   }
@@ -872,7 +874,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   mssim_sim* S = new mssim_sim();
   S->device = device;
   S->N = num_envs;
-  S->rows_per_env = d->n_dof + 6 * d->n_free > S16_LANES ? 2 : 1;
+  S->rows_per_env = rows_per_env;
   hipError_t e0 = hipSetDevice(device);
   if (e0 != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e0); delete S; return 6; }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) S->n_cu = ncu; }

@@ -52,7 +52,7 @@
 #define S16_PT_KIN 19
 #define S16_MAX_FREE 2
 #define S16_MAX_KIN 6
-#define S16_MAX_SHAPE 28
+#define S16_MAX_SHAPE_(nr) ((nr) > 1 ? 48 : 28)  // shapes per model: a lane builds the world-table entries of two (NR = 2: all 32 lanes of the env)
 #define S16_MAX_HIT 64
 #define S16_BP (S16_PT + 7 * S16_PT_LINK)  // link poses
 #define S16_U 272      // union: dynamics staging | solver rows | narrowphase scratch
@@ -84,13 +84,16 @@
 #define S16_ROWLEN S16_ROWLEN_(NR)
 // narrowphase scratch, overlays the union below the contact records
 #define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 torsional-radius
-#define S16_NP_SHP (S16_U)        // [28][20] world shape table
-#define S16_NP_HIT (S16_U + 560)  // [64] surviving pairs: pair | sa << 16 | sb << 24
-#define S16_NP_CNT (S16_U + 624)  // [64] manifold sizes (raw, before the patch reduction)
-#define S16_NP_OFF (S16_U + 688)  // [64] first point of each manifold in the point pool
+#define S16_NP_SHP (S16_U)        // [S16_MAX_SHAPE][20] world shape table
+#define S16_NP_B_(nr) (S16_U + S16_SHP * S16_MAX_SHAPE_(nr))  // what follows the shape table
+#define S16_NP_B S16_NP_B_(NR)
+#define S16_MAX_SHAPE S16_MAX_SHAPE_(NR)
+#define S16_NP_HIT (S16_NP_B)        // [64] surviving pairs: pair | sa << 16 | sb << 24
+#define S16_NP_CNT (S16_NP_B + 64)   // [64] manifold sizes (raw, before the patch reduction)
+#define S16_NP_OFF (S16_NP_B + 128)  // [64] first point of each manifold in the point pool
 // [896]: pair table during the cull (<= 896 pairs) | [56][16] box-box clip scratch of the one-lane-per-pair path |
 // afterwards the staged manifolds: normals, point pool, patch bookkeeping
-#define S16_NP_SCR (S16_U + 752)
+#define S16_NP_SCR (S16_NP_B + 192)
 #define S16_NP_HN (S16_NP_SCR)            // [64][3] manifold normals
 #define S16_NP_POOL (S16_NP_SCR + 192)    // [MSSIM_MAX_RAW_POINTS][4] x y z sep, in allocation order (16-byte aligned)
 #define S16_NP_BSCR (S16_NP_SCR + 704)    // [24] polygon scatter / gather words of the group (cooperative box-box)
@@ -98,16 +101,18 @@
 #define S16_NP_KEY (S16_NP_SCR + 792)     // [64] body pair of the manifold
 #define S16_NP_ALLOC (S16_NP_SCR + 856)   // [1] points handed out from the pool
 #define S16_NP_BOUT (S16_NP_SCR + 860)    // [20] manifold of the group's current cooperative box-box pair
-#define S16_NP_ML (S16_U + 1648)  // [64 bytes] hit indices of this env's MPR (generic convex) pairs
-#define S16_NP_BL (S16_U + 1664)  // [64 bytes] hit indices of this env's box-box pairs
-#define S16_NP_SLOT (S16_U + 1680) // [64 bytes] persistent-manifold slot of each hit (255 none | slot | 0x80 newly assigned)
+#define S16_NP_ML (S16_NP_B + 1088)  // [64 bytes] hit indices of this env's MPR (generic convex) pairs
+#define S16_NP_BL (S16_NP_B + 1104)  // [64 bytes] hit indices of this env's box-box pairs
+#define S16_NP_SLOT (S16_NP_B + 1120) // [64 bytes] persistent-manifold slot of each hit (255 none | slot | 0x80 newly assigned)
+#define S16_NP_PL (S16_NP_B + 1136)   // [64 bytes] hit indices of this env's (plane, hull) pairs
 #define S16_PCM_LEN 48            // floats per cache slot: pair npts stamp flags | relp(3) - | relR(9) n_loc(3) | 4 x (pA(3) pB(3) gap)
 #define S16_MAX_BBC 16            // box-box pairs per wave up to which they are worked on by 16-lane groups
 #define S16_MAX_MPR 64            // (= every hit: an arm folded onto itself and jammed into the table has 20+ hull pairs in range)
-static_assert(S16_NP_BOUT + 20 <= S16_NP_SCR + 896, "narrowphase staging exceeds the scratch area");
-static_assert(S16_NP_SLOT + 16 <= S16_REC_(1), "narrowphase lists run into the contact records");
+static_assert(860 + 20 <= 896, "narrowphase staging exceeds the scratch area");
+static_assert(S16_NP_B_(1) + 1136 + 16 <= S16_REC_(1) && S16_NP_B_(2) + 1136 + 16 <= S16_REC_(2), "narrowphase lists run into the contact records");
+static_assert((S16_NP_B_(1) + 192 + 192) % 4 == 0 && (S16_NP_B_(2) + 192 + 192) % 4 == 0, "point pool: 16-byte aligned");
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
-static_assert(MSSIM_MAX_TRI_TASKS + MSSIM_MAX_TRI_HITS <= S16_NP_KEY - S16_NP_BSCR, "triangle task list + candidates exceed the scratch they borrow (BSCR + KEEP)");
+static_assert(MSSIM_MAX_TRI_TASKS + MSSIM_MAX_TRI_HITS <= 792 - 704, "triangle task list + candidates exceed the scratch they borrow (BSCR + KEEP)");
 
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
@@ -414,6 +419,137 @@ MS_DEV void collide_box_box_coop(const shape_t& A, const shape_t& B, float offse
   }
   if (slot >= 0) { out[4 + 4 * slot] = q.x; out[5 + 4 * slot] = q.y; out[6 + 4 * slot] = q.z; out[7 + 4 * slot] = sp; }
 }
+// A convex hull against a plane by the 16 lanes of a group (lane c holds vertices c, c + 16, c + 32, c + 48): the hull's
+// vertices inside the contact offset; when more than 4 of them lie within MSSIM_PATCH_SLACK of the lowest -- a hull lying on
+// a face: the rim of a cup, the foot of a post -- four are taken by EXTENT among those (the patch rule: the deepest, the
+// farthest from it, the largest area on either side of that edge, first candidate within the tie tolerance of every
+// extremum), else the 4 deepest (lowest index among equals). Same points in the same order as the oracle's collide_plane.
+// Result -> out[20] like collide_box_box_coop: count | n | 4 x (x y z sep). The group's lanes must be converged.
+MS_DEV void collide_plane_hull_coop(const shape_t& pl, const shape_t& b, float offset, float* out, int c, int g) {
+  auto ballot16 = [&](bool v) __attribute__((always_inline)) { return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu; };
+  const f3 np = mcol(pl.rot, 0);
+  const int nv = b.nverts < 64 ? b.nverts : 64;
+  f3 X[4];
+  float Sp[4];
+  bool in[4];
+  int n = 0;
+  float smin = 3e38f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = c + 16 * k;
+    const bool exists = i < nv;
+    const float* v = b.verts + 3 * (exists ? i : 0);
+    const f3 p = b.c + mmulv(b.rot, f3{v[0], v[1], v[2]});
+    const float s = dot(np, p - pl.c);
+    X[k] = p - np * (0.5f * s);
+    Sp[k] = s;
+    in[k] = exists && s < offset;
+    n += __popc(ballot16(in[k]));
+    smin = fminf(smin, in[k] ? s : 3e38f);
+  }
+  smin = -gmax16(-smin);
+  // the point at vertex index `id` (owner lane id & 15, slot id >> 4), from its owner
+  auto point_at = [&](int id) __attribute__((always_inline)) {
+    const int owner = id & 15, slot = id >> 4;
+    const f3 mine = slot == 0 ? X[0] : (slot == 1 ? X[1] : (slot == 2 ? X[2] : X[3]));
+    const float ms = slot == 0 ? Sp[0] : (slot == 1 ? Sp[1] : (slot == 2 ? Sp[2] : Sp[3]));
+    return float4{gbc(mine.x, owner), gbc(mine.y, owner), gbc(mine.z, owner), gbc(ms, owner)};
+  };
+  auto first_pos = [&](const bool (&ok)[4]) __attribute__((always_inline)) {
+    int p = 1 << 20;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) p = ok[k] ? c + 16 * k : p;
+    p = gmin16i(p);
+    return p == (1 << 20) ? -1 : p;
+  };
+  int pick[4] = {-1, -1, -1, -1};
+  int near_ = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) near_ += __popc(ballot16(in[k] && Sp[k] <= smin + MSSIM_PATCH_SLACK));
+  if (n > 4 && near_ > 4) {
+    bool has[4], ok[4];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { has[k] = in[k] && Sp[k] <= smin + MSSIM_PATCH_SLACK; ok[k] = has[k] && Sp[k] <= smin + MSSIM_PATCH_TIE_SEP; }
+    const int q0 = first_pos(ok);
+    const float4 P0 = point_at(q0);
+    const f3 p0 = f3{P0.x, P0.y, P0.z};
+    float best = -1.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f3 d = X[k] - p0;
+      v[k] = dot(d, d);
+      has[k] = has[k] && c + 16 * k != q0;
+      best = fmaxf(best, has[k] ? v[k] : -1.f);
+    }
+    best = gmax16(best);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ok[k] = has[k] && v[k] >= best - MSSIM_PATCH_TIE_REL * best;
+    const int q1 = first_pos(ok);
+    const float4 P1 = point_at(q1);
+    const f3 ed = f3{P1.x, P1.y, P1.z} - p0;
+    const f3 na = -np;
+    best = -1.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k] = dot(cross(ed, X[k] - p0), na);
+      has[k] = has[k] && c + 16 * k != q1;
+      best = fmaxf(best, has[k] ? fabsf(v[k]) : -1.f);
+    }
+    best = gmax16(best);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ok[k] = has[k] && fabsf(v[k]) >= best - MSSIM_PATCH_TIE_REL * best;
+    const int q2 = first_pos(ok);
+    const float4 P2 = point_at(q2);
+    const float sgn2 = dot(cross(ed, f3{P2.x, P2.y, P2.z} - p0), na);
+    best = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k] = sgn2 >= 0.f ? -v[k] : v[k];
+      has[k] = has[k] && c + 16 * k != q2;
+      best = fmaxf(best, has[k] ? v[k] : 0.f);
+    }
+    best = gmax16(best);
+    int q3 = -1;
+    if (best > MSSIM_PATCH_TIE_REL * fabsf(sgn2)) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) ok[k] = has[k] && v[k] >= best - MSSIM_PATCH_TIE_REL * best;
+      q3 = first_pos(ok);
+    }
+    pick[0] = q0; pick[1] = q1; pick[2] = q2; pick[3] = q3;
+  } else {
+    // the 4 deepest, the lowest index among equals
+    bool rem[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rem[k] = in[k];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float best = 3e38f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) best = fminf(best, rem[k] ? Sp[k] : 3e38f);
+      best = -gmax16(-best);
+      int id = 1 << 20;
+#pragma unroll
+      for (int k = 3; k >= 0; k--) id = (rem[k] && Sp[k] == best) ? c + 16 * k : id;
+      id = gmin16i(id);
+      pick[r] = id == (1 << 20) ? -1 : id;
+#pragma unroll
+      for (int k = 0; k < 4; k++) rem[k] = rem[k] && c + 16 * k != id;
+    }
+  }
+  int count = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (pick[r] < 0) continue;  // (group-uniform)
+    const float4 P = point_at(pick[r]);
+    if (c == 0) { out[4 + 4 * count] = P.x; out[5 + 4 * count] = P.y; out[6 + 4 * count] = P.z; out[7 + 4 * count] = P.w; }
+    count++;
+  }
+  if (c == 0) {
+    out[0] = __int_as_float(count);
+    out[1] = -np.x; out[2] = -np.y; out[3] = -np.z;
+  }
+}
 // pose-table slot of a body: -1 = fixed in the env frame
 MS_DEV int pose_slot(int kind, int index) {
   if (kind == MSSIM_BODY_ART) return index < 0 ? 0 : S16_PT_LINK + index;
@@ -544,6 +680,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
   __shared__ int blk_nml[BLK_ENVS];  // generic-convex pairs of every env of the block (stage B task list)
   __shared__ int blk_nbl[BLK_ENVS];  // its box-box pairs that go to 16-lane groups (stage C task list)
   __shared__ int blk_ntl[BLK_ENVS];  // its mesh-triangle tasks (stage T task list; TRI variants only)
+  __shared__ int blk_npl[BLK_ENVS];  // its (plane, hull) pairs (stage C, after the box-box pairs)
   const int N = S.N;
   const int wv = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
   const int g = lane64 >> 4, c = threadIdx.x & 15;  // 16-lane group within the wave (ballot slices), lane within the group
@@ -684,7 +821,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     int nc = 0;
     unsigned fdist = 0u;  // free bodies touched by a disturber in this substep (sleep counters)
     if (FUSED) {
-      // shape-local data of shapes c and c + 16 and the cull pairs of this lane (model constants,
+      // shape-local data of shapes c and c + 16 (two rows per env: cl and cl + 32) and the cull pairs of this lane (model constants,
       // fetched per substep rather than held in registers over the whole step)
       pose_t shF[2];
       float shP[2][3], shBr[2], shMu[2], shTr[2];
@@ -694,10 +831,10 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          const int s = c + 16 * k;
+          const int s = cl + GW * k;
           shF[k] = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
           shP[k][0] = shP[k][1] = shP[k][2] = 0.f; shBr[k] = 0.f; shMu[k] = 0.f; shTr[k] = 0.f; shBc[k] = f3{0, 0, 0}; shH[k] = f3{0, 0, 0}; shPk[k] = 0u; shSlot[k] = -1;
-          if (lead && s < M.n_shape) {
+          if (s < M.n_shape) {
             float r[24];  // the shape's 96-byte constant record
             const float4* rp = reinterpret_cast<const float4*>(M.shape_pack + 24 * s);
 #pragma unroll
@@ -745,8 +882,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       // ---- world shape table of this env
 #pragma unroll
       for (int k = 0; k < 2; k++) {
-        const int s = c + 16 * k;
-        if (lead && s < M.n_shape) {
+        const int s = cl + GW * k;
+        if (s < M.n_shape) {
           pose_t P = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
           if (shSlot[k] >= 0) P = lds_pose(L + S16_PT + 7 * shSlot[k]);
           const pose_t W = pmul(P, shF[k]);
@@ -858,18 +995,21 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       // ---- classification: generic convex pairs (MPR) and box-box pairs of this env (byte lists of hit indices)
       int nml = 0;  // MPR pairs of this env
       int nbl = 0;  // box-box pairs of this env
+      int npl = 0;  // (plane, hull) pairs of this env: by 16-lane groups as well (stage C)
       {
         unsigned char* const ml = reinterpret_cast<unsigned char*>(L + S16_NP_ML);
         unsigned char* const bl = reinterpret_cast<unsigned char*>(L + S16_NP_BL);
+        unsigned char* const pll = reinterpret_cast<unsigned char*>(L + S16_NP_PL);
         bool over = false;
         for (int base = 0; base < nh; base += 16) {
           const int idx = base + c;
-          bool is_mpr = false, is_bb = false;
+          bool is_mpr = false, is_bb = false, is_ph = false;
           if (idx < nh) {
             const int pk = reinterpret_cast<const int*>(L)[S16_NP_HIT + idx];
             const int ta = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF) + 14]) & 7u);
             const int tb = (int)(__float_as_uint(L[S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF) + 14]) & 7u);
             is_bb = ta == SH_BOX && tb == SH_BOX;
+            is_ph = ta == SH_PLANE && tb == SH_CONVEX;
             is_mpr = !(ta == SH_PLANE || is_bb || (TRI && tb == SH_TRIMESH));  // (mesh pairs: stage T)
             reinterpret_cast<int*>(L)[S16_NP_CNT + idx] = 0;
           }
@@ -883,6 +1023,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const unsigned b16 = (unsigned)(__ballot(is_bb) >> (16 * g)) & 0xFFFFu;
           if (is_bb) bl[nbl + __popc(b16 & ((1u << c) - 1u))] = (unsigned char)idx;
           nbl += __popc(b16);
+          const unsigned p16 = (unsigned)(__ballot(is_ph) >> (16 * g)) & 0xFFFFu;
+          if (is_ph) pll[npl + __popc(p16 & ((1u << c) - 1u))] = (unsigned char)idx;
+          npl += __popc(p16);
         }
         if (__any(over) && over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONVEX);
         nml = nml < S16_MAX_MPR ? nml : S16_MAX_MPR;
@@ -933,7 +1076,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           PH_ADD(27, __popcll(__ballot(A.type == SH_PLANE)));
           PH_ADD(28, __popcll(__ballot(A.type == SH_BOX && B.type == SH_BOX)));
           PH(10);
-          const bool is_plane = A.type == SH_PLANE, is_bb = bb_lane && A.type == SH_BOX && B.type == SH_BOX;
+          const bool is_plane = A.type == SH_PLANE && B.type != SH_CONVEX, is_bb = bb_lane && A.type == SH_BOX && B.type == SH_BOX;  // ((plane, hull): stage C)
           if (is_plane) collide_plane(A, B, M.contact_offset, m);
           PH(11);
           if (is_bb) collide_box_box<16>(A, B, M.contact_offset, m, L + S16_NP_SCR + c);
@@ -961,7 +1104,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       if (T == 0) {  // (wave-uniform) no round ran: the pool counter is still to be cleared
         if (c == 0 && lead) reinterpret_cast<int*>(L)[S16_NP_ALLOC] = 0;
       }
-      if (c == 0 && lead) { blk_nml[gb] = nml; blk_nbl[gb] = bb_lane ? 0 : nbl; }
+      if (c == 0 && lead) { blk_nml[gb] = nml; blk_nbl[gb] = bb_lane ? 0 : nbl; blk_npl[gb] = npl; }
       BSYNC();  // every wave is done with its clip scratch: stage B may write manifolds into any env's staging tables
       PH(13);
       // ---- stage B: generic convex pairs through the persistent manifold cache (include/mssim.h MSSIM_PCM_*).
@@ -1681,28 +1824,31 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       BT_T(22);
       PH(25);
       // ---- stage C: box-box pairs by 16-lane groups, round-robin over the block's list like stage B (the pairs of a wave
-      // that has more than 16 of them were done one per lane in stage A)
+      // that has more than 16 of them were done one per lane in stage A); behind them in the same list the (plane, hull)
+      // pairs: the hull's vertices over the lanes, the choice of its four points by group reductions
       {
-        int TBb = 0;
+        int TBb = 0, TPb = 0;
 #pragma unroll
-        for (int j = 0; j < BLK_ENVS; j++) TBb += blk_nbl[j];
-        for (int t = grp; t < TBb; t += BLK_GRPS) {
-          int ge = 0, k = t;
+        for (int j = 0; j < BLK_ENVS; j++) { TBb += blk_nbl[j]; TPb += blk_npl[j]; }
+        for (int t = grp; t < TBb + TPb; t += BLK_GRPS) {
+          const bool ph = t >= TBb;  // (group-uniform) a (plane, hull) pair
+          int ge = 0, k = ph ? t - TBb : t;
 #pragma unroll
           for (int j = 0; j < BLK_ENVS - 1; j++) {
-            const int nj = blk_nbl[j];
+            const int nj = ph ? blk_npl[j] : blk_nbl[j];
             const bool past = ge == j && k >= nj;
             k -= past ? nj : 0;
             ge += past ? 1 : 0;
           }
           float* Lg = sm + ge * S16_ENV_FLOATS;
-          const int idx = reinterpret_cast<const unsigned char*>(Lg + S16_NP_BL)[k];
+          const int idx = ph ? reinterpret_cast<const unsigned char*>(Lg + S16_NP_PL)[k] : reinterpret_cast<const unsigned char*>(Lg + S16_NP_BL)[k];
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
           const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
           // (scratch of this GROUP: the env's other row borrows the body-pair keys' words, idle until the patch pass)
           float* out = lead ? L + S16_NP_BOUT : L + S16_NP_KEY + 24;
-          collide_box_box_coop(A, B, M.contact_offset, lead ? L + S16_NP_BSCR : L + S16_NP_KEY, out, c, g);
+          if (ph) collide_plane_hull_coop(A, B, M.contact_offset, out, c, g);
+          else collide_box_box_coop(A, B, M.contact_offset, lead ? L + S16_NP_BSCR : L + S16_NP_KEY, out, c, g);
           const int cnt = __float_as_int(out[0]);  // (one wave: the LDS writes of the group's lanes are complete)
           if (cnt > 0) {
             int off = 0;
@@ -1860,6 +2006,15 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
 #pragma unroll
               for (int k = 0; k < 4; k++) ok[k] = has[k] && P[k].w <= best + MSSIM_PATCH_TIE_SEP;
               const int q0 = first_pos(ok);
+              {  // a patch resting on three or more points: the ones well above them do not compete (MSSIM_PATCH_SLACK)
+                int near_ = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) near_ += __popc(b16(has[k] && P[k].w <= best + MSSIM_PATCH_SLACK));
+                if (near_ >= 3) {
+#pragma unroll
+                  for (int k = 0; k < 4; k++) has[k] = has[k] && P[k].w <= best + MSSIM_PATCH_SLACK;
+                }
+              }
               const float4 P0 = point_at(q0);
               const f3 p0 = f3{P0.x, P0.y, P0.z};
               // farthest from it
@@ -1919,7 +2074,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               // more than 64 candidates in one patch (a heap of bodies on one another): the sequential scans, one lane
           const f3 na = f3{L[S16_NP_HN + 3 * a], L[S16_NP_HN + 3 * a + 1], L[S16_NP_HN + 3 * a + 2]};
               // point id = manifold * 4 + point; "first candidate wins" in (manifold, point) order, as the oracle
-              auto scan = [&](auto&& f) __attribute__((always_inline)) {
+              auto scan0 = [&](auto&& f) __attribute__((always_inline)) {
                 for (int i = a; i < nh; i++) {
                   if ((keep_[i] >> 4) != a) continue;
                   const int cn = cnt_[i], of = off_[i];
@@ -1930,8 +2085,17 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
               float best = 3e38f;
               f3 p0 = f3{0, 0, 0}, p1 = f3{0, 0, 0};
-              scan([&](int, float4 P) { best = fminf(best, P.w); });
-              scan([&](int id, float4 P) { if (i0 < 0 && P.w <= best + MSSIM_PATCH_TIE_SEP) { i0 = id; p0 = f3{P.x, P.y, P.z}; } });
+              scan0([&](int, float4 P) { best = fminf(best, P.w); });
+              scan0([&](int id, float4 P) { if (i0 < 0 && P.w <= best + MSSIM_PATCH_TIE_SEP) { i0 = id; p0 = f3{P.x, P.y, P.z}; } });
+              // (MSSIM_PATCH_SLACK: with three or more points near the deepest, the ones well above them are passed over)
+              int near_ = 0;
+              const float low = best + MSSIM_PATCH_SLACK;
+              scan0([&](int, float4 P) { near_ += P.w <= low ? 1 : 0; });
+              const float lim = near_ >= 3 ? low : 3e38f;
+              auto scan_all = scan0;
+              auto scan = [&](auto&& f) __attribute__((always_inline)) {
+                scan_all([&](int id, float4 P) { if (P.w <= lim) f(id, P); });
+              };
               best = -1.f;
               scan([&](int id, float4 P) {
                 const f3 d = f3{P.x, P.y, P.z} - p0;

@@ -20,6 +20,7 @@ from maniskill_amd.utils.building.actor_builder import ActorBuilder, PhysxMateri
 from maniskill_amd.utils.building.urdf_loader import URDFLoader
 from maniskill_amd.utils.structs.actor import Actor, Link
 from maniskill_amd.utils.structs.articulation import Articulation
+from maniskill_amd.utils.structs.pose import Pose
 from maniskill_amd.utils.structs.types import SimConfig
 
 
@@ -135,23 +136,28 @@ class ManiSkillScene:
         self.articulations[art.name] = art
         self.add_to_state_dict_registry(art)
 
-    def _set_collision_group_bit(self, actor_name, group, bit_idx, bit):
-        assert not self._gpu_sim_initialized, "collision groups must be set before the simulation is initialised"
+    def _shape_records_of(self, actor_name):
+        """the shape records an actor's collision groups live in: its registered record, or -- built for some envs only and not
+        merged yet -- its fragment"""
         for rec in self._builder.actors:
             if rec.name == actor_name:
-                for s in rec.shapes:
-                    g = list(s.collision_groups)
-                    g[group] = (g[group] & ~(1 << bit_idx)) | (int(bool(bit)) << bit_idx)
-                    s.collision_groups = tuple(g)
+                return [s for es in rec.env_shapes for s in es] + list(rec.shapes) if rec.env_shapes is not None else list(rec.shapes)
+        frag = self._fragments.get(actor_name)
+        return list(frag._fragment["shapes"]) if frag is not None else []
+
+    def _set_collision_group_bit(self, actor_name, group, bit_idx, bit):
+        assert not self._gpu_sim_initialized, "collision groups must be set before the simulation is initialised"
+        for s in self._shape_records_of(actor_name):
+            g = list(s.collision_groups)
+            g[group] = (g[group] & ~(1 << bit_idx)) | (int(bool(bit)) << bit_idx)
+            s.collision_groups = tuple(g)
 
     def _set_collision_group(self, actor_name, group, value):
         assert not self._gpu_sim_initialized, "collision groups must be set before the simulation is initialised"
-        for rec in self._builder.actors:
-            if rec.name == actor_name:
-                for s in rec.shapes:
-                    g = list(s.collision_groups)
-                    g[group] = int(value)
-                    s.collision_groups = tuple(g)
+        for s in self._shape_records_of(actor_name):
+            g = list(s.collision_groups)
+            g[group] = int(value)
+            s.collision_groups = tuple(g)
 
     def _set_scene_config(self):
         sc = self.sim_config.scene_config
@@ -168,11 +174,42 @@ class ManiSkillScene:
         """px.gpu_init + initial apply/fetch (scene.py:897-939)"""
         # actors built for a subset of the envs and never merged: each becomes a batched object over its own envs (the
         # reference keeps such an actor as a view over its sub-scenes' entities, actor_builder.py:166-260)
+        # Dynamic ones whose env sets do not overlap share a body row (first fit, in build order): the reference's scene
+        # builders create every movable object of every sub-scene as an actor of its own
+        # (utils/scene_builder/replicacad/scene_builder.py:156-185), so what counts against the simulation core's
+        # bodies-per-env is the largest object set of any ONE sub-scene, not the number of distinct objects. Each
+        # such actor stays the object its builder returned: a view of the shared row over its own envs.
+        slots = []  # [set of envs, fragments]
         for frag in list(self._fragments.values()):
-            own = Actor.merge([frag], name=frag.name)
-            frag.__dict__.update(own.__dict__)  # the object the builder returned IS the registered actor
-            self.actors[frag.name] = frag
-            self.add_to_state_dict_registry(frag)
+            envs = set(frag._fragment["scene_idxs"])
+            home = None
+            if frag.px_body_type == "dynamic":
+                home = next((sl for sl in slots if not (sl[0] & envs)), None)
+            if home is None:
+                slots.append([set(envs), [frag]])
+            else:
+                home[0] |= envs
+                home[1].append(frag)
+        for k, (_, group) in enumerate(slots):
+            if len(group) == 1:
+                frag = group[0]
+                own = Actor.merge([frag], name=frag.name)
+                frag.__dict__.update(own.__dict__)  # the object the builder returned IS the registered actor
+                self.actors[frag.name] = frag
+                self.add_to_state_dict_registry(frag)
+                continue
+            members = [(f, f.name, list(f._fragment["scene_idxs"]), f.initial_pose, [sum(sr.mass_properties()[0] for sr in f._fragment["shapes"])] * len(f._fragment["scene_idxs"]))
+                       for f in group]
+            shared = Actor.merge(group, name=f"shared-dynamic-body-{k}")
+            self.actors.pop(shared.name)
+            for f, name, envs, init, masses in members:
+                f.__dict__.update(shared.__dict__)
+                f.name, f._row_name = name, shared.name
+                f._own_idx = torch.tensor(sorted(envs), dtype=torch.long, device=self.device)
+                f.initial_pose = Pose.create(init.raw_pose[:1].expand(len(envs), 7).clone())
+                f._mass_per_env = torch.tensor(masses, dtype=torch.float32)
+                self.actors[name] = f
+                self.add_to_state_dict_registry(f)
         # the env's SimConfig goes through the module-level setters like the reference's _set_scene_config
         # (sapien_env.py:1066-1070); the model is compiled from the resulting process-wide defaults
         self._set_scene_config()
@@ -194,7 +231,7 @@ class ManiSkillScene:
         # system for `px.rigid_dynamic_components / rigid_static_components / articulation_link_components`
         comps = dict(dynamic=[], static=[], links=[])
         for name, actor in self.actors.items():
-            row = model.row_of(name)
+            row = model.row_of(getattr(actor, "_row_name", name))
             actor._body_row = row if row >= 0 else None
             comp = getattr(actor, "_px_component", None)
             if comp is None:  # merged per-env actors (Actor.merge) are registered without a builder
@@ -226,8 +263,10 @@ class ManiSkillScene:
         self._gpu_sim_initialized = True
         # per-env initial poses given at build time
         for actor in self.actors.values():
-            if actor._body_row is not None and len(actor.initial_pose) == self.num_envs and self.num_envs > 1:
+            if actor._body_row is not None and len(actor.initial_pose) == self.num_envs and self.num_envs > 1 and actor._own_idx is None:
                 actor._rows()[:, :7] = actor.initial_pose.raw_pose.to(self.device)
+            elif actor._body_row is not None and getattr(actor, "_row_name", None) is not None:  # (a row shared by the objects of different sub-scenes)
+                actor._write_rows(slice(0, 7), actor.initial_pose.raw_pose.to(self.device))
         for art in self.articulations.values():
             if len(art.initial_pose) == self.num_envs and self.num_envs > 1:
                 art.root._rows()[:, :7] = art.initial_pose.raw_pose.to(self.device)

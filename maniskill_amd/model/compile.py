@@ -423,10 +423,18 @@ class SceneModelBuilder:
         env_hulls = {}  # id(vertex array) -> (first vertex, count): per-env hulls that share a mesh are stored once
 
         def hull_of(rec):
+            """(hull vertices about their mean, that mean in the record's shape frame). The narrowphase takes a convex
+            shape's frame origin as a point INSIDE it (the generic query's interior point, the side of a mesh triangle the
+            shape is on); an asset's own origin may lie anywhere -- at the base of an object, outside a part of a convex
+            decomposition --, so the compiled shape frame is moved to the mean of the hull's vertices."""
             v = np.asarray(rec.vertices, dtype=np.float64)
             if len(v) > MAX_HULL_VERTS:
                 v = mesh.simplify_hull(v, MAX_HULL_VERTS)
-            return v
+            ctr = v.mean(axis=0)
+            return v - ctr, ctr
+
+        def recentred(frame, ctr):
+            return geom.compose(frame, geom.pose(ctr))
 
         env_meshes = {}  # id(vertex array) -> (first triangle, triangle count, root node): a mesh shared by envs / slots is stored once
 
@@ -456,9 +464,13 @@ class SceneModelBuilder:
                         # a different hull per env (include/mssim.h env_shape_param): first vertex and vertex count
                         key = id(r_e.vertices)
                         if key not in env_hulls:
-                            v = hull_of(r_e)
-                            env_hulls[key] = (len(hull_verts), len(v))
+                            v, ctr = hull_of(r_e)
+                            env_hulls[key] = (len(hull_verts), len(v), ctr)
                             hull_verts.extend(v.tolist())
+                        ctr = env_hulls[key][2]
+                        fr[-1] = recentred(f_e, ctr)
+                        c_e = c_e - ctr
+                        f_e = fr[-1]
                         pr.append([float(env_hulls[key][0]), float(env_hulls[key][1]), 0.0, float(SHAPE_CONVEX + 1)])
                     elif r_e.type == "trimesh":
                         # this env's mesh: first triangle, triangle count, root node of its BVH (a different mesh per env is fine)
@@ -485,11 +497,13 @@ class SceneModelBuilder:
             smat.append([r.static_friction, r.dynamic_friction, r.restitution, max(r.patch_radius, r.min_patch_radius)])
             if r.type == "convex":
                 if s.get("env") is not None:
-                    shull.append(list(env_hulls[id(r.vertices)]))  # (the representative's hull; every env reads its own)
+                    shull.append(list(env_hulls[id(r.vertices)][:2]))  # (the representative's hull; every env reads its own)
+                    ctr = env_hulls[id(r.vertices)][2]
                 else:
-                    v = hull_of(r)
+                    v, ctr = hull_of(r)
                     shull.append([len(hull_verts), len(v)])
                     hull_verts.extend(v.tolist())
+                sframe[-1] = recentred(sframe[-1], ctr)
             elif r.type == "trimesh":
                 # triangle mesh (static / kinematic bodies): its triangles join the soup, its 16-wide BVH the node table;
                 # shape_hull = (root node, triangle count) -- include/mssim.h MSSIM_SHAPE_TRIMESH
@@ -500,6 +514,8 @@ class SceneModelBuilder:
             else:
                 shull.append([0, 0])
             c, rad = r.bound()
+            if r.type == "convex":
+                c = c - ctr  # (centre of the bounding sphere in the recentred shape frame)
             sbound.append([*c, rad])
 
         # ---------------- candidate pairs ----------------

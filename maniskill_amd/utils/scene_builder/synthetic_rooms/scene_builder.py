@@ -6,8 +6,12 @@ is built; scenery as static TRIANGLE MESHES (one mesh for a layout's walls, one 
 of ReplicaCAD are triangle meshes too), built with `set_scene_idxs` per layout and merged into two actors, "walls" and
 "furniture", whose mesh differs from sub-scene to sub-scene (`Actor.merge`: one shape slot each, however many layouts
 there are); start arrangements of the robot (`init_configs`: base position and heading, inside the room); navigable
-positions per env. What it does not have: objects to manipulate (a free body next to the Fetch's 15 joints is more than an
-env's 16 velocity components) and articulated furniture.
+positions per env; and MOVABLE OBJECTS: every layout has two dynamic objects of its own, each a convex decomposition of
+several hulls (`add_multiple_convex_collisions_from_file` on an OBJ with one `o` group per part, as ReplicaCAD's
+dynamic objects are loaded, replicacad/scene_builder.py:156-185), built per layout with `set_scene_idxs` and -- as there
+-- left as actors of their own: `movable_objects["env-<i>_<name>"]`. Objects of different layouts never share an env, so
+the scene gives them common body rows (envs/scene.py `_setup`): ten distinct objects, two per sub-scene, two rows.
+`initialize` puts them back on their furniture. What it does not have: articulated furniture.
 
 A layout is a list of boxes (lo, hi) for its walls and another for its furniture; each list becomes one OBJ file in a
 scratch directory, loaded through `ActorBuilder.add_nonconvex_collision_from_file` like any asset.
@@ -74,6 +78,52 @@ LAYOUTS = {
 }
 
 
+# movable objects: name -> convex parts, each a box (lo, hi) or a prism ("prism", n, radius, z0, z1, centre xy) in the object frame
+OBJECTS = {
+    "bracket": [((-0.06, -0.02, 0.0), (0.06, 0.02, 0.03)), ((0.03, -0.02, 0.03), (0.06, 0.02, 0.10))],                      # an L
+    "mug": [("prism", 10, 0.04, 0.0, 0.09, (0.0, 0.0)), ((0.035, -0.012, 0.02), (0.075, 0.012, 0.07))],                      # a cup with a handle
+    "tee": [((-0.07, -0.02, 0.0), (0.07, 0.02, 0.04)), ((-0.02, 0.02, 0.0), (0.02, 0.09, 0.04))],                            # a T lying flat
+    "dumbbell": [("prism", 8, 0.04, 0.0, 0.04, (-0.07, 0.0)), ("prism", 8, 0.04, 0.0, 0.04, (0.07, 0.0)), ((-0.07, -0.012, 0.008), (0.07, 0.012, 0.032))],
+    "tray": [((-0.10, -0.07, 0.0), (0.10, 0.07, 0.012)), ((-0.10, -0.07, 0.012), (-0.088, 0.07, 0.04)), ((0.088, -0.07, 0.012), (0.10, 0.07, 0.04))],
+    "wedge": [("prism", 3, 0.07, 0.0, 0.05, (0.0, 0.0)), ((-0.02, -0.09, 0.0), (0.02, -0.03, 0.03))],
+    "post": [("prism", 6, 0.03, 0.0, 0.16, (0.0, 0.0)), ((-0.06, -0.06, 0.0), (0.06, 0.06, 0.015))],                        # a hexagonal post on a foot plate
+    "step": [((-0.08, -0.05, 0.0), (0.08, 0.05, 0.04)), ((-0.08, 0.0, 0.04), (0.08, 0.05, 0.08))],                           # two stairs
+    "block": [((-0.04, -0.04, 0.0), (0.04, 0.04, 0.08)), ((-0.015, -0.015, 0.08), (0.015, 0.015, 0.11))],                    # a cube with a knob
+    "bar": [((-0.12, -0.015, 0.0), (0.12, 0.015, 0.03)), ((-0.12, -0.04, 0.0), (-0.09, 0.04, 0.03)), ((0.09, -0.04, 0.0), (0.12, 0.04, 0.03))],  # an I
+}
+# layout -> its two objects: (object, (x, y, z) of the object frame -- on a piece of furniture or on the floor in the robot's way --, yaw)
+LAYOUT_OBJECTS = {
+    "study": [("mug", (1.05, -0.25, 0.75), 0.3), ("bracket", (0.15, 0.05, 0.0), 1.2)],
+    "corridor": [("tee", (1.85, 0.5, 0.9), 0.0), ("dumbbell", (0.6, 0.0, 0.0), 1.5708)],
+    "kitchen": [("tray", (0.6, 0.1, 0.9), 0.4), ("wedge", (-0.1, 0.35, 0.0), 2.0)],
+    "lab": [("post", (-0.6, 0.8, 0.9), 0.0), ("step", (-0.75, -0.5, 0.0), 0.2)],
+    "hall": [("block", (-0.55, 0.0, 0.0), 0.5), ("bar", (0.9, -0.35, 0.0), 1.0)],
+}
+
+
+def _write_parts_obj(path: str, parts) -> None:
+    """one `o` group per convex part: what a convex-decomposition file looks like to `add_multiple_convex_collisions_from_file`"""
+    with open(path, "w") as fh:
+        base = 1
+        for k, part in enumerate(parts):
+            fh.write(f"o part_{k}\n")
+            if part[0] == "prism":
+                _, n, rad, z0, z1, (cx, cy) = part
+                ring = [(cx + rad * np.cos(2 * np.pi * i / n), cy + rad * np.sin(2 * np.pi * i / n)) for i in range(n)]
+                verts = [(x, y, z0) for x, y in ring] + [(x, y, z1) for x, y in ring]
+                faces = [(i, (i + 1) % n, n + (i + 1) % n) for i in range(n)] + [(i, n + (i + 1) % n, n + i) for i in range(n)]
+                faces += [(0, i + 1, i) for i in range(1, n - 1)] + [(n, n + i, n + i + 1) for i in range(1, n - 1)]
+            else:
+                lo, hi = np.asarray(part[0], float), np.asarray(part[1], float)
+                verts = [tuple((hi if (i >> k2) & 1 else lo)[k2] for k2 in range(3)) for i in range(8)]
+                faces = [tuple(t) for t in _FACES]
+            for v in verts:
+                fh.write("v %.6f %.6f %.6f\n" % v)
+            for t in faces:
+                fh.write("f %d %d %d\n" % tuple(base + i for i in t))
+            base += len(verts)
+
+
 def _write_boxes_obj(path: str, boxes) -> None:
     with open(path, "w") as fh:
         for b, (lo, hi) in enumerate(boxes):
@@ -90,9 +140,10 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
     init_configs = [0, 1]  # which of a layout's start arrangements
     robot_initial_pose = sapien.Pose()
 
-    def __init__(self, env, robot_init_qpos_noise=0.02):
+    def __init__(self, env, robot_init_qpos_noise=0.02, movable_objects=True):
         super().__init__(env, robot_init_qpos_noise)
         self._mesh_dir = tempfile.mkdtemp(prefix="synthetic_rooms_")
+        self.movable = movable_objects  # False: scenery only (the round-2 scenes: 15 velocity components per env)
 
     def build(self, build_config_idxs: List[int] = None):
         n = self.env.num_envs
@@ -122,7 +173,29 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
                 b.initial_pose = sapien.Pose()
                 fragments[part].append(b.build_static(name=f"{name}_{part}"))
         for part, frags in fragments.items():
-            self.scene_objects[part] = Actor.merge(frags, name=part)
+            # (one layout in every env: its actor is no fragment, there is nothing to merge)
+            self.scene_objects[part] = frags[0] if len(frags) == 1 and frags[0]._fragment is None else Actor.merge(frags, name=part)
+        # the layouts' own movable objects (replicacad/scene_builder.py:156-185: one dynamic actor per object and layout,
+        # `movable_objects` / `scene_objects` keyed by env), with the pose `initialize` puts them back to
+        self._default_object_poses = []
+        for li, name in enumerate(self.build_configs):
+            envs = [e for e, i in enumerate(self.build_config_idxs) if i == li]
+            if not envs or not self.movable:
+                continue
+            for oname, xyz, yaw in LAYOUT_OBJECTS[name]:
+                path = os.path.join(self._mesh_dir, f"{oname}.obj")
+                if not os.path.exists(path):
+                    _write_parts_obj(path, OBJECTS[oname])
+                b = self.scene.create_actor_builder()
+                b.add_multiple_convex_collisions_from_file(path)
+                b.set_scene_idxs(envs)
+                pose = sapien.Pose(p=list(xyz), q=[float(np.cos(yaw / 2)), 0.0, 0.0, float(np.sin(yaw / 2))])
+                b.initial_pose = pose
+                actor = b.build(name=f"{name}_{oname}")
+                self._default_object_poses.append((actor, pose))
+                for e in envs:
+                    self.movable_objects[f"env-{e}_{oname}"] = actor
+                    self.scene_objects[f"env-{e}_{oname}"] = actor
         self.navigable_positions = [LAYOUTS[self.build_configs[i]][2] for i in self.build_config_idxs]
 
     def initialize(self, env_idx: torch.Tensor, init_config_idxs: List[int] = None):
@@ -140,3 +213,16 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
                 x, y, yaw = starts[int(init_config_idxs[e]) % len(starts)]
                 rest[row, 0], rest[row, 1], rest[row, 2] = x, y, yaw
         agent.reset(rest)
+        # movable objects back to where the layout has them, at rest (replicacad/scene_builder.py:303-310)
+        for actor, pose in self._default_object_poses:  # (only the rows of envs being reset are written)
+            actor.set_pose(pose)
+            actor.set_linear_velocity(torch.zeros(3, device=dev))
+            actor.set_angular_velocity(torch.zeros(3, device=dev))
+
+
+@register_scene_builder("SyntheticRoomsStatic")
+class SyntheticRoomsStaticSceneBuilder(SyntheticRoomsSceneBuilder):
+    """the same rooms without the movable objects: scenery only (15 velocity components per env with the Fetch)"""
+
+    def __init__(self, env, robot_init_qpos_noise=0.02):
+        super().__init__(env, robot_init_qpos_noise, movable_objects=False)

@@ -14,6 +14,7 @@
 // Contact convention: normal n points from shape B towards shape A (pushing A along +n separates),
 // sep is the signed gap (negative = penetration), x is the midpoint between the two surfaces.
 #pragma once
+#include "../include/mssim.h"
 #include "oracle_math.hpp"
 
 namespace orc {
@@ -131,6 +132,45 @@ inline void collide_plane(const Shape<R>& pl, const Shape<R>& b, R offset, Manif
       add(b.c + b.rot * V3<R>(R(b.verts[3 * i]), R(b.verts[3 * i + 1]), R(b.verts[3 * i + 2])), R(0));
   } else {
     add(support(b, -np), R(0));
+  }
+  // A hull lying on a face has more than 4 vertices at (nearly) the lowest depth -- the rim of a cup, the foot of a post: which
+  // four of them are "the deepest" is decided by rounding, they may all lie on one side of the rim, and the body rocks and
+  // sinks. With more than 4 of the hull's vertices within MSSIM_PATCH_SLACK of its lowest one, the four are taken by EXTENT
+  // among those -- the patch rule (include/mssim.h MSSIM_PATCH_*): the deepest, the farthest from it, the largest area on
+  // either side of that edge, every scan taking the first candidate within the tie tolerance of the extremum. Otherwise (a
+  // corner or an edge down, a box: 4 corners per face) the 4 deepest, as for every other shape.
+  if (b.type == SH_CONVEX && n > 4) {
+    R smin = seps[0];
+    for (int i = 1; i < n; i++) smin = std::min(smin, seps[i]);
+    int near_ = 0;
+    for (int i = 0; i < n; i++) near_ += seps[i] <= smin + R(MSSIM_PATCH_SLACK) ? 1 : 0;
+    if (near_ > 4) {
+      auto cand = [&](int i) { return seps[i] <= smin + R(MSSIM_PATCH_SLACK); };
+      int i0 = -1;
+      for (int i = 0; i < n && i0 < 0; i++)
+        if (seps[i] <= smin + R(MSSIM_PATCH_TIE_SEP)) i0 = i;
+      const V3<R> p0 = pts[i0];
+      auto first_near_max = [&](auto&& value, auto&& allowed, R floor_) {
+        R mx = floor_;
+        for (int i = 0; i < n; i++)
+          if (cand(i) && allowed(i)) mx = std::max(mx, value(i));
+        if (!(mx > floor_)) return -1;
+        for (int i = 0; i < n; i++)
+          if (cand(i) && allowed(i) && value(i) >= mx - R(MSSIM_PATCH_TIE_REL) * mx) return i;
+        return -1;
+      };
+      const int i1 = first_near_max([&](int i) { const V3<R> d = pts[i] - p0; return dot(d, d); }, [&](int i) { return i != i0; }, R(-1));
+      const V3<R> ed = pts[i1] - p0;
+      auto area = [&](int i) { return dot(cross(ed, pts[i] - p0), m.n); };
+      const int i2 = first_near_max([&](int i) { return std::fabs(area(i)); }, [&](int i) { return i != i0 && i != i1; }, R(-1));
+      const R sgn2 = area(i2);
+      const int i3 = first_near_max([&](int i) { return sgn2 >= 0 ? -area(i) : area(i); }, [&](int i) { return i != i0 && i != i1 && i != i2; }, R(MSSIM_PATCH_TIE_REL) * std::fabs(sgn2));
+      const int pick[4] = {i0, i1, i2, i3};
+      m.count = 0;
+      for (int k = 0; k < 4; k++)
+        if (pick[k] >= 0) { m.x[m.count] = pts[pick[k]]; m.sep[m.count] = seps[pick[k]]; m.count++; }
+      return;
+    }
   }
   keep4_deepest(n, pts, seps, m);
 }

@@ -271,13 +271,18 @@ void reduce_patches(const std::vector<RawManifold>& man, const std::vector<Conta
     for (int i = 0; i < n && i0 < 0; i++)
       if (raw[pts[i]].sep <= best + Real(MSSIM_PATCH_TIE_SEP)) i0 = i;
     const Vec p0 = raw[pts[i0]].x;
+    // a patch resting on three or more points: the ones well above them do not compete (include/mssim.h MSSIM_PATCH_SLACK)
+    int near_ = 0;
+    for (int i = 0; i < n; i++) near_ += raw[pts[i]].sep <= best + Real(MSSIM_PATCH_SLACK) ? 1 : 0;
+    const bool slack = near_ >= 3;
+    auto cand = [&](int i) { return !slack || raw[pts[i]].sep <= best + Real(MSSIM_PATCH_SLACK); };
     auto first_near_max = [&](auto&& value, auto&& allowed, Real floor_) {
       Real mx = floor_;
       for (int i = 0; i < n; i++)
-        if (allowed(i)) mx = std::max(mx, value(i));
+        if (allowed(i) && cand(i)) mx = std::max(mx, value(i));
       if (!(mx > floor_)) return -1;
       for (int i = 0; i < n; i++)
-        if (allowed(i) && value(i) >= mx - Real(MSSIM_PATCH_TIE_REL) * mx) return i;
+        if (allowed(i) && cand(i) && value(i) >= mx - Real(MSSIM_PATCH_TIE_REL) * mx) return i;
       return -1;
     };
     const int i1 = first_near_max([&](int i) { const Vec d = raw[pts[i]].x - p0; return dot(d, d); }, [&](int i) { return i != i0; }, Real(-1));
