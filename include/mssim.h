@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MSSIM_ABI_VERSION 5
+#define MSSIM_ABI_VERSION 6
 /* Free bodies: the angular velocity a substep starts from, and the one its pose is integrated with, are clamped
  * to this magnitude (rad/s) -- PhysX's default PxRigidDynamic maxAngularVelocity. Without it a thin body knocked
  * into a fast spin (a peg squeezed out of the gripper) feeds the explicitly integrated gyroscopic term until the
@@ -248,7 +248,9 @@ typedef struct mssim_model_desc {
                                     stays below it for MSSIM_WAKE_TIME seconds, without a moving partner in range, goes to
                                     sleep: zero velocity, out of the solver, its contacts with fixed bodies dropped. It wakes
                                     when an awake moving body comes into range of one of its shape pairs (cull level), when
-                                    the user writes a different pose / velocity or a force for it (apply). 0 = never sleeps */
+                                    the user writes a different pose / velocity or a force for it, or a different pose for ANY
+                                    kinematic body of its env (apply: a platform moved into a sleeping body, or away from under
+                                    it, must not leave it asleep -- PhysX wakes what a kinematic target touches). 0 = never sleeps */
 
   /* ---- per-env geometry overrides (ABI v2): same shape types in every env, different sizes /
    *      local poses / inertias -- the reference builds such actors per sub-scene and merges them
@@ -347,6 +349,12 @@ int MSSIM_FN(step)(mssim_handle h, int32_t n_substeps, void* stream);
  * `rigid_body_data` does not carry, so a caller that restores a state and wants the run that follows to depend on that
  * state alone (BaseEnv.set_state_dict, envs/sapien_env.py:1167-1179) calls this after apply. */
 int MSSIM_FN(wake_all)(mssim_handle h, void* stream);
+/* The same for the listed envs only (ABI v6): env_idx = device array of n_idx env indices (int64, what torch index tensors
+ * are; host array for the oracle). BaseEnv.reset calls it for the envs it resets (envs/sapien_env.py:776-879: a partial
+ * reset re-initialises those envs and nothing else), so that an episode never starts from the previous episode's sleep
+ * counters, manifolds and multipliers -- with PhysX the reset writes go through setGlobalPose / setLinearVelocity, which
+ * wake the body and drop its cached contacts. No host synchronisation. */
+int MSSIM_FN(wake_envs)(mssim_handle h, const int64_t* env_idx, int32_t n_idx, void* stream);
 /* px.gpu_update_articulation_kinematics() (sapien_env.py:861-865) */
 int MSSIM_FN(update_kinematics)(mssim_handle h, void* stream);
 /* px.gpu_create_contact_pair_impulse_query (scene.py:769-772): body_pairs = [n_pairs][2]
@@ -476,10 +484,10 @@ int MSSIM_FN(task_peg_outputs)(mssim_handle h, const mssim_peg_task* task, float
  * step's own FK state (world joint axes / anchors), no separate kinematics pass. */
 int MSSIM_FN(link_jacobian)(mssim_handle h, int32_t link_index, float* out, void* stream);
 
-/* Measurement aid (bench.py roofline block): when enabled, every k_solve / k_narrow launch inside
- * mssim_step is bracketed by HIP events on the SAME stream it is launched on. profile_read
- * synchronises, returns the accumulated milliseconds and launch counts since the last read
- * (index 0 = solve kernel, 1 = narrowphase kernel) and clears them. The oracle returns zeros. */
+/* Measurement aid (bench.py roofline block): when enabled, every launch of the control-step kernel (k_solve16: a whole
+ * control step, or the substeps of mssim_step) is bracketed by HIP events on the SAME stream it is launched on. profile_read
+ * synchronises, returns the accumulated milliseconds and launch counts since the last read (index 0 = the control-step
+ * kernel; index 1 is reserved and reads zero: there is no separate narrowphase kernel) and clears them. The oracle returns zeros. */
 int MSSIM_FN(profile_enable)(mssim_handle h, int32_t on);
 int MSSIM_FN(profile_read)(mssim_handle h, float* out_ms2, int32_t* out_counts2);
 /* last error message of this handle (or of create when h == NULL) */

@@ -249,10 +249,18 @@ __global__ void k_apply(DevModel M, DevState S, mssim_buffers B, unsigned what) 
       for (int c = 0; c < 13; c++) SOA(S.free_s, 13 * b + c) = r[c];
       SOA(S.free_wake, b) = MSSIM_WAKE_TIME;
     }
+    // a kinematic body given a different pose wakes the env's free bodies (include/mssim.h sleep_threshold): it may have been
+    // moved into a sleeping body, or away from under one
+    bool kin_moved = false;
     for (int k = 0; k < M.n_kin; k++) {
       const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
-      for (int c = 0; c < 7; c++) SOA(S.kin, 7 * k + c) = r[c];
+      for (int c = 0; c < 7; c++) {
+        kin_moved = kin_moved || r[c] != SOA(S.kin, 7 * k + c);
+        SOA(S.kin, 7 * k + c) = r[c];
+      }
     }
+    if (kin_moved)
+      for (int b = 0; b < M.n_free; b++) SOA(S.free_wake, b) = MSSIM_WAKE_TIME;
   }
   if ((what & MSSIM_ART_ROOT_POSE) && B.rigid_body_data && M.n_link > 0) {
     const float* r = B.rigid_body_data + 13 * (size_t)e;
@@ -1226,6 +1234,26 @@ int mssim_wake_all(mssim_handle h, void* stream) {
   if (cnt > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->S.free_wake, MSSIM_WAKE_TIME, cnt);
   HIPCHK(h, hipMemsetAsync(h->S.pcm, 0xFF, (size_t)h->N * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float), (hipStream_t)stream));  // every slot empty
   HIPCHK(h, hipMemsetAsync(h->S.warm, 0xFF, (size_t)16 * (h->M.n_pair > 0 ? h->M.n_pair : 1) * h->N * sizeof(float), (hipStream_t)stream));
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+// hidden state of the listed envs back to "fresh": every free body awake, manifold cache empty, no multipliers to start from
+__global__ void k_wake_envs(DevModel M, DevState S, const long long* __restrict__ idx, int n_idx) {
+  const int N = S.N;
+  if ((int)blockIdx.x >= n_idx) return;
+  const long long e64 = idx[blockIdx.x];
+  if (e64 < 0 || e64 >= N) return;
+  const int e = (int)e64;
+  for (int b = threadIdx.x; b < M.n_free; b += blockDim.x) SOA(S.free_wake, b) = MSSIM_WAKE_TIME;
+  for (int s = threadIdx.x; s < MSSIM_PCM_SLOTS; s += blockDim.x) reinterpret_cast<int*>(S.pcm)[((size_t)e * MSSIM_PCM_SLOTS + s) * S16_PCM_LEN] = -1;  // pair = -1: slot empty
+  for (int k = threadIdx.x; k < 4 * M.n_pair; k += blockDim.x) reinterpret_cast<int*>(S.warm)[((size_t)k * N + e) * 4 + 3] = -1;  // stamp -1
+}
+int mssim_wake_envs(mssim_handle h, const int64_t* env_idx, int32_t n_idx, void* stream) {
+  flush_deferred(h, (hipStream_t)stream);
+  if (n_idx <= 0) return 0;
+  if (!env_idx) { h->err = "wake_envs: no index array"; return 1; }
+  hipLaunchKernelGGL(k_wake_envs, dim3((unsigned)n_idx), dim3(256), 0, (hipStream_t)stream, h->M, h->S, reinterpret_cast<const long long*>(env_idx), (int)n_idx);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

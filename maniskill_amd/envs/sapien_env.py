@@ -364,6 +364,9 @@ class BaseEnv(gym.Env):
         self._run_initialize_episode(seed, env_idx, options)
         scene._set_reset_idx(None)
         scene._gpu_apply_all()
+        # the envs being reset start from their written state alone: sleep counters, cached manifolds and multipliers of the
+        # episode that ended are dropped (PhysX: the setters wake the body and its cached contacts go with the teleport)
+        scene.px.wake_envs(env_idx)
         scene.px.gpu_update_articulation_kinematics()
         scene._gpu_fetch_all()
         if self.agent is not None:

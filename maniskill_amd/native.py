@@ -13,7 +13,7 @@ import numpy as np
 from . import PACKAGE_DIR
 from .model.compile import CompiledModel
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NATIVE_LIB_PATH = os.environ.get("MSSIM_LIB") or os.path.join(PACKAGE_DIR, "_native", "libmssim.so")  # MSSIM_LIB: debug builds of the same HIP library
 
 # apply / fetch selector bits (include/mssim.h)
@@ -181,6 +181,7 @@ class NativeLib:
         f("step", C.c_int, [H, C.c_int32, C.c_void_p])
         f("update_kinematics", C.c_int, [H, C.c_void_p])
         f("wake_all", C.c_int, [H, C.c_void_p])
+        f("wake_envs", C.c_int, [H, C.c_void_p, C.c_int32, C.c_void_p])
         f("create_pair_query", C.c_int, [H, _I32P, C.c_int32, _I32P])
         f("query_pair_impulses", C.c_int, [H, C.c_int32, C.c_void_p, C.c_void_p])
         f("create_body_query", C.c_int, [H, _I32P, C.c_int32, _I32P])
@@ -207,7 +208,7 @@ class NativeLib:
 
     EXPORTS = [
         "create", "destroy", "bind_buffers", "set_timestep", "get_timestep", "apply", "fetch", "step",
-        "update_kinematics", "wake_all", "create_pair_query", "query_pair_impulses", "create_body_query",
+        "update_kinematics", "wake_all", "wake_envs", "create_pair_query", "query_pair_impulses", "create_body_query",
         "query_body_impulses", "set_drive_properties", "read_internal", "link_jacobian", "overflow_count", "set_action_map", "set_ee_action_map",
         "apply_action", "step_action", "defer_fetch", "defer_step_action", "task_pick_outputs", "task_push_outputs", "task_peg_outputs", "profile_enable",
         "profile_read", "last_error",
@@ -281,6 +282,9 @@ class NativeSim:
 
     def wake_all(self, stream=None):
         self._check(self.lib.wake_all(self.h, stream), "wake_all")
+
+    def wake_envs(self, env_idx_ptr, n_idx, stream=None):
+        self._check(self.lib.wake_envs(self.h, env_idx_ptr, n_idx, stream), "wake_envs")
 
     def update_kinematics(self, stream=None):
         self._check(self.lib.update_kinematics(self.h, stream), "update_kinematics")

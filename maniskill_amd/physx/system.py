@@ -186,6 +186,12 @@ class MssimSystem:
         """wake every sleeping free body (their sleep counters are state the buffers do not carry; include/mssim.h)"""
         self._sim.wake_all(self._stream())
 
+    def wake_envs(self, env_idx: torch.Tensor):
+        """the same for the listed envs (an int64 index tensor on the system's device): what a reset of those envs does to the
+        hidden state (include/mssim.h `wake_envs`); no host synchronisation"""
+        idx = env_idx.to(device=self.device, dtype=torch.int64).contiguous()
+        self._sim.wake_envs(idx.data_ptr(), int(idx.numel()), self._stream())
+
     # ------------------------------------------------------------------ apply / fetch
     def _apply(self, what):
         self._sim.apply(what, self._stream())

@@ -1609,7 +1609,19 @@ int mssim_ref_apply(mssim_handle h, uint32_t what, void*) {
         E.free_v[b] = Vec(r[7], r[8], r[9]);
         E.free_w[b] = Vec(r[10], r[11], r[12]);
       }
-      for (int k = 0; k < M.n_kin; k++) E.kin_pose[k] = pose7(B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e));
+      // a kinematic body given a different pose (than the f32 image the last fetch wrote) wakes the env's free bodies
+      bool kin_moved = false;
+      for (int k = 0; k < M.n_kin; k++) {
+        const float* r = B.rigid_body_data + 13 * ((size_t)(M.n_link + M.n_free + k) * N + e);
+        const Pose<Real>& P0 = E.kin_pose[k];
+        const float was[7] = {(float)P0.p.x, (float)P0.p.y, (float)P0.p.z, (float)P0.q.w, (float)P0.q.x, (float)P0.q.y, (float)P0.q.z};
+        bool changed = false;
+        for (int c = 0; c < 7; c++) changed = changed || r[c] != was[c];
+        if (!changed) continue;
+        kin_moved = true;
+        E.kin_pose[k] = pose7(r);
+      }
+      if (kin_moved) std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
     }
     if ((what & MSSIM_ART_ROOT_POSE) && B.rigid_body_data && M.n_link > 0) E.root = pose7(B.rigid_body_data + 13 * (size_t)e);
     if ((what & MSSIM_ART_QPOS) && B.art_qpos) for (int j = 0; j < n; j++) E.q[j] = B.art_qpos[(size_t)e * n + j];
@@ -1685,6 +1697,17 @@ int mssim_ref_step(mssim_handle h, int32_t n_substeps, void*) {
 
 int mssim_ref_wake_all(mssim_handle h, void*) {
   for (auto& E : h->env) {
+    std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
+    for (auto& s : E.pcm) s = PcmSlot();
+    E.warm.clear();
+  }
+  return 0;
+}
+
+int mssim_ref_wake_envs(mssim_handle h, const int64_t* env_idx, int32_t n_idx, void*) {
+  for (int i = 0; i < n_idx; i++) {
+    if (env_idx[i] < 0 || env_idx[i] >= h->N) continue;
+    EnvState& E = h->env[(size_t)env_idx[i]];
     std::fill(E.free_wake.begin(), E.free_wake.end(), Real(MSSIM_WAKE_TIME));
     for (auto& s : E.pcm) s = PcmSlot();
     E.warm.clear();

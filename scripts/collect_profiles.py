@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out")
-dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "round2")
+dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "round3")
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha
 os.makedirs(dst, exist_ok=True)
@@ -43,7 +43,8 @@ if os.path.exists(p):
     ks = json.load(open(os.path.join(dst, "pmc_summary.json")))["kernels"]
     key = [k for k in ks if k.startswith("k_solve16<")]
     if key:
-        d["roofline"]["traffic"] = ks[key[0]]["hbm_bytes_per_launch_raw"]
+        d["roofline"]["traffic"] = ks[key[0]]["hbm_bytes_per_launch"]
+        d["roofline"]["traffic_raw"] = ks[key[0]]["hbm_bytes_per_launch_raw"]
     open(os.path.join(dst, "bench.json.log"), "w").write(json.dumps(d) + "\n")
     print(d["value"], d["ms_per_step"], d["roofline"]["avg_kernel_ms"], d["roofline"]["traffic"], d["cpu_baseline"]["value"])
 for k, v in out.items():

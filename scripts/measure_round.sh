@@ -13,12 +13,14 @@ echo "== bench (default flags: 1000 steps)"; python3 bench.py > "$O"/bench.json.
 tail -c 600 "$O"/bench.json.log
 echo "== kernel stats"; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$P"/stats -- python3 "$OLDPWD"/bench.py --no-cpu-baseline > "$O"/bench_prof.log 2>&1) || exit 1
 echo "== PMC passes"
-(cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P"/pmc_fetch -- python3 "$OLDPWD"/bench.py --steps 50 --warmup 5 --no-cpu-baseline > "$O"/pmc_fetch.log 2>&1) || exit 1
-(cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P"/pmc_write -- python3 "$OLDPWD"/bench.py --steps 50 --warmup 5 --no-cpu-baseline > "$O"/pmc_write.log 2>&1) || exit 1
-(cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES --output-format csv -d "$P"/pmc_ic -- python3 "$OLDPWD"/bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$O"/pmc_ic.log 2>&1) || exit 1
-(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --output-format csv -d "$P"/pmc_sq -- python3 "$OLDPWD"/bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$O"/pmc_sq.log 2>&1) || exit 1
-python3 scripts/summarize_pmc.py "$P"/pmc_fetch "$P"/pmc_write "$O"/pmc_summary.json > /dev/null || exit 1
-python3 scripts/summarize_sq.py "$P" "$O"/sq_counters.json || exit 1
+# (the counter passes run the SAME command as the timed run -- default flags, 1000 unreset steps -- so that a launch counted is a launch timed)
+PROTO="PickCube-v1 envs=4096 control_freq=20 steps=1000 warmup=5"
+(cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P"/pmc_fetch -- python3 "$OLDPWD"/bench.py --no-cpu-baseline > "$O"/pmc_fetch.log 2>&1) || exit 1
+(cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P"/pmc_write -- python3 "$OLDPWD"/bench.py --no-cpu-baseline > "$O"/pmc_write.log 2>&1) || exit 1
+(cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES --output-format csv -d "$P"/pmc_ic -- python3 "$OLDPWD"/bench.py --no-cpu-baseline > "$O"/pmc_ic.log 2>&1) || exit 1
+(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --output-format csv -d "$P"/pmc_sq -- python3 "$OLDPWD"/bench.py --no-cpu-baseline > "$O"/pmc_sq.log 2>&1) || exit 1
+python3 scripts/summarize_pmc.py "$P"/pmc_fetch "$P"/pmc_write "$O"/pmc_summary.json "$PROTO" > /dev/null || exit 1
+python3 scripts/summarize_sq.py "$P" "$O"/sq_counters.json "$PROTO" || exit 1
 mkdir -p "$O"/stats && cp "$P"/stats/*/*kernel_stats.csv "$O"/stats/ || exit 1
 if [ "$1" != "quick" ]; then
   echo "== config matrix"; python3 scripts/bench_matrix.py > "$O"/bench_matrix.log 2>&1; grep "^{" "$O"/bench_matrix.log | cut -c1-240

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha
 
 fetch_dir, write_dir, out = sys.argv[1:4]
+protocol = sys.argv[4] if len(sys.argv) > 4 else None  # bench.protocol_of(args) of the passes (scripts/measure_round.sh)
 res = collections.defaultdict(dict)
 for d, key in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
     f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
@@ -29,5 +30,9 @@ for d, key in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
             res[k]["launches_" + key] = n
 for k, v in res.items():
     v["hbm_bytes_per_launch_raw"] = 1024.0 * (v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0))
-json.dump(dict(kernel_source_sha=kernel_source_sha(), note="raw rocprofv3 counters, KB; FETCH_SIZE may under-count reads by up to 2x on gfx950 (see MI355X_MICROARCH.md, HBM)", kernels=res), open(out, "w"), indent=1)
+    # MI355X_MICROARCH.md (HBM): gfx950 tallies a 128-byte read request as 64 bytes -- double FETCH_SIZE before comparing with a byte count
+    v["hbm_bytes_per_launch"] = 1024.0 * (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0))
+json.dump(dict(kernel_source_sha=kernel_source_sha(), protocol=protocol,
+               note="rocprofv3 counters, KB per launch; hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md, HBM), _raw = their plain sum",
+               kernels=res), open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha
 
 root, out_path = sys.argv[1:3]
+protocol = sys.argv[3] if len(sys.argv) > 3 else None  # bench.protocol_of(args) of the passes (scripts/measure_round.sh)
 out = {}
 for d in ("pmc_ic", "pmc_sq"):
     files = glob.glob(os.path.join(root, d, "*", "*_counter_collection.csv"))
@@ -20,8 +21,8 @@ for d in ("pmc_ic", "pmc_sq"):
             a[1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         out[k] = dict(launches=n, per_launch=v / n)
-json.dump(dict(kernel_source_sha=kernel_source_sha(),
-               note="rocprofv3 --pmc, control-step kernel k_solve16<9, TASK> (whole env.step), PickCube-v1 4096 envs, bench.py --steps 20 --warmup 3; "
+json.dump(dict(kernel_source_sha=kernel_source_sha(), protocol=protocol,
+               note="rocprofv3 --pmc, control-step kernel k_solve16<9, TASK> (whole env.step), bench.py with the flags of `protocol`; "
                     "two passes (instruction counts + instruction cache, SQ cycles); SQ_*_CYCLES / SQ_WAIT_* are quad-cycles summed over waves",
                counters=out), open(out_path, "w"), indent=1)
 for k, v in sorted(out.items()):

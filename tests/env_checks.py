@@ -17,7 +17,7 @@ def assert_obs_equal(a, b, atol=1e-4):
     else:
         a, b = a.cpu().float(), b.cpu().float()
         assert a.shape == b.shape
-        assert torch.allclose(a, b, atol=atol), (a - b).abs().max()
+        assert torch.allclose(a, b, atol=atol, rtol=0.0 if atol == 0.0 else 1e-5), (a - b).abs().max()
 
 
 def make(env_id, num_envs, sim_backend, **kw):
@@ -104,9 +104,11 @@ def check_seeded_reset_determinism(sim_backend):
     r1 = [env.step(a)[0].clone() for a in acts]
     o2, _ = env.reset(seed=7)
     r2 = [env.step(a)[0].clone() for a in acts]
-    assert_obs_equal(o1, o2, atol=1e-6)
+    assert_obs_equal(o1, o2, atol=0.0)
+    # (bit for bit: a reset drops the hidden state of the envs it resets -- sleep counters, cached manifolds, warm-start
+    # multipliers, `mssim_wake_envs` -- so an episode depends on its seed and actions alone)
     for a, b in zip(r1, r2):
-        assert_obs_equal(a, b, atol=1e-5)
+        assert_obs_equal(a, b, atol=0.0)
     o3, _ = env.reset(seed=8)
     assert (o3.cpu() - o1.cpu()).abs().max() > 1e-3
     env.close()

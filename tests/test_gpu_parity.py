@@ -988,3 +988,38 @@ def test_random_object_sets_on_random_terrain_stay_finite_and_close_to_the_oracl
         gone = ~present
         assert torch.allclose(st["rb"][row, gone, :7], start[gone, :7])  # an object that is not there does not move
         assert px.overflow_count() == 0
+
+
+def test_kinematic_bodies_wake_sleepers_on_hip():
+    """tests/test_oracle_contacts.py::test_kinematic_bodies_wake_sleepers on the HIP kernel (the advisor's round-2 finding:
+    oracle and kernel shared the rule, so a kernel-vs-oracle test could not see it -- this is a known-answer test)"""
+    from tests.test_oracle_contacts import check_kinematic_bodies_wake_sleepers, kinematic_platform_scene
+
+    model = kinematic_platform_scene()
+    gpu = MssimSystem(device="cuda:0")
+    gpu.gpu_init(model, 5)
+    check_kinematic_bodies_wake_sleepers(gpu, model, N=5)
+
+
+def test_wake_envs_on_hip_equals_a_fresh_system_for_those_envs():
+    """`mssim_wake_envs`: after it, the listed envs of a system with a history step exactly like the envs of a fresh system
+    given the same state (hidden state gone), the others keep theirs"""
+    model = panda_tabletop_model()
+    N = 64
+    q, qd, tq, cube = random_tabletop_state(N, 31)
+    old = MssimSystem(device="cuda:0")
+    old.gpu_init(model, N)
+    set_state(old, model, N, q, qd, tq, cube)
+    for _ in range(8):
+        old.step(5)  # a history: manifolds, multipliers, sleep counters
+    q2, qd2, tq2, cube2 = random_tabletop_state(N, 32)
+    idx = torch.arange(0, N, 2)
+    fresh = MssimSystem(device="cuda:0")
+    fresh.gpu_init(model, N)
+    set_state(fresh, model, N, q2, qd2, tq2, cube2)
+    set_state(old, model, N, q2, qd2, tq2, cube2)
+    old.wake_envs(idx.to("cuda"))
+    for px in (old, fresh):
+        px.step(5)
+    a, b = get_state(old, model, N), get_state(fresh, model, N)
+    assert torch.equal(a["q"][idx], b["q"][idx]) and torch.equal(a["rb"][:, idx], b["rb"][:, idx])

@@ -706,3 +706,69 @@ def test_triangle_search_range_narrows_before_anything_is_dropped():
     assert abs(s[2].item() - 0.02) < 2e-4 and s[7:13].abs().max() < 2e-2, s
     assert px.read_internal("contact_count", model.n_pair).sum().item() >= 4
     assert px.overflow_count() == 0
+
+
+def kinematic_platform_scene():
+    """a kinematic slab carrying a cube, a second kinematic block beside the cube, no static support anywhere near"""
+    b = SceneModelBuilder()
+    b.add_actor(ActorRecord("slab", "kinematic", [ShapeRecord("box", geom.pose(), half_size=np.array([0.2, 0.2, 0.01]))], initial_pose=geom.pose([0, 0, -0.01])))
+    b.add_actor(ActorRecord("pusher", "kinematic", [ShapeRecord("box", geom.pose(), half_size=np.array([0.02, 0.05, 0.02]))], initial_pose=geom.pose([-0.1, 0, 0.02])))
+    b.add_actor(cube_record())
+    return b.compile()
+
+
+def check_kinematic_bodies_wake_sleepers(px, model, N=1):
+    """the advisor's round-2 finding: a sleeping body must not stay asleep when a kinematic body is moved into it (it used to
+    pass straight through: the manifolds of a body that stays asleep are dropped) or away from under it (it used to float)"""
+    rc, rs, rp = model.row_of("cube"), model.row_of("slab"), model.row_of("pusher")
+    px.step(60)  # 0.6 s: the cube has been asleep on the slab for a while
+    px.gpu_fetch_all()
+    rb = px.cuda_rigid_body_data.torch().reshape(model.n_rows, N, 13)
+    assert float(px.read_internal("free_wake", 1).max()) == 0 and float(rb[rc, :, 7:].abs().max()) == 0
+    # an apply that changes nothing keeps it asleep
+    px.gpu_apply_all()
+    px.step(2)
+    assert float(px.read_internal("free_wake", 1).max()) == 0
+    # the pusher is moved 1 cm per control step towards and through the cube's place (a kinematic body has no velocity here:
+    # what it overlaps is pushed out by the penetration bias): the cube is shoved along, it is not passed through
+    for k in range(16):
+        rb[rp, :, 0] = -0.1 + 0.01 * (k + 1)
+        px.gpu_apply_all()
+        px.step(5)
+        px.gpu_fetch_all()
+    assert float(rb[rc, :, 0].min()) > 0.085, rb[rc, :, :3]               # ahead of the block, whose front face is at x = 0.08
+    assert float(rb[rc, :, 2].min()) > 0.018                              # still on the slab
+    # let it come to rest and fall asleep again, then take the slab away from under it: it wakes and falls
+    px.step(80)
+    assert float(px.read_internal("free_wake", 1).max()) == 0
+    px.gpu_fetch_all()
+    rb[rs, :, 2] = -0.5
+    px.gpu_apply_all()
+    px.step(20)  # 0.2 s of free fall: 0.196 m
+    px.gpu_fetch_all()
+    z = rb[rc, :, 2]
+    assert float(z.max()) < 0.02 - 0.15 and float(px.read_internal("free_wake", 1).min()) > 0, z
+
+
+def test_kinematic_bodies_wake_sleepers():
+    model = kinematic_platform_scene()
+    check_kinematic_bodies_wake_sleepers(ob.make_system(model, 1), model)
+
+
+def test_wake_envs_resets_the_hidden_state_of_the_listed_envs_only():
+    """`mssim_wake_envs` (what BaseEnv.reset calls for the envs it resets): sleep counters re-armed, manifold cache and
+    warm-start multipliers dropped -- for those envs, not for the others"""
+    b = SceneModelBuilder()
+    b.add_actor(table_record())
+    b.add_actor(ground_record())
+    b.add_actor(cube_record())
+    model = b.compile()
+    px = ob.make_system(model, 3)
+    px.step(60)
+    assert float(px.read_internal("free_wake", 1).max()) == 0
+    px.wake_envs(torch.tensor([1]))
+    w = px.read_internal("free_wake", 1)[0]
+    assert w[0] == 0 and w[2] == 0 and abs(float(w[1]) - 0.4) < 1e-6
+    px.step(1)
+    cnt = px.read_internal("contact_count", model.n_pair).sum(0)
+    assert cnt.tolist() == [0.0, 4.0, 0.0]  # only env 1's cube is back in the solver
