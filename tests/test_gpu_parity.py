@@ -134,6 +134,14 @@ def test_one_substep_tabletop_matches_oracle(urdf):
     r = model.row_of("cube")
     assert torch.max(torch.abs(a["rb"][r, :, :7] - b["rb"][r, :, :7])[ok]) < 2e-5
     assert torch.max(torch.abs(a["rb"][r, :, 7:] - b["rb"][r, :, 7:])[ok]) < 2e-3
+    # the envs left out above (a contact more or less than the oracle: a point on the edge of the contact offset, a manifold
+    # dropped by a rounding error in a cone test) are held to the bounds of the file header all the same: one substep cannot
+    # take an env further than 0.02 rad / 2 mm from the oracle, whatever its contacts
+    out = ~same_cnt
+    dq_all, dp_all = torch.abs(a["q"] - b["q"]).max(1).values, torch.abs(a["rb"][r, :, :3] - b["rb"][r, :, :3]).max(1).values
+    print(f"{urdf}: counts equal in {int(same_cnt.sum())} of {N} envs, {int(light.sum())} of them with <= 8 contacts; excluded {int(out.sum())}: "
+          f"|dq| {float(dq_all[out].max()) if out.any() else 0.0:.2e} |dp| {float(dp_all[out].max()) if out.any() else 0.0:.2e}; all envs: |dq| {float(dq_all.max()):.2e} |dp| {float(dp_all.max()):.2e}")
+    assert dq_all.max() < 0.02 and dp_all.max() < 2e-3
     assert gpu.overflow_count() == 0
 
 
@@ -354,9 +362,15 @@ def test_env_counts_that_do_not_fill_a_wave(N):
         set_state(px, model, N, q, qd, tq, cube)
         px.step(5)
     a, b = get_state(gpu, model, N), get_state(cpu, model, N)
-    ok = (a["cnt"] == b["cnt"]).all(0) & (b["cnt"].sum(0) <= 8)
-    assert ok.float().mean() > 0.5
-    assert torch.max(torch.abs(a["q"] - b["q"])[ok]) < 2e-4
+    same = (a["cnt"] == b["cnt"]).all(0)
+    ok = same & (b["cnt"].sum(0) <= 8)
+    dq = torch.abs(a["q"] - b["q"]).max(1).values
+    print(f"N = {N}: counts equal in {int(same.sum())} envs, {int(ok.sum())} with <= 8 contacts; |dq| those {float(dq[ok].max()) if ok.any() else 0.0:.2e}, all {float(dq.max()):.2e}")
+    # (five substeps from a random state, free-running: the seed's envs are 1 / 4 of 5 / 50 of 67 light ones, measured)
+    assert same.float().mean() >= 0.8 and ok.float().mean() >= (0.7 if N > 1 else 1.0)
+    assert torch.max(dq[ok]) < 2e-4
+    # every env, also the jammed ones and the ones a contact apart from the oracle: bounded over the control step
+    assert dq.max() < 0.02 and torch.abs(a["rb"] - b["rb"])[model.row_of("cube"), :, :3].max() < 2e-3
     assert torch.isfinite(a["rb"]).all() and torch.isfinite(a["q"]).all()
 
 
@@ -1023,3 +1037,32 @@ def test_wake_envs_on_hip_equals_a_fresh_system_for_those_envs():
         px.step(5)
     a, b = get_state(old, model, N), get_state(fresh, model, N)
     assert torch.equal(a["q"][idx], b["q"][idx]) and torch.equal(a["rb"][:, idx], b["rb"][:, idx])
+
+
+@pytest.mark.parametrize("name", ["sliding", "sticking", "stack", "pinned", "slipping"])
+def test_contact_solver_matches_direct_lcp_solution(name):
+    """the HIP kernel's contact solver against the DIRECT solution of the same complementarity problem (tests/indep_lcp.py:
+    Lemke's pivoting, no sweeps) on the canonical contact sets of tests/test_oracle_lcp.py -- an answer that does not come from
+    the oracle. One substep with 400 sweeps allowed (they stop at MSSIM_PGS_EXIT_TOLERANCE); f32: velocities to 1e-4, pair impulses to 2e-5 N s"""
+    from tests import indep_lcp
+    from tests.test_oracle_lcp import DT, compare, compile_scene, run_solver, scene
+
+    recs, bodies, contacts, names = scene(name)
+    model = compile_scene(recs)
+    N = 4
+    gpu = MssimSystem(device="cuda:0")
+    gpu.gpu_init(model, N)
+    v, by_pair = run_solver(gpu, model, names, bodies, N=N)
+    v_direct, imp_direct = indep_lcp.solve_substep(bodies, contacts, DT)
+    compare(model, names, contacts, v_direct, imp_direct, v, by_pair, tol_v=1e-4, tol_i=2e-5)
+
+
+def test_product_configuration_converges_over_substeps_on_hip():
+    from tests.test_oracle_lcp import check_product_configuration_converges_over_substeps
+
+    def make(model):
+        gpu = MssimSystem(device="cuda:0")
+        gpu.gpu_init(model, 3)
+        return gpu
+
+    check_product_configuration_converges_over_substeps(make)
