@@ -87,7 +87,9 @@ extern "C" {
  * linear and angular velocities) by more than this (m/s or rad/s): the sweeps that would follow contract further, so
  * what is left out is below the solver's own residual by orders of magnitude. solver_position_iterations is the maximum.
  * An env without contacts and without an active joint limit takes one sweep, a warm-started resting contact two or three. */
+#ifndef MSSIM_PGS_EXIT_TOLERANCE
 #define MSSIM_PGS_EXIT_TOLERANCE 1e-6f
+#endif
 /* PxSceneDesc::wakeCounterResetValue (PhysX default 20 * 0.02 s): how long the energy of a free body has to stay below
  * sleep_threshold before it is put to sleep */
 #define MSSIM_WAKE_TIME 0.4f

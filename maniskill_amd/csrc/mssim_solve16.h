@@ -2141,7 +2141,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           }
         }
         BT_T(23);
-        PH_ADD(9, __any(any_big) ? 1 : 0);
+        (void)0;
         WSYNC();
         // records in solver order: patch by patch (patches in the order of their anchors), inside a patch manifold by
         // manifold (a manifold belongs to one patch: the points of a shape pair stay together), then the patch's
@@ -2774,6 +2774,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       const bool run = !(settled && use_bias);
       if (!__any(run)) { it = M.pos_iters - 1; continue; }  // (wave-uniform) every env of the wave has settled: on to the integration
       const float v_before = v_c;
+      BT_ADD(9, 1);  // (debug builds: sweeps this wave ran, limit-row visits)
       if (run) {
       // block scalars of contact k + 1 are read from the LDS table before the dependent chain of contact k
       // (one wave per SIMD: nothing else hides the LDS latency); slot k + 1 always exists in the table
@@ -2848,6 +2849,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       // its contacts, as in PhysX); exact sequential Gauss-Seidel semantics, but only rows that change are
       // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
       // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
+#ifndef EXP_NO_LIMROWS  // (timing experiments only)
       {
         int cursor = 0;
         const float bl = use_bias ? lim_bpos : lim_bvel;
@@ -2856,6 +2858,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
           const unsigned long long bal = __ballot(cand);
           if (bal == 0ull) break;
+          BT_ADD(31, 1);
           const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
           const bool act = m16 != 0u;
           const int j = act ? (__ffs(m16) - 1) : 0;
@@ -2866,6 +2869,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           cursor = act ? j + 1 : 16;
         }
       }
+#endif
       }  // run
       if (use_bias) settled = settled || benv(fabsf(v_c - v_before) > MSSIM_PGS_EXIT_TOLERANCE) == 0u;
       PH(18);

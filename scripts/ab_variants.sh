@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 # usage: ab_variants.sh name:flags ...   e.g.  ab_variants.sh base: it1:-DEXP_ITERS=1
-for v in "base:" "$@"; do
+for v in "base:-DMSSIM_ONLY_PANDA" "$@"; do
   name=${v%%:*}; flags=${v#*:}
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-pass-failed -fno-hip-fp32-correctly-rounded-divide-sqrt $flags \
     -o maniskill_amd/_native/libmssim_exp_$name.so maniskill_amd/csrc/mssim_kernels.hip

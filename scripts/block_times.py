@@ -64,5 +64,7 @@ for rep in range(3):
     for b in order[:12]:
         print("    " + " ".join(f"{a[b, k]:8d}" for k in (8, 25, 23, 24)))
     print(f"  all blocks: uncached {a[:, 10].sum()} new slot {a[:, 11].sum()} moved {a[:, 12].sum()} empty asked again {a[:, 13].sum()} growth {a[:, 15].sum()} refresh only {a[:, 16].sum()}")
+    print(f"  sweeps run per wave and launch (of {5 * 17} possible): mean {a[:, 9].mean():.1f} p50 {np.median(a[:, 9]):.0f} max {a[:, 9].max()}; limit-row visits: mean {a[:, 31].mean():.1f} p50 {np.median(a[:, 31]):.0f} max {a[:, 31].max()}; "
+          f"of the 12 last blocks: sweeps {[int(a[b, 9]) for b in order[:12]]} limit visits {[int(a[b, 31]) for b in order[:12]]}")
     c = np.corrcoef(dur, a[:, 29])[0, 1]
     print(f"  correlation duration ~ max-env contacts: {c:.2f}; mean duration by MPR rounds: " + ", ".join(f"{k}: {dur[a[:, 14] == k].mean():.0f} us (n={int((a[:, 14] == k).sum())})" for k in np.unique(a[:, 14])[:8]))
