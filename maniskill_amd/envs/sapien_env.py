@@ -366,7 +366,10 @@ class BaseEnv(gym.Env):
         scene._gpu_apply_all()
         # the envs being reset start from their written state alone: sleep counters, cached manifolds and multipliers of the
         # episode that ended are dropped (PhysX: the setters wake the body and its cached contacts go with the teleport)
-        scene.px.wake_envs(env_idx)
+        if partial:
+            scene.px.wake_envs(env_idx)
+        else:
+            scene.px.wake_all()  # (every env: three fills instead of a strided write per env and pair)
         scene.px.gpu_update_articulation_kinematics()
         scene._gpu_fetch_all()
         if self.agent is not None:
