@@ -858,11 +858,12 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   if (d->n_dof > MSSIM_MAX_DOF || d->n_free > MSSIM_MAX_FREE) { g_create_error = "model exceeds MSSIM_MAX_DOF / MSSIM_MAX_FREE"; return 3; }
   // the control-step kernel keeps an env on one or two 16-lane rows (one velocity component per lane: the joints in row 0, the free
   // bodies behind them or, when that is more than 16 components, in a row of their own) and its scene in fixed LDS tables
-  const int rows_per_env = d->n_dof + 6 * d->n_free > S16_LANES ? 2 : 1;
-  if (d->n_dof > S16_LANES || d->n_free > S16_MAX_FREE || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE_(rows_per_env) || d->n_pair > 56 * 16) {
+  // (rows per env: 1 while joints and free bodies fit 16 lanes together; else the joints in row 0 and two free bodies per further row)
+  const int rows_per_env = d->n_dof + 6 * d->n_free <= S16_LANES ? 1 : (d->n_free <= 2 ? 2 : 4);
+  if (d->n_dof > S16_LANES || d->n_free > S16_MAX_FREE_(4) || d->n_kin > S16_MAX_KIN || d->n_shape > S16_MAX_SHAPE_(rows_per_env) || d->n_pair > 56 * 16) {
     char msg[320];
     snprintf(msg, sizeof msg, "model exceeds the control-step kernel's tables: %d joints (max %d), %d free bodies (max %d), %d kinematic bodies (max %d), "
-             "%d shapes (max %d with %d velocity components), %d candidate pairs (max %d)", d->n_dof, S16_LANES, d->n_free, S16_MAX_FREE, d->n_kin, S16_MAX_KIN, d->n_shape,
+             "%d shapes (max %d with %d velocity components), %d candidate pairs (max %d)", d->n_dof, S16_LANES, d->n_free, S16_MAX_FREE_(4), d->n_kin, S16_MAX_KIN, d->n_shape,
              S16_MAX_SHAPE_(rows_per_env), d->n_dof + 6 * d->n_free, d->n_pair, 56 * 16);
     g_create_error = msg;
     return 9;
@@ -1294,6 +1295,13 @@ static void launch_control_step(mssim_handle h, const DevState& S, int n_substep
   // (timing experiments, scripts/ab_variants.sh: only the benchmark's instances are compiled -- a fifth of the build time)
   hipLaunchKernelGGL((k_solve16<9, TASK>), env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK), block, 0, st, h->M, S, n_substeps);
 #else
+  if (h->rows_per_env == 4) {  // three to six free bodies: four 16-lane rows (a whole wave) per env, 4 envs per block; the generic-topology instances
+    const dim3 grid4 = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK / 4);
+    if (h->has_tri) hipLaunchKernelGGL((k_solve16<0, 0, true, 4>), grid4, block, 0, st, h->M, S, n_substeps);
+    else hipLaunchKernelGGL((k_solve16<0, 0, false, 4>), grid4, block, 0, st, h->M, S, n_substeps);
+    prof_mark(h, 0, st);
+    return;
+  }
   if (h->rows_per_env == 2) {  // more than 16 velocity components: two 16-lane rows per env, 8 envs per block
     const dim3 grid2 = env_grid(h->N, S16_WAVES * S16_ENVS_PER_BLOCK / 2);
     if (h->has_tri) {

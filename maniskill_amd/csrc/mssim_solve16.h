@@ -43,19 +43,23 @@
 #define S16_ENVS_PER_BLOCK 4
 #endif
 // per-env LDS layout (floats)
-#define S16_COM 0      // [2][3] free-body centres of mass | [8..23] ancestor-or-self masks of the dofs
-#define S16_ANC 8
+#define S16_COM_(nr) ((nr) == 4 ? 300 : 0)  // [S16_MAX_FREE][3] free-body centres of mass (NR = 4: behind the longer pose table)
+#define S16_COM S16_COM_(NR)
+#define S16_ANC 8      // [8..23] ancestor-or-self masks of the dofs
 #define S16_VEC 32     // 4 x [16] scratch vectors
-#define S16_PT 96      // pose table [25][7]: root | 16 links | 2 free | 6 kinematic
+#define S16_PT 96      // pose table [23 + S16_MAX_FREE][7]: root | 16 links | the free bodies | 6 kinematic
 #define S16_PT_LINK 1
 #define S16_PT_FREE 17
-#define S16_PT_KIN 19
-#define S16_MAX_FREE 2
+#define S16_MAX_FREE_(nr) ((nr) == 4 ? 6 : 2)  // free bodies per env: two per 16-lane row that holds free bodies
+#define S16_MAX_FREE S16_MAX_FREE_(NR)
+#define S16_PT_KIN_(nr) (S16_PT_FREE + S16_MAX_FREE_(nr))
+#define S16_PT_KIN S16_PT_KIN_(NR)
 #define S16_MAX_KIN 6
-#define S16_MAX_SHAPE_(nr) ((nr) > 1 ? 48 : 28)  // shapes per model: a lane builds the world-table entries of two (NR = 2: all 32 lanes of the env)
+#define S16_MAX_SHAPE_(nr) ((nr) == 4 ? 64 : ((nr) > 1 ? 48 : 28))  // shapes per model: a lane builds the world-table entries of two (NR > 1: all lanes of the env)
 #define S16_MAX_HIT 64
 #define S16_BP (S16_PT + 7 * S16_PT_LINK)  // link poses
-#define S16_U 272      // union: dynamics staging | solver rows | narrowphase scratch
+#define S16_U_(nr) ((nr) == 4 ? 320 : 272)  // union: dynamics staging | solver rows | narrowphase scratch
+#define S16_U S16_U_(NR)
 #define S16_S (S16_U)          // [16][6]
 #define S16_V (S16_U + 96)     // [16][6]
 #define S16_T (S16_U + 192)    // [16][6]
@@ -71,10 +75,13 @@
 // names read its template parameter NR)
 #define S16_JWLEN_(nr) (96 * (nr))  // 3 x (J[16 nr] W[16 nr]) of one contact
 #define S16_JW (S16_CS + 16 * MAXC)                     // [S16_LDSC][S16_JWLEN]
-#define S16_REC_(nr) (S16_JW + S16_JWLEN_(nr) * S16_LDSC)  // contact records [MAXC][S16_REC_LEN]
-#define S16_REC_LEN_(nr) ((nr) > 1 ? 12 : 10)  // n(3) x(3) sep pair lane-masks of row 0 (A | B << 16) mu [lane-masks of row 1, -]
+#define S16_REC_(nr) (S16_U_(nr) + 256 + 16 * MAXC + S16_JWLEN_(nr) * S16_LDSC)  // contact records [MAXC][S16_REC_LEN]
+#define S16_REC_LEN_(nr) ((nr) == 4 ? 14 : ((nr) > 1 ? 12 : 10))  // n(3) x(3) sep pair lane-masks of row 0 (A | B << 16) mu [lane-masks of rows 1.., -]
 // per env: NR = 1: 2552 floats (== 24 mod 32 banks); NR = 2: 3344 floats (== 16 mod 32: the wave's two envs on different banks)
-#define S16_ENV_FLOATS_(nr) (S16_REC_(nr) + S16_REC_LEN_(nr) * MAXC + ((nr) > 1 ? 16 : 0))
+// (NR = 4: behind the records, box-box scratch of the three rows that are not the env's own: 3 x (24 polygon words + 20 result words))
+#define S16_XSCR_(nr) (S16_REC_(nr) + S16_REC_LEN_(nr) * MAXC)
+#define S16_XSCR S16_XSCR_(NR)
+#define S16_ENV_FLOATS_(nr) (S16_REC_(nr) + S16_REC_LEN_(nr) * MAXC + ((nr) == 2 ? 16 : ((nr) == 4 ? 136 : 0)))
 #define S16_ROWLEN_(nr) (32 * (nr))
 #define S16_ROWS_GLB (3 * (MAXC - S16_REGC - S16_LDSC))  // global scratch rows per env (x S16_ROWLEN floats)
 #define S16_JWLEN S16_JWLEN_(NR)
@@ -85,7 +92,7 @@
 // narrowphase scratch, overlays the union below the contact records
 #define S16_SHP 20                // floats per entry: pose7 param3 centre3 radius packed mu half3 torsional-radius
 #define S16_NP_SHP (S16_U)        // [S16_MAX_SHAPE][20] world shape table
-#define S16_NP_B_(nr) (S16_U + S16_SHP * S16_MAX_SHAPE_(nr))  // what follows the shape table
+#define S16_NP_B_(nr) (S16_U_(nr) + S16_SHP * S16_MAX_SHAPE_(nr))  // what follows the shape table
 #define S16_NP_B S16_NP_B_(NR)
 #define S16_MAX_SHAPE S16_MAX_SHAPE_(NR)
 #define S16_NP_HIT (S16_NP_B)        // [64] surviving pairs: pair | sa << 16 | sb << 24
@@ -109,8 +116,9 @@
 #define S16_MAX_BBC 16            // box-box pairs per wave up to which they are worked on by 16-lane groups
 #define S16_MAX_MPR 64            // (= every hit: an arm folded onto itself and jammed into the table has 20+ hull pairs in range)
 static_assert(860 + 20 <= 896, "narrowphase staging exceeds the scratch area");
-static_assert(S16_NP_B_(1) + 1136 + 16 <= S16_REC_(1) && S16_NP_B_(2) + 1136 + 16 <= S16_REC_(2), "narrowphase lists run into the contact records");
-static_assert((S16_NP_B_(1) + 192 + 192) % 4 == 0 && (S16_NP_B_(2) + 192 + 192) % 4 == 0, "point pool: 16-byte aligned");
+static_assert(S16_NP_B_(1) + 1136 + 16 <= S16_REC_(1) && S16_NP_B_(2) + 1136 + 16 <= S16_REC_(2) && S16_NP_B_(4) + 1136 + 16 <= S16_REC_(4), "narrowphase lists run into the contact records");
+static_assert((S16_NP_B_(1) + 192 + 192) % 4 == 0 && (S16_NP_B_(2) + 192 + 192) % 4 == 0 && (S16_NP_B_(4) + 192 + 192) % 4 == 0, "point pool: 16-byte aligned");
+static_assert(S16_PT + 7 * (S16_PT_KIN_(1) + S16_MAX_KIN) <= S16_U_(1) && S16_PT + 7 * (S16_PT_KIN_(4) + S16_MAX_KIN) <= S16_COM_(4) && S16_COM_(4) + 18 <= S16_U_(4), "pose table runs into the union");
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
 static_assert(MSSIM_MAX_TRI_TASKS + MSSIM_MAX_TRI_HITS <= 792 - 704, "triangle task list + candidates exceed the scratch they borrow (BSCR + KEEP)");
 
@@ -223,9 +231,14 @@ MS_DEV float xrow_sum(float x) {
   if constexpr (NR == 1) {
     return x;
   } else {
-    static_assert(NR == 2, "rows per env");
+    static_assert(NR == 2 || NR == 4, "rows per env");
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    if constexpr (NR == 4) {  // (and the two halves of the wave: v_permlane32_swap exchanges the upper half of one operand with the lower half of the other)
+      const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+      s = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+    }
+    return s;
   }
 }
 template <int NR>
@@ -551,6 +564,7 @@ MS_DEV void collide_plane_hull_coop(const shape_t& pl, const shape_t& b, float o
   }
 }
 // pose-table slot of a body: -1 = fixed in the env frame
+template <int NR>
 MS_DEV int pose_slot(int kind, int index) {
   if (kind == MSSIM_BODY_ART) return index < 0 ? 0 : S16_PT_LINK + index;
   if (kind == MSSIM_BODY_FREE) return S16_PT_FREE + index;
@@ -559,14 +573,15 @@ MS_DEV int pose_slot(int kind, int index) {
 }
 // lanes (velocity components) that move with the body in pose-table slot `sl`: the dofs on the path
 // to a link, the 6 components of a free body, nothing for fixed / kinematic bodies
-// (`row`: which 16-lane row of the env the mask is for. NR = 1: joints, then the free bodies, all in row 0; NR = 2: the joints
-// in row 0, the free bodies from lane 0 of row 1)
+// (`row`: which 16-lane row of the env the mask is for. NR = 1: joints, then the free bodies, all in row 0; NR > 1: the joints
+// in row 0, free bodies 2k and 2k + 1 from lane 0 of row 1 + k)
 template <int NR>
 MS_DEV unsigned slot_lane_mask(const float* L, int sl, int n, int row) {
   if (sl >= S16_PT_LINK && sl < S16_PT_FREE) return row == 0 ? reinterpret_cast<const unsigned*>(L)[S16_ANC + sl - S16_PT_LINK] : 0u;
   if (sl >= S16_PT_FREE && sl < S16_PT_KIN) {
-    if constexpr (NR == 1) return 0x3Fu << (n + 6 * (sl - S16_PT_FREE));
-    else return row == 1 ? 0x3Fu << (6 * (sl - S16_PT_FREE)) : 0u;
+    const int b = sl - S16_PT_FREE;
+    if constexpr (NR == 1) return 0x3Fu << (n + 6 * b);
+    else return row == 1 + (b >> 1) ? 0x3Fu << (6 * (b & 1)) : 0u;
   }
   return 0u;
 }
@@ -671,7 +686,7 @@ struct SupCoop16 {
 template <int NDOF = 0, int TASK = 0, bool TRI = false, int NR = 1>
 __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState S, int n_sub) {
   constexpr bool FUSED = true;  // (the per-substep variant fed by a separate narrowphase kernel is gone)
-  static_assert(NR == 1 || (NR == 2 && TASK == 0), "rows per env: 1 or 2; the task tails are compiled for one row only");
+  static_assert(NR == 1 || ((NR == 2 || NR == 4) && TASK == 0), "rows per env: 1, 2 or 4; the task tails are compiled for one row only");
   constexpr int EPW = 4 / NR;                 // envs per wave
   constexpr int BLK_ENVS = S16_WAVES * EPW;   // envs per block
   constexpr int BLK_GRPS = S16_WAVES * 4;     // 16-lane groups per block: who takes the tasks of the shared narrowphase stages
@@ -702,22 +717,25 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
   const float inv_dt = rcp_f(dt);
   const f3 g3 = f3{M.gx, M.gy, M.gz};
   const bool art = lead && c < n;
-  // lane role among the free-body components (NR = 1: behind the joints in the same row; NR = 2: row 1 from lane 0)
-  const int fc = NR == 1 ? c - n : (r == 1 ? c : -1);
-  const bool freel = fc >= 0 && fc < 6 * nf;
-  const int fb_id = freel ? fc / 6 : 0;
+  // lane role among the free-body components (NR = 1: behind the joints in the same row; NR > 1: rows 1.. from lane 0, two bodies
+  // per row). fb0 = first free body of this lane's row, nfr = how many it holds
+  const int fc = NR == 1 ? c - n : (r >= 1 ? c : -1);
+  const bool frow = NR == 1 || r >= 1;  // a row that holds free bodies' lanes
+  const int fb0 = (NR == 4 && r >= 1) ? 2 * (r - 1) : 0;
+  const int nfr = frow ? min(max(nf - fb0, 0), 2) : 0;
+  const bool freel = fc >= 0 && fc < 6 * nfr;
+  const int fb_id = fb0 + (freel ? fc / 6 : 0);
   const int fk = freel ? fc % 6 : 0;  // 0..2 linear xyz, 3..5 angular xyz
   const int fcol0 = NR == 1 ? n : 0;  // this row's first free-body column
-  const int fbase = fcol0 + 6 * fb_id;
-  const bool frow = NR == 1 || r == 1;  // the row that holds the free bodies' lanes
+  const int fbase = fcol0 + 6 * (fb_id - fb0);
   // ballot over the lanes of this env / broadcast from its lane `j` (j < 16: a lane of row 0)
-  auto benv = [&](bool v) __attribute__((always_inline)) -> unsigned {
+  auto benv = [&](bool v) __attribute__((always_inline)) -> unsigned {  // (nonzero iff any lane of the env says so)
     if constexpr (NR == 1) return (unsigned)(__ballot(v) >> (16 * g)) & 0xFFFFu;
-    else return (unsigned)(__ballot(v) >> (32 * ew));
+    else if constexpr (NR == 2) return (unsigned)(__ballot(v) >> (32 * ew));
+    else return __ballot(v) != 0ull ? 1u : 0u;
   };
   auto env_bci = [&](int x, int j) __attribute__((always_inline)) -> int {
-    if constexpr (NR == 1) return __shfl(x, j, 16);
-    else return __shfl(x, j, 32);
+    return __shfl(x, j, 16 * NR);
   };
   (void)cl; (void)grp; (void)benv; (void)env_bci; (void)frow;
 
@@ -793,6 +811,19 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       if (!(in0[0] > 0.f)) { fwake[b] = 0.f; fcalm[b] = true; }  // mass 0: the body does not exist in this env -- never awake
     }
   }
+  // (body index known at run time: a select chain over the registers)
+  auto fw_at = [&](int b) __attribute__((always_inline)) {
+    float w = fwake[0];
+#pragma unroll
+    for (int k = 1; k < S16_MAX_FREE; k++) w = b == k ? fwake[k] : w;
+    return w;
+  };
+  auto fc_at = [&](int b) __attribute__((always_inline)) {
+    bool w = fcalm[0];
+#pragma unroll
+    for (int k = 1; k < S16_MAX_FREE; k++) w = b == k ? fcalm[k] : w;
+    return w;
+  };
   // pose table: root, links, free bodies, kinematic bodies
   if (lead) {
     reinterpret_cast<unsigned*>(L)[S16_ANC + c] = (art ? M.dof_anc[c] : 0u) | self_c;
@@ -820,7 +851,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     BT_T0;
     int nc = 0;
     unsigned fdist = 0u;  // free bodies touched by a disturber in this substep (sleep counters)
+#ifdef EXP_NO_NP
+    if (false) {
+#else
     if (FUSED) {
+#endif
       // shape-local data of shapes c and c + 16 (two rows per env: cl and cl + 32) and the cull pairs of this lane (model constants,
       // fetched per substep rather than held in registers over the whole step)
       pose_t shF[2];
@@ -868,7 +903,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             }
             shMu[k] = r[17];
             shTr[k] = r[22];
-            shSlot[k] = pose_slot(__float_as_int(r[19]), __float_as_int(r[20]));
+            shSlot[k] = pose_slot<NR>(__float_as_int(r[19]), __float_as_int(r[20]));
             shPk[k] = (unsigned)ty | ((unsigned)hull_count << 3) | ((unsigned)(shSlot[k] + 1) << 10) | ((unsigned)hull_first << 15);
           }
         }
@@ -926,7 +961,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int s1a = (int)((__float_as_uint(ta_[14]) >> 10) & 31u), s1b = (int)((__float_as_uint(tb_[14]) >> 10) & 31u);
           auto inactive = [&](int s1) {
             const int b = s1 - 1 - S16_PT_FREE;
-            return s1 == 0 || (b >= 0 && b < S16_MAX_FREE && (b == 0 ? fwake[0] : fwake[1]) <= 0.f);
+            return s1 == 0 || (b >= 0 && b < S16_MAX_FREE && fw_at(b) <= 0.f);
           };
           const int tb = (int)(__float_as_uint(tb_[14]) & 7u);
           surv = !cull && !(inactive(s1a) && inactive(s1b)) && ta != SH_NONE && tb != SH_NONE;  // (SH_NONE: no shape in this env's slot)
@@ -939,8 +974,13 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         nh += __popc(m16);
         WSYNC();
       };
+#ifdef EXP_CULL_ROUNDS  // (timing experiments only: wrong contacts)
+      const int n_pair_cull = M.n_pair < 16 * EXP_CULL_ROUNDS ? M.n_pair : 16 * EXP_CULL_ROUNDS;
+#else
+      const int n_pair_cull = M.n_pair;
+#endif
 #pragma unroll 1
-      for (int base = 0; base < M.n_pair; base += 16) {
+      for (int base = 0; base < n_pair_cull; base += 16) {
         const int p = base + c;
         cull_round(p, (lead && p < M.n_pair) ? reinterpret_cast<const int*>(L + S16_NP_SCR)[p] : -1);  // (the lanes of an env's other rows idle through its own bookkeeping)
       }
@@ -1830,6 +1870,9 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         int TBb = 0, TPb = 0;
 #pragma unroll
         for (int j = 0; j < BLK_ENVS; j++) { TBb += blk_nbl[j]; TPb += blk_npl[j]; }
+#ifdef EXP_NO_STAGE_C
+        TBb = 0; TPb = 0;
+#endif
         for (int t = grp; t < TBb + TPb; t += BLK_GRPS) {
           const bool ph = t >= TBb;  // (group-uniform) a (plane, hull) pair
           int ge = 0, k = ph ? t - TBb : t;
@@ -1845,10 +1888,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int pk = reinterpret_cast<const int*>(Lg)[S16_NP_HIT + idx];
           const shape_t A = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF));
           const shape_t B = shape_from_table(M, Lg + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF));
-          // (scratch of this GROUP: the env's other row borrows the body-pair keys' words, idle until the patch pass)
-          float* out = lead ? L + S16_NP_BOUT : L + S16_NP_KEY + 24;
+          // (scratch of this GROUP: with two rows the env's other row borrows the body-pair keys' words, idle until the patch pass;
+          // with four the three other rows have words of their own behind the records)
+          float* const xscr = NR == 4 ? L + S16_XSCR + 44 * (r - 1) : L + S16_NP_KEY;
+          float* out = lead ? L + S16_NP_BOUT : xscr + 24;
           if (ph) collide_plane_hull_coop(A, B, M.contact_offset, out, c, g);
-          else collide_box_box_coop(A, B, M.contact_offset, lead ? L + S16_NP_BSCR : L + S16_NP_KEY, out, c, g);
+          else collide_box_box_coop(A, B, M.contact_offset, lead ? L + S16_NP_BSCR : xscr, out, c, g);
           const int cnt = __float_as_int(out[0]);  // (one wave: the LDS writes of the group's lanes are complete)
           if (cnt > 0) {
             int off = 0;
@@ -1899,7 +1944,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           auto disturber = [&](int slot1) {
             if (slot1 > S16_PT_LINK && slot1 <= S16_PT_FREE) return true;  // pose slots 1..16: articulation links
             const int b = free_of(slot1);
-            return b >= 0 && (b == 0 ? (fwake[0] > 0.f && !fcalm[0]) : (fwake[1] > 0.f && !fcalm[1]));
+            return b >= 0 && fw_at(b) > 0.f && !fc_at(b);
           };
           for (int i = c; i < nh; i += 16) {
             if (cnt_[i] <= 0) continue;
@@ -1918,7 +1963,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           for (int i = c; i < nh; i += 16) {
             const int ky = key_[i];
             const int ba = free_of(ky & 31), bb = free_of((ky >> 8) & 31);
-            const bool sa_ = ba >= 0 && (ba == 0 ? fwake[0] : fwake[1]) <= 0.f, sb_ = bb >= 0 && (bb == 0 ? fwake[0] : fwake[1]) <= 0.f;
+            const bool sa_ = ba >= 0 && fw_at(ba) <= 0.f, sb_ = bb >= 0 && fw_at(bb) <= 0.f;
             if (sa_ || sb_) cnt_[i] = 0;
           }
           WSYNC();
@@ -2206,6 +2251,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int slA = (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sa + 14]) >> 10) & 31u) - 1, slB = (int)((__float_as_uint(L[S16_NP_SHP + S16_SHP * sb + 14]) >> 10) & 31u) - 1;
           const int bodies = (int)(slot_lane_mask<NR>(L, slA, n, 0) | (slot_lane_mask<NR>(L, slB, n, 0) << 16));
           const int bodies1 = NR > 1 ? (int)(slot_lane_mask<NR>(L, slA, n, 1) | (slot_lane_mask<NR>(L, slB, n, 1) << 16)) : 0;
+          const int bodies2 = NR > 2 ? (int)(slot_lane_mask<NR>(L, slA, n, 2) | (slot_lane_mask<NR>(L, slB, n, 2) << 16)) : 0;
+          const int bodies3 = NR > 2 ? (int)(slot_lane_mask<NR>(L, slA, n, 3) | (slot_lane_mask<NR>(L, slB, n, 3) << 16)) : 0;
           const f3 nn = f3{L[S16_NP_HN + 3 * i], L[S16_NP_HN + 3 * i + 1], L[S16_NP_HN + 3 * i + 2]};
           const int of = off_[i];
           for (int q = 0; q < 4; q++) {
@@ -2221,6 +2268,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
               r[8] = __int_as_float(bodies);
               r[9] = mu;
               if constexpr (NR > 1) r[10] = __int_as_float(bodies1);
+              if constexpr (NR > 2) { r[11] = __int_as_float(bodies2); r[12] = __int_as_float(bodies3); }
             }
             off++;
           }
@@ -2232,6 +2280,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
             r[8] = __int_as_float(bodies);
             r[9] = mu * my_tr;
             if constexpr (NR > 1) r[10] = __int_as_float(bodies1);
+            if constexpr (NR > 2) { r[11] = __int_as_float(bodies2); r[12] = __int_as_float(bodies3); }
           }
         }
         if (tot > MAXC) { if (live && c == 0) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_CONTACTS); tot = MAXC; }
@@ -2278,12 +2327,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       grav_c = __float_as_int(r[30]) != 0;
       qt_c = SOA(S.qt, c); qdt_c = SOA(S.qdt, c); qf_c = SOA(S.qf, c);
     }
-    float fin[S16_MAX_FREE][10];
+    float fin[2][10];  // (the inertial parameters of the free bodies of this lane's row)
 #pragma unroll
-    for (int b = 0; b < S16_MAX_FREE; b++) {
+    for (int b = 0; b < 2; b++) {
 #pragma unroll
       for (int k = 0; k < 10; k++) fin[b][k] = 0.f;
-      if (b < nf) free_inertial_of(M, N, b, e, fin[b]);
+      if (b < nfr) free_inertial_of(M, N, fb0 + b, e, fin[b]);
     }
 
     // ================================================================ dynamics: RNEA bias + CRBA
@@ -2486,16 +2535,17 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     v_c = art ? vstar : 0.f;
     f3 mycom = f3{0, 0, 0};
 #pragma unroll
-    for (int b = 0; b < S16_MAX_FREE; b++) {
-      if (b >= nf) break;
-      const float* in = fin[b];
+    for (int bl = 0; bl < 2; bl++) {  // (the free bodies of this lane's row; a row without any skips the loop)
+      if (bl >= nfr) break;
+      const int b = fb0 + bl;
+      const float* in = fin[bl];
       const pose_t P = lds_pose(L + S16_PT + 7 * (S16_PT_FREE + b));
       m3 R = qmat(P.q);
       s3 Iw = srotate(R, s3{in[4], in[5], in[6], in[7], in[8], in[9]});
       s3 Ii = sinverse(Iw);
       const float minv = rcp_f(in[0]);
       f3 com = P.p + mmulv(R, f3{in[1], in[2], in[3]});
-      const int base = fcol0 + 6 * b;  // (the free bodies' row reads its own lanes; what another row makes of this loop goes nowhere)
+      const int base = fcol0 + 6 * bl;
       f3 v0 = f3{gbc(vfree_c, base), gbc(vfree_c, base + 1), gbc(vfree_c, base + 2)};
       f3 w0 = clamp_norm(f3{gbc(vfree_c, base + 3), gbc(vfree_c, base + 4), gbc(vfree_c, base + 5)}, MSSIM_MAX_ANGULAR_VELOCITY);
       f3 acc = f3{gbc(fforce_c, base), gbc(fforce_c, base + 1), gbc(fforce_c, base + 2)} * minv;
@@ -2505,8 +2555,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       const float ld = 1.f - dt * M.free_damping[2 * b], ad = 1.f - dt * M.free_damping[2 * b + 1];
       vv = vv * (ld > 0.f ? ld : 0.f);
       ww = ww * (ad > 0.f ? ad : 0.f);
-      if (c == 0 && frow) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
-      const bool asleep_b = fwake[b] <= 0.f;  // at rest and out of the solver (none of its manifolds was kept)
+      if (c == 0) { L[S16_COM + 3 * b] = com.x; L[S16_COM + 3 * b + 1] = com.y; L[S16_COM + 3 * b + 2] = com.z; }
+      const bool asleep_b = fw_at(b) <= 0.f;  // at rest and out of the solver (none of its manifolds was kept)
       if (freel && fb_id == b) {
         mycom = com;
         v_c = asleep_b ? 0.f : (fk < 3 ? comp(vv, fk) : comp(ww, fk - 3));
@@ -2578,7 +2628,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       const bool tors = ck && ((pw >> 30) & 1);  // torsional friction block of the patch that ends just before it
       const int p = pw & 0xFFFF;
       const bool first = i == 0 || ((__float_as_int(L[S16_REC + S16_REC_LEN * (i - 1) + 7]) ^ pw) & 0x3F0000) != 0;  // first block of its patch
-      const int bodies = __float_as_int((NR > 1 && !lead) ? rec[10] : rec[8]);  // (lane masks of this lane's row)
+      const int bodies = __float_as_int((NR > 1 && !lead) ? rec[9 + r] : rec[8]);  // (lane masks of this lane's row)
       const float mu = tors ? 0.f : rec[9];
       // (one cross product and one normalisation: the helper axis is selected, not the result)
       const bool use_x = fabsf(nrm.x) < 0.57735f;
@@ -2743,10 +2793,11 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       if (it == M.pos_iters) {
         q_c += dt * fminf(fmaxf(v_c, -MSSIM_MAX_JOINT_VELOCITY), MSSIM_MAX_JOINT_VELOCITY);
 #pragma unroll
-        for (int b = 0; b < S16_MAX_FREE; b++) {
-          if (b >= nf) break;
-          const float* in = fin[b];
-          const int base = fcol0 + 6 * b;
+        for (int bl = 0; bl < 2; bl++) {
+          if (bl >= nfr) break;
+          const int b = fb0 + bl;
+          const float* in = fin[bl];
+          const int base = fcol0 + 6 * bl;
           f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)};
           f3 ww = clamp_norm(f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)}, MSSIM_MAX_ANGULAR_VELOCITY);
           f3 com = f3{L[S16_COM + 3 * b], L[S16_COM + 3 * b + 1], L[S16_COM + 3 * b + 2]} + vv * dt;
@@ -2756,12 +2807,12 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           qq = qnormalized(q4{qq.w + 0.5f * dt * dq.w, qq.x + 0.5f * dt * dq.x, qq.y + 0.5f * dt * dq.y, qq.z + 0.5f * dt * dq.z});
           f3 pp = com - qrot(qq, f3{in[1], in[2], in[3]});
           WSYNC();
-          if (fwake[b] <= 0.f) {  // asleep: the pose stays bit for bit
+          if (fw_at(b) <= 0.f) {  // asleep: the pose stays bit for bit
             pp = f3{pt[0], pt[1], pt[2]};
             qq = q4{pt[3], pt[4], pt[5], pt[6]};
           }
-          if (c == 0 && frow) lds_pose_store(pt, pose_t{pp, qq});
-          if (c == 0 && frow && live && last) {
+          if (c == 0) lds_pose_store(pt, pose_t{pp, qq});
+          if (c == 0 && live && last) {
             SOA(S.free_s, 13 * b) = pp.x; SOA(S.free_s, 13 * b + 1) = pp.y; SOA(S.free_s, 13 * b + 2) = pp.z;
             SOA(S.free_s, 13 * b + 3) = qq.w; SOA(S.free_s, 13 * b + 4) = qq.x; SOA(S.free_s, 13 * b + 5) = qq.y; SOA(S.free_s, 13 * b + 6) = qq.z;
           }
@@ -2986,15 +3037,22 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       qd_c = vj;
     }
     vfree_c = freel ? v_c : 0.f;
-    // sleep counters: run down while the body is calm and no disturber touches it, restart otherwise
+    // sleep counters: run down while the body is calm and no disturber touches it, restart otherwise. Whether a body is calm is
+    // seen by its own row; every lane of the env keeps the counters
+    bool calm_l[2] = {false, false};
+#pragma unroll
+    for (int bl = 0; bl < 2; bl++) {
+      if (bl >= nfr) break;
+      const int base = fcol0 + 6 * bl;
+      const f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)}, ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
+      const float* pt = L + S16_PT + 7 * (S16_PT_FREE + fb0 + bl);
+      calm_l[bl] = norm_energy(fin[bl], vv, ww, q4{pt[3], pt[4], pt[5], pt[6]}) < M.sleep_threshold;
+    }
 #pragma unroll
     for (int b = 0; b < S16_MAX_FREE; b++) {
       if (b >= nf) break;
-      const int base = fcol0 + 6 * b;
-      const f3 vv = f3{gbc(v_c, base), gbc(v_c, base + 1), gbc(v_c, base + 2)}, ww = f3{gbc(v_c, base + 3), gbc(v_c, base + 4), gbc(v_c, base + 5)};
-      const float* pt = L + S16_PT + 7 * (S16_PT_FREE + b);
-      bool calm = norm_energy(fin[b], vv, ww, q4{pt[3], pt[4], pt[5], pt[6]}) < M.sleep_threshold;
-      if constexpr (NR > 1) calm = env_bci(calm ? 1 : 0, 16) != 0;  // (as the free bodies' row sees it: every lane of the env keeps the counters)
+      bool calm = (b & 1) ? calm_l[1] : calm_l[0];
+      if constexpr (NR > 1) calm = env_bci(calm ? 1 : 0, 16 * (1 + (b >> 1))) != 0;  // (from the row that holds body b)
       if (fwake[b] > 0.f) {
         fwake[b] = (calm && M.sleep_threshold > 0.f && !((fdist >> b) & 1u)) ? fwake[b] - dt : MSSIM_WAKE_TIME;
         if (fwake[b] <= 0.f) {
@@ -3017,7 +3075,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         SOA(S.free_s, 13 * fb_id + 7 + fk) = v_c;
         if (fk < 3) SOA(S.free_force, 3 * fb_id + fk) = 0.f;
       }
-      if (c < nf && lead && live) SOA(S.free_wake, c) = c == 0 ? fwake[0] : fwake[1];
+      if (c < nf && lead && live) SOA(S.free_wake, c) = fw_at(c);
       if (c == 0 && lead && live) S.pcm_tick[e] = pcm_tick;
       // body velocities about O with the new subspaces
       sv6 nS = sv6{f3{0, 0, 0}, f3{0, 0, 0}};

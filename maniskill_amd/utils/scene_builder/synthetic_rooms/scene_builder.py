@@ -91,13 +91,14 @@ OBJECTS = {
     "block": [((-0.04, -0.04, 0.0), (0.04, 0.04, 0.08)), ((-0.015, -0.015, 0.08), (0.015, 0.015, 0.11))],                    # a cube with a knob
     "bar": [((-0.12, -0.015, 0.0), (0.12, 0.015, 0.03)), ((-0.12, -0.04, 0.0), (-0.09, 0.04, 0.03)), ((0.09, -0.04, 0.0), (0.12, 0.04, 0.03))],  # an I
 }
-# layout -> its two objects: (object, (x, y, z) of the object frame -- on a piece of furniture or on the floor in the robot's way --, yaw)
+# layout -> its objects: (object, (x, y, z) of the object frame -- on a piece of furniture or on the floor in the robot's way --, yaw).
+# `SyntheticRooms` builds the first two of a layout, `SyntheticRoomsCrowded` all four.
 LAYOUT_OBJECTS = {
-    "study": [("mug", (1.05, -0.25, 0.75), 0.3), ("bracket", (0.15, 0.05, 0.0), 1.2)],
-    "corridor": [("tee", (1.85, 0.5, 0.9), 0.0), ("dumbbell", (0.6, 0.0, 0.0), 1.5708)],
-    "kitchen": [("tray", (0.6, 0.1, 0.9), 0.4), ("wedge", (-0.1, 0.35, 0.0), 2.0)],
-    "lab": [("post", (-0.6, 0.8, 0.9), 0.0), ("step", (-0.75, -0.5, 0.0), 0.2)],
-    "hall": [("block", (-0.55, 0.0, 0.0), 0.5), ("bar", (0.9, -0.35, 0.0), 1.0)],
+    "study": [("mug", (1.05, -0.25, 0.75), 0.3), ("bracket", (0.15, 0.05, 0.0), 1.2), ("block", (1.2, 0.3, 0.75), 0.8), ("step", (-0.3, -0.45, 0.0), 0.4)],
+    "corridor": [("tee", (1.85, 0.5, 0.9), 0.0), ("dumbbell", (0.6, 0.0, 0.0), 1.5708), ("mug", (2.05, 0.52, 0.9), 1.0), ("wedge", (1.2, -0.15, 0.0), 0.3)],
+    "kitchen": [("tray", (0.6, 0.1, 0.9), 0.4), ("wedge", (-0.1, 0.35, 0.0), 2.0), ("post", (0.4, -1.5, 0.9), 0.0), ("bar", (-0.2, -0.45, 0.0), 0.9)],
+    "lab": [("post", (-0.6, 0.8, 0.9), 0.0), ("step", (-0.75, -0.5, 0.0), 0.2), ("tray", (0.0, -0.3, 0.7), 0.0), ("tee", (-1.0, 0.1, 0.0), 1.1)],
+    "hall": [("block", (-0.55, 0.0, 0.0), 0.5), ("bar", (0.9, -0.35, 0.0), 1.0), ("dumbbell", (-0.9, 0.5, 0.0), 0.2), ("bracket", (0.3, -1.0, 0.0), 2.2)],
 }
 
 
@@ -140,10 +141,12 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
     init_configs = [0, 1]  # which of a layout's start arrangements
     robot_initial_pose = sapien.Pose()
 
-    def __init__(self, env, robot_init_qpos_noise=0.02, movable_objects=True):
+    def __init__(self, env, robot_init_qpos_noise=0.02, movable_objects=2):
         super().__init__(env, robot_init_qpos_noise)
         self._mesh_dir = tempfile.mkdtemp(prefix="synthetic_rooms_")
-        self.movable = movable_objects  # False: scenery only (the round-2 scenes: 15 velocity components per env)
+        # movable objects per layout: 0 = scenery only (15 velocity components per env with the Fetch), 2 (27: two 16-lane rows per
+        # env in the control-step kernel), up to 4 (39: four rows)
+        self.movable = int(movable_objects)
 
     def build(self, build_config_idxs: List[int] = None):
         n = self.env.num_envs
@@ -182,7 +185,7 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
             envs = [e for e, i in enumerate(self.build_config_idxs) if i == li]
             if not envs or not self.movable:
                 continue
-            for oname, xyz, yaw in LAYOUT_OBJECTS[name]:
+            for oname, xyz, yaw in LAYOUT_OBJECTS[name][: self.movable]:
                 path = os.path.join(self._mesh_dir, f"{oname}.obj")
                 if not os.path.exists(path):
                     _write_parts_obj(path, OBJECTS[oname])
@@ -225,4 +228,12 @@ class SyntheticRoomsStaticSceneBuilder(SyntheticRoomsSceneBuilder):
     """the same rooms without the movable objects: scenery only (15 velocity components per env with the Fetch)"""
 
     def __init__(self, env, robot_init_qpos_noise=0.02):
-        super().__init__(env, robot_init_qpos_noise, movable_objects=False)
+        super().__init__(env, robot_init_qpos_noise, movable_objects=0)
+
+
+@register_scene_builder("SyntheticRoomsCrowded")
+class SyntheticRoomsCrowdedSceneBuilder(SyntheticRoomsSceneBuilder):
+    """four movable objects per layout (39 velocity components per env with the Fetch: a whole wave per env)"""
+
+    def __init__(self, env, robot_init_qpos_noise=0.02):
+        super().__init__(env, robot_init_qpos_noise, movable_objects=4)

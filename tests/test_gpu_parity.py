@@ -646,7 +646,7 @@ def test_per_env_shape_types_match_oracle():
 
 def test_create_rejects_what_the_kernel_cannot_hold():
     """`mssim_create` fails with an error string -- it never falls back to another path -- for a model that does not fit
-    the control-step kernel's tables (three free bodies next to the Panda: 27 velocity components for 16 lanes) and for
+    the control-step kernel's tables (seven free bodies: six is what four 16-lane rows hold next to the joints) and for
     per-env rows that make no sense (a hull reference outside hull_verts, a plane as a per-env shape type)"""
     from maniskill_amd.model import geom
     from maniskill_amd.model.compile import ActorRecord, ShapeRecord
@@ -655,7 +655,7 @@ def test_create_rejects_what_the_kernel_cannot_hold():
     b = SceneModelBuilder()
     b.set_articulation(panda_record())
     b.add_actor(table_record())
-    for k in range(3):
+    for k in range(7):
         b.add_actor(cube_record(name=f"c{k}", p=(0.1 * k, 0.2, 0.02)))
     with pytest.raises(Exception) as ei:
         too_big = b.compile()
