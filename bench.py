@@ -72,8 +72,8 @@ def committed_counters(kernel_key, protocol):
     try:
         with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
             d = json.load(f)
-        if d.get("kernel_source_sha") == kernel_source_sha() and d.get("protocol") == protocol:
-            for name, v in d["kernels"].items():  # template arguments vary (k_solve16<9, 1>): match by prefix
+        if d.get("kernel_source_sha") == kernel_source_sha():
+            for name, v in d["protocols"][protocol]["kernels"].items():  # template arguments vary (k_solve16<9, 1>): match by prefix
                 if name.startswith(kernel_key):
                     traffic, raw = v["hbm_bytes_per_launch"], v["hbm_bytes_per_launch_raw"]
     except Exception:
@@ -81,8 +81,8 @@ def committed_counters(kernel_key, protocol):
     try:
         with open(os.path.join(PROFILE_DIR, "sq_counters.json")) as f:
             d = json.load(f)
-        if d.get("kernel_source_sha") == kernel_source_sha() and d.get("protocol") == protocol:
-            valu = d["counters"]["SQ_INSTS_VALU"]["per_launch"]
+        if d.get("kernel_source_sha") == kernel_source_sha():
+            valu = d["protocols"][protocol]["counters"]["SQ_INSTS_VALU"]["per_launch"]
     except Exception:
         pass
     return traffic, raw, valu
@@ -222,10 +222,19 @@ def main():
             raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the simulation core is HIP-only (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # MSSIM_BENCH_REHEARSE=1: a dry run of the multi-rank path on a box with ONE GPU (every rank on cuda:0, gloo for the barrier and
+    # the max over ranks, no gather): launch, build handshake, seed sharding, timing protocol and the JSON line are the real
+    # ones, the number is not a measurement of anything (the ranks share a GPU) and the line says so
+    rehearse = os.environ.get("MSSIM_BENCH_REHEARSE") == "1" and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+            args.no_gather = True
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     def barrier():
         if world > 1:
@@ -236,7 +245,7 @@ def main():
     global_seeds = [2022 + i for i in range(n * world)]
     torch.manual_seed(2022 + rank)  # reproducible action stream (A/B comparisons between builds)
     set_env_index_offset(rank * n)  # this rank holds envs [rank * n, (rank + 1) * n) of the global run
-    env = gym.make(args.env_id, num_envs=n, sim_backend=f"cuda:{local_rank}", sim_config=dict(control_freq=args.control_freq))
+    env = gym.make(args.env_id, num_envs=n, sim_backend=f"cuda:{dev_index}", sim_config=dict(control_freq=args.control_freq))
     base = env.unwrapped
     seeds = shard_seeds(global_seeds, rank, world)
     obs, _ = env.reset(seed=seeds)
@@ -256,7 +265,7 @@ def main():
         env.reset(seed=seeds)
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -344,6 +353,8 @@ def main():
                 "ms_per_step": round(elapsed_gathered / args.steps * 1e3, 4),
                 "what": f"second timed region of {args.steps} steps in the same run: {other}",
             }
+        if rehearse:
+            out["rehearsal"] = f"{world} ranks sharing one GPU (MSSIM_BENCH_REHEARSE=1): the multi-rank code path, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             env.close()
             try:

@@ -26,6 +26,9 @@ def clean_copy(name, out=None):
 f = newest("stats/*kernel_stats.csv") or newest("stats/*/*kernel_stats.csv")
 if f:
     shutil.copy(f, os.path.join(dst, "bench_kernel_stats.csv"))
+f = newest("stats20/*kernel_stats.csv") or newest("stats20/*/*kernel_stats.csv")
+if f:  # (python bench.py --steps 20 --warmup 5: what the driver's round-end run executes)
+    shutil.copy(f, os.path.join(dst, "bench_kernel_stats_steps20.csv"))
 if os.path.exists(os.path.join(src, "pmc_summary.json")):
     shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "pmc_summary.json"))
 for name in ("bench_matrix.log", "block_times.log", "cpu_config1.log", "bench_series.log"):
@@ -34,13 +37,14 @@ clean_copy("phase_pick.log", "phase_clocks_pickcube.log")
 
 if os.path.exists(os.path.join(src, "sq_counters.json")):
     shutil.copy(os.path.join(src, "sq_counters.json"), os.path.join(dst, "sq_counters.json"))
-out = json.load(open(os.path.join(dst, "sq_counters.json")))["counters"] if os.path.exists(os.path.join(dst, "sq_counters.json")) else {}
+PROTO = "PickCube-v1 envs=4096 control_freq=20 steps=1000 warmup=5"
+out = json.load(open(os.path.join(dst, "sq_counters.json")))["protocols"].get(PROTO, {}).get("counters", {}) if os.path.exists(os.path.join(dst, "sq_counters.json")) else {}
 
 # bench line with the PMC traffic of the dominant kernel
 p = os.path.join(src, "bench.json.log")
 if os.path.exists(p):
     d = json.loads([l for l in open(p) if l.startswith("{")][-1])
-    ks = json.load(open(os.path.join(dst, "pmc_summary.json")))["kernels"]
+    ks = json.load(open(os.path.join(dst, "pmc_summary.json")))["protocols"][PROTO]["kernels"]
     key = [k for k in ks if k.startswith("k_solve16<")]
     if key:
         d["roofline"]["traffic"] = ks[key[0]]["hbm_bytes_per_launch"]

@@ -21,9 +21,17 @@ for d in ("pmc_ic", "pmc_sq"):
             a[1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         out[k] = dict(launches=n, per_launch=v / n)
-json.dump(dict(kernel_source_sha=kernel_source_sha(), protocol=protocol,
-               note="rocprofv3 --pmc, control-step kernel k_solve16<9, TASK> (whole env.step), bench.py with the flags of `protocol`; "
-                    "two passes (instruction counts + instruction cache, SQ cycles); SQ_*_CYCLES / SQ_WAIT_* are quad-cycles summed over waves",
-               counters=out), open(out_path, "w"), indent=1)
+doc = dict(kernel_source_sha=kernel_source_sha(), protocols={})
+if os.path.exists(out_path):
+    try:
+        old = json.load(open(out_path))
+        if old.get("kernel_source_sha") == doc["kernel_source_sha"]:
+            doc["protocols"] = old.get("protocols", {})
+    except Exception:
+        pass
+doc["note"] = ("rocprofv3 --pmc, control-step kernel k_solve16<9, TASK> (whole env.step), bench.py with the flags of the protocol; "
+               "two passes (instruction counts + instruction cache, SQ cycles); SQ_*_CYCLES / SQ_WAIT_* are quad-cycles summed over waves")
+doc["protocols"][protocol] = dict(counters=out)
+json.dump(doc, open(out_path, "w"), indent=1)
 for k, v in sorted(out.items()):
     print(k, f"{v['per_launch']:.4g}")
