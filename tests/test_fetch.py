@@ -188,7 +188,8 @@ def test_rooms_carry_their_own_movable_objects():
         env.step(hold)
     # at rest on their furniture / on the floor (1 s): nothing falls through a table top, nothing sinks into the ground
     for name, actor in sb.movable_objects.items():
-        z0 = next(xyz[2] for lay in sb_objects().values() for o, xyz, _ in lay if o == name.split("_", 1)[1])
+        env_i, oname = int(name.split("_", 1)[0][4:]), name.split("_", 1)[1]
+        z0 = next(xyz[2] for o, xyz, _ in sb_objects()[sb.build_configs[sb.build_config_idxs[env_i]]] if o == oname)
         assert float((actor.pose.p[:, 2] - z0).abs().max()) < 1.5e-3, (name, actor.pose.p[:, 2], z0)
         assert float(actor.linear_velocity.abs().max()) < 5e-3, name
     # the state dict lists every object with the rows of its own envs; restoring it restores the objects
