@@ -13,7 +13,10 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 mode = sys.argv[4] if len(sys.argv) > 4 else "pd_joint_delta_pos"
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 torch.manual_seed(seed)
-env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode=mode, **({"robot_uids": os.environ["MS_ROBOT"]} if os.environ.get("MS_ROBOT") else {}))  # (MS_ROBOT=fetch with Empty-v1)
+extra = {"robot_uids": os.environ["MS_ROBOT"]} if os.environ.get("MS_ROBOT") else {}  # (MS_ROBOT=fetch with Empty-v1)
+if os.environ.get("MS_SCENE_BUILDER"):  # (MS_SCENE_BUILDER=SyntheticRoomsCrowded with SceneManipulation-v1)
+    extra["scene_builder_cls"] = os.environ["MS_SCENE_BUILDER"]
+env = gym.make(env_id, num_envs=N, obs_mode="state", control_mode=mode, **extra)
 base = env.unwrapped
 adim = base.single_action_space.shape[0]
 env.reset(seed=seed)

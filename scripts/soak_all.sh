@@ -11,4 +11,5 @@ run PushCube-v1 4096 3000 pd_joint_delta_pos
 run PegInsertionSide-v1 2048 3000 pd_joint_delta_pos
 MS_ROBOT=fetch run Empty-v1 1024 2000 pd_joint_delta_pos
 run SceneManipulation-v1 1024 3000 pd_joint_delta_pos
+MS_SCENE_BUILDER=SyntheticRoomsCrowded run SceneManipulation-v1 1024 2000 pd_joint_delta_pos
 grep -c "soak ok" $O; grep -n "FAILED\|Error\|assert" $O | head
