@@ -880,6 +880,27 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       g_create_error = "convex hull vertex count out of range";
       return 5;
     }
+  // tables the kernels index without checks (a malformed model gets an error string here, not an out-of-bounds device read)
+  if (d->n_tri_node >= (1 << 17) || d->n_tri >= (1 << 24)) { g_create_error = "triangle meshes: more than 131071 BVH nodes or 16777215 triangles (the shape word packs the root node into 17 bits)"; return 5; }
+  for (int nd = 0; nd < d->n_tri_node; nd++)
+    for (int c = 0; c < 16; c++) {
+      const float* nb = d->tri_bvh + (size_t)nd * 112;
+      if (!(nb[6 * c] <= nb[6 * c + 3])) continue;  // (min > max: no child)
+      int32_t ref;
+      std::memcpy(&ref, nb + 96 + c, 4);
+      if (ref >= 0 ? ref >= d->n_tri_node : ~ref >= d->n_tri) { g_create_error = "tri_bvh: a child reference points outside the node / triangle tables"; return 5; }
+    }
+  if (d->n_env_shape > 0)
+    for (int s = 0; s < d->n_shape; s++)
+      if (d->shape_env_slot[s] >= d->n_env_shape) { g_create_error = "shape_env_slot names a slot beyond n_env_shape"; return 5; }
+  if (d->n_env_free > 0)
+    for (int b = 0; b < d->n_free; b++)
+      if (d->free_env_slot[b] >= d->n_env_free) { g_create_error = "free_env_slot names a slot beyond n_env_free"; return 5; }
+  for (int s = 0; s < d->n_shape; s++)
+    if (d->shape_type[s] == MSSIM_SHAPE_CONVEX && (d->shape_hull[2 * s] < 0 || d->shape_hull[2 * s] + d->shape_hull[2 * s + 1] > d->n_hull_verts)) {
+      g_create_error = "convex hull: vertex range outside hull_verts";
+      return 5;
+    }
   mssim_sim* S = new mssim_sim();
   S->device = device;
   S->N = num_envs;
@@ -895,7 +916,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   for (int j = 0; j < n; j++)
     for (int i = d->dof_parent[j]; i >= 0; i = d->dof_parent[i]) anc[j] |= 1u << i;
   int rc = 0;
-#define UP(field, count) if ((rc = upload(S, d->field, (size_t)(count), &M.field))) { mssim_destroy(S); return rc; }
+#define UP(field, count) if ((rc = upload(S, d->field, (size_t)(count), &M.field))) { g_create_error = S->err; mssim_destroy(S); return rc; }
   UP(dof_parent, n) UP(dof_type, n) UP(body_gravity, n) UP(tendon_dof, 2 * d->n_tendon) UP(link_body, d->n_link) UP(free_gravity, d->n_free)
   UP(dof_frame, 7 * n) UP(dof_axis, 3 * n) UP(dof_limit, 2 * n) UP(dof_drive, 4 * n) UP(dof_armature, n) UP(body_inertial, 10 * n)
   UP(tendon_param, 5 * d->n_tendon) UP(link_frame, 7 * d->n_link) UP(free_inertial, 10 * d->n_free) UP(free_damping, 2 * d->n_free)
@@ -1011,11 +1032,11 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       }
     }
     if (hv.size() / 3 >= (1u << 17)) { g_create_error = "too many hull vertices"; mssim_destroy(S); return 8; }
-    if ((rc = upload(S, sh.data(), sh.size(), &M.shape_hull)) || (rc = upload(S, hv.data(), hv.size(), &M.hull_verts))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, sh.data(), sh.size(), &M.shape_hull)) || (rc = upload(S, hv.data(), hv.size(), &M.hull_verts))) { g_create_error = S->err; mssim_destroy(S); return rc; }
   }
-  if ((rc = upload(S, d->shape_body_kind, (size_t)ns, &M.shape_kind))) { mssim_destroy(S); return rc; }
-  if ((rc = upload(S, d->shape_body_index, (size_t)ns, &M.shape_index))) { mssim_destroy(S); return rc; }
-  if ((rc = upload(S, anc.data(), (size_t)n, &M.dof_anc))) { mssim_destroy(S); return rc; }
+  if ((rc = upload(S, d->shape_body_kind, (size_t)ns, &M.shape_kind))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+  if ((rc = upload(S, d->shape_body_index, (size_t)ns, &M.shape_index))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+  if ((rc = upload(S, anc.data(), (size_t)n, &M.dof_anc))) { g_create_error = S->err; mssim_destroy(S); return rc; }
   {
     std::vector<float> ctr(3 * (ns > 0 ? ns : 1), 0.f);
     for (int s2 = 0; s2 < ns; s2++) {
@@ -1029,7 +1050,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
                              {2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
       for (int i = 0; i < 3; i++) ctr[3 * s2 + i] = f[i] + R[i][0] * b[0] + R[i][1] * b[1] + R[i][2] * b[2];
     }
-    if ((rc = upload(S, ctr.data(), (size_t)3 * ns, &M.shape_center))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, ctr.data(), (size_t)3 * ns, &M.shape_center))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     // oriented bounding boxes for the cull (shape frame axes, centred at the bound centre)
     std::vector<float> half(3 * (ns > 0 ? ns : 1), 0.f);
     for (int s2 = 0; s2 < ns; s2++) {
@@ -1063,8 +1084,8 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       if (d->shape_type[s2] != MSSIM_SHAPE_CONVEX && d->shape_type[s2] != MSSIM_SHAPE_PLANE && d->shape_type[s2] != MSSIM_SHAPE_TRIMESH)
         for (int k = 0; k < 3; k++) h[k] += std::fabs(b[k]);
     }
-    if ((rc = upload(S, half.data(), (size_t)3 * ns, &M.shape_half))) { mssim_destroy(S); return rc; }
-    if ((rc = upload(S, d->tri_soup, (size_t)12 * d->n_tri, &M.tri_soup)) || (rc = upload(S, d->tri_bvh, (size_t)112 * d->n_tri_node, &M.tri_bvh))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, half.data(), (size_t)3 * ns, &M.shape_half))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+    if ((rc = upload(S, d->tri_soup, (size_t)12 * d->n_tri, &M.tri_soup)) || (rc = upload(S, d->tri_bvh, (size_t)112 * d->n_tri_node, &M.tri_bvh))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     // packed constant records (one or two cache lines per joint / shape instead of ~10 arrays)
     auto fbits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     std::vector<float> sp(24 * (size_t)(ns > 0 ? ns : 1), 0.f);
@@ -1080,7 +1101,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       r[21] = fbits((d->n_env_shape > 0) ? d->shape_env_slot[s2] : -1);
       r[22] = d->shape_material[4 * s2 + 3];  // torsional patch radius
     }
-    if ((rc = upload(S, sp.data(), sp.size(), &M.shape_pack))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, sp.data(), sp.size(), &M.shape_pack))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     S->h_dof_pack.assign(32 * (size_t)(n > 0 ? n : 1), 0.f);
     for (int j = 0; j < n; j++) {
       float* r = &S->h_dof_pack[32 * (size_t)j];
@@ -1092,7 +1113,7 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
       for (int k = 0; k < 10; k++) r[20 + k] = d->body_inertial[10 * j + k];
       r[30] = fbits(d->body_gravity[j]);
     }
-    if ((rc = upload(S, S->h_dof_pack.data(), S->h_dof_pack.size(), &M.dof_pack))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, S->h_dof_pack.data(), S->h_dof_pack.size(), &M.dof_pack))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     S->d_dof_pack = const_cast<float*>(M.dof_pack);
   }
   {
@@ -1121,21 +1142,22 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
   DevState& D = S->S;
   D.N = num_envs;
   const size_t N = (size_t)num_envs;
-#define AL(field, count) if ((rc = dalloc(S, (size_t)(count) * N, &D.field))) { mssim_destroy(S); return rc; }
+#define AL(field, count) if ((rc = dalloc(S, (size_t)(count) * N, &D.field))) { g_create_error = S->err; mssim_destroy(S); return rc; }
   AL(root, 7) AL(q, n) AL(qd, n) AL(qt, n) AL(qdt, n) AL(qf, n) AL(qacc, n)
   AL(free_s, 13 * d->n_free) AL(free_force, 3 * d->n_free) AL(kin, 7 * d->n_kin) AL(free_wake, d->n_free)
   AL(bodypose, 7 * n) AL(bodyvel, 6 * n) AL(bodyaux, 6 * n)
   AL(pair_cnt, d->n_pair) AL(pair_imp, 3 * d->n_pair)
-  if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN_(S->rows_per_env), &D.rows))) { mssim_destroy(S); return rc; }
+  if ((rc = dalloc(S, (size_t)num_envs * S16_ROWS_GLB * S16_ROWLEN_(S->rows_per_env), &D.rows))) { g_create_error = S->err; mssim_destroy(S); return rc; }
   AL(overflow, 1)
   AL(hit_list, 1 + MAXC)
   AL(pcm_tick, 1)
-  if ((rc = dalloc(S, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN, &D.pcm))) { mssim_destroy(S); return rc; }
-  HIPCHK(S, hipMemset(D.pcm, 0xFF, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float)));  // pair = -1: every slot empty
+  if ((rc = dalloc(S, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN, &D.pcm))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+#define HIPCHK_NEW(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(_e); mssim_destroy(S); return 100 + (int)_e; } } while (0)
+  HIPCHK_NEW(hipMemset(D.pcm, 0xFF, (size_t)num_envs * MSSIM_PCM_SLOTS * S16_PCM_LEN * sizeof(float)));  // pair = -1: every slot empty
   {
     const size_t nw = (size_t)4 * (d->n_pair > 0 ? d->n_pair : 1) * N * 4;
-    if ((rc = dalloc(S, nw, &D.warm))) { mssim_destroy(S); return rc; }
-    HIPCHK(S, hipMemset(D.warm, 0xFF, nw * sizeof(float)));  // stamp -1: nothing to start from
+    if ((rc = dalloc(S, nw, &D.warm))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+    HIPCHK_NEW(hipMemset(D.warm, 0xFF, nw * sizeof(float)));  // stamp -1: nothing to start from
   }
   {
     // clearance of every (convex shape, mesh) pair (mssim_solve16.h stage T0); NaN bit pattern = no clearance known
@@ -1143,10 +1165,11 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
     int n_mesh_pair = 0;
     for (int p = 0; p < d->n_pair; p++)
       if (d->shape_type[d->pair_shape[2 * p + 1]] == MSSIM_SHAPE_TRIMESH) slot[p] = n_mesh_pair++;
-    if ((rc = upload(S, slot.data(), slot.size(), &M.pair_mesh_slot))) { mssim_destroy(S); return rc; }
+    if ((rc = upload(S, slot.data(), slot.size(), &M.pair_mesh_slot))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     const size_t nc = (size_t)4 * (n_mesh_pair > 0 ? n_mesh_pair : 1) * N;
-    if ((rc = dalloc(S, nc, &D.tri_clear))) { mssim_destroy(S); return rc; }
-    HIPCHK(S, hipMemset(D.tri_clear, 0xFF, nc * sizeof(float)));
+    if ((rc = dalloc(S, nc, &D.tri_clear))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+    HIPCHK_NEW(hipMemset(D.tri_clear, 0xFF, nc * sizeof(float)));
+#undef HIPCHK_NEW
   }
 #undef AL
   // identity quaternions

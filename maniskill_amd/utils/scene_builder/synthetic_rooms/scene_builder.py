@@ -148,6 +148,11 @@ class SyntheticRoomsSceneBuilder(SceneBuilder):
         # env in the control-step kernel), up to 4 (39: four rows)
         self.movable = int(movable_objects)
 
+    def __del__(self):  # (the scratch directory of generated meshes goes with the builder)
+        import shutil
+
+        shutil.rmtree(getattr(self, "_mesh_dir", ""), ignore_errors=True)
+
     def build(self, build_config_idxs: List[int] = None):
         n = self.env.num_envs
         if build_config_idxs is None:

@@ -680,7 +680,33 @@ def test_create_rejects_what_the_kernel_cannot_hold():
     with pytest.raises(RuntimeError, match="pair_shape"):
         MssimSystem(device="cuda:0").gpu_init(model, N)
     pairs[:] = keep_pairs
+    # index tables the kernels read unchecked: a slot beyond the env tables, a hull range outside hull_verts, a BVH reference
+    # outside its tables (round-2 advisor finding: these used to become out-of-bounds device reads)
+    slots = model.arrays["shape_env_slot"]
+    keep_slots = slots.copy()
+    slots[int(np.argmax(slots >= 0))] = 77
+    with pytest.raises(RuntimeError, match="shape_env_slot"):
+        MssimSystem(device="cuda:0").gpu_init(model, N)
+    slots[:] = keep_slots
+    hulls = model.arrays["shape_hull"]
+    keep_hulls = hulls.copy()
+    k = int(np.argmax(model.arrays["shape_type"] == 5))
+    hulls[k, 0] = model.arrays["hull_verts"].shape[0] - 2
+    with pytest.raises(RuntimeError, match="hull"):
+        MssimSystem(device="cuda:0").gpu_init(model, N)
+    hulls[:] = keep_hulls
     MssimSystem(device="cuda:0").gpu_init(model, N)  # (the untouched model is fine)
+    from tests.test_oracle_contacts import _mesh_scene
+
+    mesh_model = _mesh_scene()
+    refs = mesh_model.arrays["tri_bvh"][:, 96:].view(np.int32)
+    keep_refs = refs.copy()
+    leaf = np.argwhere((refs < -1) & (refs != -2**31))  # (a real leaf: -2**31 marks an empty child)
+    refs[leaf[0][0], leaf[0][1]] = ~np.int32(10_000_000)  # a triangle that does not exist
+    with pytest.raises(RuntimeError, match="tri_bvh"):
+        MssimSystem(device="cuda:0").gpu_init(mesh_model, 2)
+    refs[:] = keep_refs
+    MssimSystem(device="cuda:0").gpu_init(mesh_model, 2)
 
 
 def test_triangle_mesh_matches_oracle():
