@@ -6,7 +6,7 @@
 // component of a free body), so N = 4096 is 1024 waves and the long serial chains become
 //   * tree recursions  -> sums over ancestor / descendant bit sets of per-body quantities staged
 //                         in LDS; FK by pointer jumping,
-//   * dense 9x9 algebra-> Gauss-Jordan with one matrix row per lane, pivot row broadcast via LDS,
+//   * dense 9x9 algebra-> Gauss-Jordan with one matrix row per lane, pivot row broadcast by DPP row_newbcast,
 //   * Gauss-Seidel row -> one multiply, a DPP row-rotate all-reduce, a clamp, one FMA.
 //
 // k_solve16<NDOF, TASK, TRI, NR>: one launch runs a whole control step. A wave keeps its envs' state in registers /
@@ -66,7 +66,6 @@
 #define S16_F (S16_U + 288)    // [16][6]
 #define S16_IC (S16_U + 384)   // [16][10]
 #define S16_MAT (S16_U + 544)  // [16][16]
-#define S16_PIV (S16_U + 800)  // [32] pivot row broadcast
 #define S16_LIMW (S16_U)       // [16][16] W = A^-1 J^T of the joint-limit rows
 #define S16_CS (S16_U + 256)   // [MAXC][16] block scalars of every contact: 1/d0 bias+ bias- mu | 1/d1 k10 1/d2 k20 | k21 lam0 lam1 lam2 | pair
 #define S16_REGC 12            // first contacts of an env: this lane's J / W entries and the multipliers stay in registers
@@ -311,6 +310,36 @@ MS_DEV void rot_gather(const float* row, int c, float (&Irot)[16]) {
   } else if constexpr (K < 16) {
     Irot[K] = row[__builtin_amdgcn_update_dpp(0, c, 0x120 + K, 0xF, 0xF, false)];
     rot_gather<K + 1>(row, c, Irot);
+  }
+}
+// One pivot of the Gauss-Jordan elimination of k_solve16 (matrix row per lane, env per 16-lane DPP row), see the call site.
+template <int K, int NA>
+MS_DEV void gj_eliminate(float (&A)[NA], float (&I)[16], float& diag, int c, int n) {
+  if constexpr (K < NA) {
+    if (K >= n) return;
+    const float inv = rcp_f(dpp_f<0x150 + K>(A[K]));  // row_newbcast:K
+    const float nfac = c == K ? 0.f : -A[K] * inv;
+    diag = c == K ? inv : diag;
+#pragma unroll
+    for (int j = K + 1; j < NA; j++) A[j] = fmaf(dpp_f<0x150 + K>(A[j]), nfac, A[j]);
+#pragma unroll
+    for (int j = 0; j < K; j++) I[j] = fmaf(dpp_f<0x150 + K>(I[j]), nfac, I[j]);
+    I[K] += nfac;
+    gj_eliminate<K + 1, NA>(A, I, diag, c, n);
+  }
+}
+
+// The joint-limit rows of one sweep of k_solve16, joints in order (see the call site): rows without a limit have lim_inv = 0 and
+// lim_lam = 0, so their d(lambda) is 0.
+template <int J, int NL>
+MS_DEV void limit_rows_pass(const float (&wj)[NL], float& v_c, float& lim_lam, float lim_side, float lim_inv, float bl, int c, int n) {
+  if constexpr (J < NL) {
+    if (J >= n) return;
+    const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
+    const float dl = dpp_f<0x150 + J>(nl - lim_lam);  // row_newbcast:J
+    lim_lam = c == J ? nl : lim_lam;
+    v_c = fmaf(wj[J], dl, v_c);
+    limit_rows_pass<J + 1, NL>(wj, v_c, lim_lam, lim_side, lim_inv, bl, c, n);
   }
 }
 MS_DEV float gbc(float x, int j) { return __shfl(x, j, 16); }
@@ -2481,32 +2510,14 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         Arow[k] = art ? (Mrow[k] + Trow[k] + (k == c ? Dj + arm : 0.f)) : (k == c ? 1.f : 0.f);
         Irow[k] = k == c ? 1.f : 0.f;
       }
+      // (division-free elimination: the pivot row stays unscaled and is broadcast inside the env's 16-lane row by
+      // DPP row_newbcast -- one v_fmac per element, no LDS round trip --; the columns left of the pivot are already zero
+      // in A and the ones right of it still zero in I, so a pivot costs NA multiply-adds; each row is divided by its
+      // own diagonal at the end.  Measured: the LDS-broadcast version of this loop was 25 % of a fresh PickCube launch)
+      float diag = 1.f;
+      gj_eliminate<0, NA>(Arow, Irow, diag, c, n);
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        if (k >= n) break;
-        WSYNC();
-        if (c == k && lead) {
-#pragma unroll
-          for (int j = 0; j < NA; j++) { L[S16_PIV + j] = Arow[j]; L[S16_PIV + NA + j] = Irow[j]; }
-        }
-        WSYNC();
-        float PA[NA], PI[NA];
-#pragma unroll
-        for (int j = 0; j < NA; j += 4) {
-          const float4 a4 = *reinterpret_cast<const float4*>(L + S16_PIV + j);
-          const float4 i4 = *reinterpret_cast<const float4*>(L + S16_PIV + NA + j);
-          PA[j] = a4.x; PA[j + 1] = a4.y; PA[j + 2] = a4.z; PA[j + 3] = a4.w;
-          PI[j] = i4.x; PI[j + 1] = i4.y; PI[j + 2] = i4.z; PI[j + 3] = i4.w;
-        }
-        const float inv = rcp_f(PA[k < NA ? k : 0]);
-        const float fac = Arow[k < NA ? k : 0] * inv;
-        const bool piv = c == k;
-#pragma unroll
-        for (int j = 0; j < NA; j++) {
-          Arow[j] = piv ? PA[j] * inv : Arow[j] - fac * PA[j];
-          Irow[j] = piv ? PI[j] * inv : Irow[j] - fac * PI[j];
-        }
-      }
+      for (int j = 0; j < NA; j++) Irow[j] *= diag;
       WSYNC();
       if (lead) L[S16_VEC + 16 + c] = rhs_c;
       WSYNC();
@@ -2897,27 +2908,22 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
       }
       PH(20);
       // joint-limit rows, after the contacts of the sweep (an articulation's internal constraints are solved after
-      // its contacts, as in PhysX); exact sequential Gauss-Seidel semantics, but only rows that change are
-      // visited: lane j evaluates its own row against the current v (J is +-1 at lane j, no reduction),
-      // each group advances to its lowest changing row >= cursor, broadcasts d(lambda), applies W.
+      // its contacts, as in PhysX); exact sequential Gauss-Seidel semantics over the joints in order: lane j evaluates
+      // its own row against the current v (J is +-1 at lane j, no reduction), d(lambda) reaches the env's lanes by DPP
+      // row_newbcast:j and each applies its entry of W. A row that does not change contributes d(lambda) = 0 exactly, so
+      // every joint is visited -- ~7 VALU instructions each, no LDS or ballot on the dependent chain (the previous
+      // version walked the changing rows only, ~800 cycles per visit: a third of the time of the slowest waves) --
+      // and the pass is skipped when no row of the wave would change.
 #ifndef EXP_NO_LIMROWS  // (timing experiments only)
       {
-        int cursor = 0;
         const float bl = use_bias ? lim_bpos : lim_bvel;
-        while (true) {
-          const float nl = fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f);
-          const bool cand = art && lim_inv > 0.f && c >= cursor && nl != lim_lam;
-          const unsigned long long bal = __ballot(cand);
-          if (bal == 0ull) break;
+        if (__any(fmaxf(lim_lam - (lim_side * v_c + bl) * lim_inv, 0.f) != lim_lam)) {
           BT_ADD(31, 1);
-          const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
-          const bool act = m16 != 0u;
-          const int j = act ? (__ffs(m16) - 1) : 0;
-          float dl = gbc(nl - lim_lam, j);
-          dl = act ? dl : 0.f;
-          if (act && c == j) lim_lam = nl;
-          if (lead) v_c = fmaf(L[S16_LIMW + 16 * j + c], dl, v_c);  // (W of a limit row is zero outside the articulation's block)
-          cursor = act ? j + 1 : 16;
+          constexpr int NL = NDOF ? NDOF : 16;
+          float wj[NL];
+#pragma unroll
+          for (int j = 0; j < NL; j++) wj[j] = (lead && j < n) ? L[S16_LIMW + 16 * j + c] : 0.f;  // (W of a limit row is zero outside the articulation's block)
+          limit_rows_pass<0, NL>(wj, v_c, lim_lam, lim_side, lim_inv, bl, c, n);
         }
       }
 #endif
