@@ -35,6 +35,7 @@ struct DevModel {
   const float *dof_frame, *dof_axis, *dof_limit, *dof_drive, *dof_armature, *body_inertial, *tendon_param, *link_frame;
   const float *free_inertial, *free_damping;
   const int *shape_type, *shape_kind, *shape_index, *shape_row, *shape_hull, *pair_shape;
+  const int* pair_packed;  // [n_pair rounded up to 128, + 128] shape a | shape b << 8 (-1 behind the last pair): what the control-step kernel's cull reads, one word per pair
   const float *shape_frame, *shape_param, *shape_material, *shape_bound, *hull_verts;
   const float* shape_center;  // [n_shape][3] bounding-sphere centre in the BODY frame (shape_frame applied)
   const float* dof_pack;      // [n_dof][32]  all per-joint constants of the cooperative kernel in one 128-byte record
@@ -1166,6 +1167,9 @@ int mssim_create(const mssim_model_desc* d, int32_t num_envs, int32_t device, ms
     for (int p = 0; p < d->n_pair; p++)
       if (d->shape_type[d->pair_shape[2 * p + 1]] == MSSIM_SHAPE_TRIMESH) slot[p] = n_mesh_pair++;
     if ((rc = upload(S, slot.data(), slot.size(), &M.pair_mesh_slot))) { g_create_error = S->err; mssim_destroy(S); return rc; }
+    std::vector<int32_t> packed((size_t)((d->n_pair + 127) / 128 * 128 + 128), -1);  // (read in chunks of 8 rounds of 16)
+    for (int p = 0; p < d->n_pair; p++) packed[p] = d->pair_shape[2 * p] | (d->pair_shape[2 * p + 1] << 8);
+    if ((rc = upload(S, packed.data(), packed.size(), &M.pair_packed))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     const size_t nc = (size_t)4 * (n_mesh_pair > 0 ? n_mesh_pair : 1) * N;
     if ((rc = dalloc(S, nc, &D.tri_clear))) { g_create_error = S->err; mssim_destroy(S); return rc; }
     HIPCHK_NEW(hipMemset(D.tri_clear, 0xFF, nc * sizeof(float)));

@@ -121,6 +121,46 @@ static_assert(S16_PT + 7 * (S16_PT_KIN_(1) + S16_MAX_KIN) <= S16_U_(1) && S16_PT
 static_assert(MSSIM_MAX_HITS == S16_MAX_HIT && MSSIM_MAX_CONTACTS == MAXC, "capacity constants out of sync with include/mssim.h");
 static_assert(MSSIM_MAX_TRI_TASKS + MSSIM_MAX_TRI_HITS <= 792 - 704, "triangle task list + candidates exceed the scratch they borrow (BSCR + KEEP)");
 
+// Timing by repetition (scripts/ab_variants.sh with -DEXP_DUP_<PHASE>): an idempotent phase is run twice, the launch gets
+// longer by what the phase costs inside the product kernel -- same physics, no clock reads, no extra waits. (A knock-out that
+// leaves a phase out changes what runs downstream; the phase clocks wait for all outstanding memory operations at every
+// read: DESIGN.md section 3 has what each of them got wrong.)
+#define EXP_DUP(flag) for (int dup_ = 0; dup_ < ((flag) ? 2 : 1); dup_++)
+#ifdef EXP_DUP_SHAPE
+#define DUP_SHAPE 1
+#else
+#define DUP_SHAPE 0
+#endif
+#ifdef EXP_DUP_CULL
+#define DUP_CULL 1
+#else
+#define DUP_CULL 0
+#endif
+#ifdef EXP_DUP_CULL1
+#define DUP_CULL1 1
+#else
+#define DUP_CULL1 0
+#endif
+#ifdef EXP_DUP_CULL2
+#define DUP_CULL2 1
+#else
+#define DUP_CULL2 0
+#endif
+#ifdef EXP_DUP_GJ
+#define DUP_GJ 1
+#else
+#define DUP_GJ 0
+#endif
+#ifdef EXP_DUP_FK
+#define DUP_FK 1
+#else
+#define DUP_FK 0
+#endif
+#ifdef EXP_DUP_IROT
+#define DUP_IROT 1
+#else
+#define DUP_IROT 0
+#endif
 // Phase timing aid (scripts/phase_clocks.py builds a separate library with -DMSSIM_PHASE_CLOCKS):
 // per-phase cycle deltas are kept in registers and flushed once at the end.
 #ifdef MSSIM_PHASE_CLOCKS
@@ -937,13 +977,8 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           }
         }
       }
-      // the pair table (sa | sb << 8 per pair) is staged in this env's clip-scratch area for the cull
-      // rounds (the area is only needed again by the box-box manifolds afterwards)
-      if (lead) {
-        int* const lp = reinterpret_cast<int*>(L + S16_NP_SCR);
-        for (int p = c; p < M.n_pair; p += 16) lp[p] = M.pair_shape[2 * p] | (M.pair_shape[2 * p + 1] << 8);
-      }
       // ---- world shape table of this env
+      EXP_DUP(DUP_SHAPE)
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const int s = cl + GW * k;
@@ -995,36 +1030,46 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
           const int tb = (int)(__float_as_uint(tb_[14]) & 7u);
           surv = !cull && !(inactive(s1a) && inactive(s1b)) && ta != SH_NONE && tb != SH_NONE;  // (SH_NONE: no shape in this env's slot)
         }
-        // survivors are compacted in place into the staged pair table (write index <= read index)
-        WSYNC();  // all reads of this round before its writes
+        // survivors in pair order into the clip-scratch area (idle until the box-box manifolds)
         const unsigned long long bal = __ballot(surv);
         const unsigned m16 = (unsigned)(bal >> (16 * g)) & 0xFFFFu;
         if (surv) reinterpret_cast<int*>(L)[S16_NP_SCR + nh + __popc(m16 & ((1u << c) - 1u))] = p | (sa << 16) | (sb << 24);
         nh += __popc(m16);
-        WSYNC();
       };
 #ifdef EXP_CULL_ROUNDS  // (timing experiments only: wrong contacts)
       const int n_pair_cull = M.n_pair < 16 * EXP_CULL_ROUNDS ? M.n_pair : 16 * EXP_CULL_ROUNDS;
 #else
       const int n_pair_cull = M.n_pair;
 #endif
+      EXP_DUP(DUP_CULL) {
+      if (dup_) { WSYNC(); nh = 0; nmesh = 0; }  // (timing by repetition)
+      // (the pair table -- sa | sb << 8 per pair, -1 behind the last -- comes straight from the model, one word per lane and
+      // round: staging it in LDS first cost six dependent L2 round trips per substep)
+      EXP_DUP(DUP_CULL1) {
+        if (dup_) { WSYNC(); nh = 0; }
+        int sab_next = lead ? M.pair_packed[c] : -1;  // (the next round's word is loaded before this round's tests)
 #pragma unroll 1
-      for (int base = 0; base < n_pair_cull; base += 16) {
-        const int p = base + c;
-        cull_round(p, (lead && p < M.n_pair) ? reinterpret_cast<const int*>(L + S16_NP_SCR)[p] : -1);  // (the lanes of an env's other rows idle through its own bookkeeping)
+        for (int base = 0; base < n_pair_cull; base += 16) {
+          const int sab = sab_next;
+          sab_next = lead ? M.pair_packed[base + 16 + c] : -1;
+          cull_round(base + c, sab);  // (the lanes of an env's other rows idle through its own bookkeeping)
+        }
       }
+      WSYNC();
       // stage 2, on the survivors only (usually one or two rounds): 15-axis separating-axis test of the two
       // shapes' oriented boxes, contact offset added to the radii. It discards the pairs whose bounding
       // spheres overlap but whose shapes are apart -- most of the hull pairs that would otherwise run a
       // full MPR only to find no contact. Survivors go to the hit list, order preserved.
-      {
+      const int nh_s1 = nh;  // survivors of stage 1
+      EXP_DUP(DUP_CULL2) {
         int nh2 = 0;
+        if (dup_) { WSYNC(); nmesh = 0; }
 #pragma unroll 1
-        for (int base = 0; base < nh; base += 16) {
+        for (int base = 0; base < nh_s1; base += 16) {
           const int idx = base + c;
           bool keep = false, mesh = false;
           int pk = 0;
-          if (idx < nh) {
+          if (idx < nh_s1) {
             pk = reinterpret_cast<const int*>(L)[S16_NP_SCR + idx];
             const float* ta_ = L + S16_NP_SHP + S16_SHP * ((pk >> 16) & 0xFF);
             const float* tb_ = L + S16_NP_SHP + S16_SHP * ((pk >> 24) & 0xFF);
@@ -1058,6 +1103,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
         nh = nh2 < S16_MAX_HIT ? nh2 : S16_MAX_HIT;
         if (!live) { nh = 0; nmesh = 0; }  // (a shadow group of the last env produces nothing: its pairs would touch that env's manifold cache twice)
       }
+      }  // EXP_DUP
       WSYNC();
       if (__any(hit_over) && hit_over && live) atomicOr(&S.overflow[e], MSSIM_OVERFLOW_HITS);
       PH(23);
@@ -2503,6 +2549,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     constexpr int NA = NDOF ? ((NDOF + 3) & ~3) : 16;
 #pragma unroll
     for (int k = 0; k < 16; k++) Irow[k] = 0.f;
+    EXP_DUP(DUP_GJ)
     for (int pass = 0; pass < 2; pass++) {
       float Arow[NA];
 #pragma unroll
@@ -2616,7 +2663,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     // lane a DPP row rotation by k delivers to lane c (taken from the rotation itself, so no convention
     // about its direction enters). Per-lane dynamic indexing goes through 16 private LDS words.
     float Irot[16];
-    {
+    EXP_DUP(DUP_IROT) {
       float* tmp = L + S16_JW + 16 * cl;
 #pragma unroll
       for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(tmp + j) = float4{Irow[j], Irow[j + 1], Irow[j + 2], Irow[j + 3]};
@@ -3005,7 +3052,7 @@ __global__ __launch_bounds__(64 * S16_WAVES) void k_solve16(DevModel M, DevState
     const pose_t rootf = lds_pose(L + S16_PT);
     pose_t nb = rootf;
     f3 naw = f3{0, 0, 0}, nan = f3{0, 0, 0};
-    {
+    EXP_DUP(DUP_FK) {
       pose_t T = pose_t{f3{0, 0, 0}, q4{1, 0, 0, 0}};
       int up = -1;
       if (art) {
